@@ -1,0 +1,181 @@
+"""Architecture description of the native transformer and its mapping from HF ``config.json``.
+
+Covers the dense families the reference converts in ``realhf/api/from_hf/{llama,qwen2,qwen3,mistral,
+gemma}.py`` plus MoE (``mixtral``, ``qwen3_moe``) through the ``n_experts`` fields. The reference's
+``ReaLModelConfig`` (``realhf/api/core/model_api.py:340``) is the analogue.
+"""
+import dataclasses
+import json
+import os
+from typing import Any, Dict, Optional
+
+
+@dataclasses.dataclass
+class ModelConfig:
+    family: str = "qwen2"
+    vocab_size: int = 151936
+    hidden_size: int = 1536
+    n_layers: int = 28
+    n_q_heads: int = 12
+    n_kv_heads: int = 2
+    head_dim: int = 128
+    intermediate_size: int = 8960
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1000000.0
+    rope_scaling: float = 1.0
+    max_position_embeddings: int = 32768
+    tie_word_embeddings: bool = True
+    qkv_bias: bool = True
+    qk_norm: bool = False  # per-head RMSNorm on q and k (Qwen3)
+    gemma_norm: bool = False  # (1 + w) RMSNorm weights and sqrt(H) embedding scale (Gemma)
+    is_critic: bool = False  # value head [1, H] instead of the LM head
+    # mixture of experts (0 = dense)
+    n_experts: int = 0
+    n_experts_per_tok: int = 0
+    moe_intermediate_size: int = 0
+    norm_topk_prob: bool = True
+    router_aux_loss_coef: float = 0.0
+    bos_token_id: Optional[int] = None
+    eos_token_id: Optional[int] = None
+    pad_token_id: Optional[int] = None
+
+    @property
+    def q_dim(self) -> int:
+        return self.n_q_heads * self.head_dim
+
+    @property
+    def kv_dim(self) -> int:
+        return self.n_kv_heads * self.head_dim
+
+    @property
+    def qkv_dim(self) -> int:
+        return self.q_dim + 2 * self.kv_dim
+
+    def n_params(self, with_embedding: bool = True) -> int:
+        H, F, L = self.hidden_size, self.intermediate_size, self.n_layers
+        per_layer = H * self.qkv_dim + (self.qkv_dim if self.qkv_bias else 0) + self.q_dim * H + 2 * H
+        if self.n_experts > 0:
+            per_layer += H * self.n_experts + self.n_experts * 3 * H * self.moe_intermediate_size
+        else:
+            per_layer += 3 * H * F
+        if self.qk_norm:
+            per_layer += 2 * self.head_dim
+        n = L * per_layer + H
+        if with_embedding:
+            n += self.vocab_size * H
+            if not self.tie_word_embeddings and not self.is_critic:
+                n += self.vocab_size * H
+        if self.is_critic:
+            n += H
+        return n
+
+    # ------------------------------------------------------------------ HF interop
+    @classmethod
+    def from_hf_dict(cls, d: Dict[str, Any], is_critic: bool = False) -> "ModelConfig":
+        mt = d.get("model_type", "qwen2")
+        H = d["hidden_size"]
+        nq = d["num_attention_heads"]
+        nkv = d.get("num_key_value_heads", nq)
+        hd = d.get("head_dim") or H // nq
+        fam_bias = {"qwen2": True, "qwen2_moe": True}
+        rs = d.get("rope_scaling") or {}
+        scaling = float(rs.get("factor", 1.0)) if rs.get("type", rs.get("rope_type")) == "linear" else 1.0
+        cfg = cls(
+            family=mt,
+            vocab_size=d["vocab_size"],
+            hidden_size=H,
+            n_layers=d["num_hidden_layers"],
+            n_q_heads=nq,
+            n_kv_heads=nkv,
+            head_dim=hd,
+            intermediate_size=d.get("intermediate_size", 4 * H),
+            rms_norm_eps=d.get("rms_norm_eps", 1e-6),
+            rope_theta=float(d.get("rope_theta", 10000.0)),
+            rope_scaling=scaling,
+            max_position_embeddings=d.get("max_position_embeddings", 32768),
+            tie_word_embeddings=bool(d.get("tie_word_embeddings", False)),
+            qkv_bias=bool(d.get("attention_bias", fam_bias.get(mt, False))),
+            qk_norm=mt in ("qwen3", "qwen3_moe"),
+            gemma_norm=mt in ("gemma", "gemma2"),
+            is_critic=is_critic,
+            n_experts=d.get("num_local_experts", d.get("num_experts", 0)) or 0,
+            n_experts_per_tok=d.get("num_experts_per_tok", 0) or 0,
+            moe_intermediate_size=d.get("moe_intermediate_size", d.get("intermediate_size", 0))
+            if (d.get("num_local_experts") or d.get("num_experts")) else 0,
+            norm_topk_prob=bool(d.get("norm_topk_prob", True)),
+            router_aux_loss_coef=float(d.get("router_aux_loss_coef", 0.0) or 0.0),
+            bos_token_id=d.get("bos_token_id"),
+            eos_token_id=d.get("eos_token_id") if not isinstance(d.get("eos_token_id"), list) else d["eos_token_id"][0],
+            pad_token_id=d.get("pad_token_id"),
+        )
+        return cfg
+
+    @classmethod
+    def from_pretrained(cls, path: str, is_critic: bool = False) -> "ModelConfig":
+        with open(os.path.join(path, "config.json")) as f:
+            return cls.from_hf_dict(json.load(f), is_critic=is_critic)
+
+    def to_hf_dict(self) -> Dict[str, Any]:
+        arch = {
+            "qwen2": "Qwen2ForCausalLM", "qwen3": "Qwen3ForCausalLM", "llama": "LlamaForCausalLM",
+            "mistral": "MistralForCausalLM", "gemma": "GemmaForCausalLM", "mixtral": "MixtralForCausalLM",
+            "qwen3_moe": "Qwen3MoeForCausalLM", "qwen2_moe": "Qwen2MoeForCausalLM",
+        }.get(self.family, "Qwen2ForCausalLM")
+        d = {
+            "architectures": [arch],
+            "model_type": self.family,
+            "vocab_size": self.vocab_size,
+            "hidden_size": self.hidden_size,
+            "num_hidden_layers": self.n_layers,
+            "num_attention_heads": self.n_q_heads,
+            "num_key_value_heads": self.n_kv_heads,
+            "head_dim": self.head_dim,
+            "intermediate_size": self.intermediate_size,
+            "rms_norm_eps": self.rms_norm_eps,
+            "rope_theta": self.rope_theta,
+            "max_position_embeddings": self.max_position_embeddings,
+            "tie_word_embeddings": self.tie_word_embeddings,
+            "attention_bias": self.qkv_bias,
+            "hidden_act": "silu",
+            "torch_dtype": "bfloat16",
+            "bos_token_id": self.bos_token_id,
+            "eos_token_id": self.eos_token_id,
+            "pad_token_id": self.pad_token_id,
+        }
+        if self.n_experts:
+            d["num_local_experts" if self.family == "mixtral" else "num_experts"] = self.n_experts
+            d["num_experts_per_tok"] = self.n_experts_per_tok
+            d["moe_intermediate_size"] = self.moe_intermediate_size
+            d["norm_topk_prob"] = self.norm_topk_prob
+            d["router_aux_loss_coef"] = self.router_aux_loss_coef
+        return d
+
+
+# Named presets (public model-card dimensions) for random-init benchmarking without checkpoints.
+PRESETS: Dict[str, Dict[str, Any]] = {
+    "qwen2-1.5b": dict(family="qwen2", vocab_size=151936, hidden_size=1536, n_layers=28, n_q_heads=12, n_kv_heads=2,
+                       head_dim=128, intermediate_size=8960, tie_word_embeddings=True, qkv_bias=True,
+                       rope_theta=1e6, eos_token_id=151645, pad_token_id=151643),
+    "qwen2.5-7b": dict(family="qwen2", vocab_size=152064, hidden_size=3584, n_layers=28, n_q_heads=28, n_kv_heads=4,
+                       head_dim=128, intermediate_size=18944, tie_word_embeddings=False, qkv_bias=True,
+                       rope_theta=1e6, eos_token_id=151645, pad_token_id=151643),
+    "qwen2.5-32b": dict(family="qwen2", vocab_size=152064, hidden_size=5120, n_layers=64, n_q_heads=40, n_kv_heads=8,
+                        head_dim=128, intermediate_size=27648, tie_word_embeddings=False, qkv_bias=True,
+                        rope_theta=1e6, eos_token_id=151645, pad_token_id=151643),
+    "llama3-8b": dict(family="llama", vocab_size=128256, hidden_size=4096, n_layers=32, n_q_heads=32, n_kv_heads=8,
+                      head_dim=128, intermediate_size=14336, tie_word_embeddings=False, qkv_bias=False,
+                      rope_theta=5e5, rms_norm_eps=1e-5, eos_token_id=128001),
+    "tiny": dict(family="qwen2", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
+                 head_dim=128, intermediate_size=512, tie_word_embeddings=True, qkv_bias=True, rope_theta=1e4,
+                 max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
+    "tiny-moe": dict(family="qwen3_moe", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
+                     head_dim=128, intermediate_size=512, tie_word_embeddings=False, qkv_bias=False, qk_norm=True,
+                     rope_theta=1e4, max_position_embeddings=4096, n_experts=4, n_experts_per_tok=2,
+                     moe_intermediate_size=256, eos_token_id=1, pad_token_id=0),
+}
+
+
+def preset(name: str, **overrides) -> ModelConfig:
+    d = dict(PRESETS[name.lower()])
+    d.update(overrides)
+    return ModelConfig(**d)

@@ -1,0 +1,365 @@
+"""Native decoder-only transformer (Qwen2/2.5/3, Llama, Mistral, Gemma, Mixtral/Qwen-MoE) built on the
+HIP ops of this package.
+
+Design points (MI355X-first rather than a port of ``realhf/impl/model/nn/real_llm_api.py:100-834``):
+
+* All parameters are views into ONE flat bf16 buffer (``FlatParams``) with a matching flat fp32
+  gradient-accumulation buffer. The ZeRO sharder reduce-scatters / all-gathers those buffers directly,
+  weight shipping to rollout engines is a handful of large peer copies, and the interval ops address
+  parameters by flat offsets.
+* q/k/v and gate/up projections are fused GEMMs; RoPE runs in place on the fused projection and the
+  attention kernel reads q, k, v out of it with strides, so nothing is copied between them.
+* The residual stream is carried through the fused residual-add RMSNorm kernel.
+* Tensor parallelism: column-parallel qkv / gate_up, row-parallel o / down with an all-reduce over the
+  TP group (xGMI); sequence-parallel variants live in ``parallel/tensor_parallel.py``.
+"""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .config import ModelConfig
+
+ALIGN = 128  # elements; keeps every parameter 256-byte aligned inside the flat buffer
+
+
+def _pad(n: int, a: int = ALIGN) -> int:
+    return (n + a - 1) // a * a
+
+
+class FlatParams:
+    """Flat storage for a module's parameters (bf16 or fp32) plus an fp32 main-grad buffer."""
+
+    def __init__(self, module: nn.Module, dtype: torch.dtype, device, pad_to: int = 1):
+        params = [(n, p) for n, p in module.named_parameters()]
+        seen = set()
+        self.specs: List[Tuple[str, int, torch.Size]] = []
+        off = 0
+        for n, p in params:
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            self.specs.append((n, off, p.shape))
+            off += _pad(p.numel())
+        self.numel = _pad(off, ALIGN * max(1, pad_to))
+        self.flat = torch.zeros(self.numel, dtype=dtype, device=device)
+        self.main_grad: Optional[torch.Tensor] = None
+        named = dict(params)
+        for n, o, shape in self.specs:
+            p = named[n]
+            view = self.flat[o:o + p.numel()].view(shape)
+            if p.device.type != "meta":
+                view.copy_(p.data)
+            p.data = view
+        self.offsets: Dict[str, Tuple[int, int]] = {n: (o, int(math.prod(s))) for n, o, s in self.specs}
+        self._named = {n: named[n] for n, _, _ in self.specs}
+
+    def alloc_main_grad(self):
+        """fp32 gradient accumulation buffer; every parameter gets a `.main_grad` view and a hook that
+        folds the bf16 autograd gradient into it (the role of the reference's wgrad_gemm_accum_fp32,
+        ``realhf/impl/model/parallelism/tensor_parallel/modules.py:242-402``)."""
+        self.main_grad = torch.zeros(self.numel, dtype=torch.float32, device=self.flat.device)
+        for n, o, shape in self.specs:
+            p = self._named[n]
+            p.main_grad = self.main_grad[o:o + p.numel()].view(shape)
+            if not getattr(p, "_main_grad_hooked", False):
+                p.register_post_accumulate_grad_hook(_fold_grad)
+                p._main_grad_hooked = True
+
+    def zero_grad(self):
+        if self.main_grad is not None:
+            self.main_grad.zero_()
+        for p in self._named.values():
+            p.grad = None
+
+
+def _fold_grad(p: torch.Tensor):
+    if p.grad is not None:
+        p.main_grad.add_(p.grad)
+        p.grad = None
+
+
+# ----------------------------------------------------------------------------- TP collectives
+class _AllReduceFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        if group is not None and dist.get_world_size(group) > 1:
+            x = x.contiguous()
+            dist.all_reduce(x, group=group)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _AllReduceBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.group is not None and dist.get_world_size(ctx.group) > 1:
+            g = g.contiguous()
+            dist.all_reduce(g, group=ctx.group)
+        return g, None
+
+
+# ------------------------------------------------------------------------------------ layers
+class Attention(nn.Module):
+    def __init__(self, cfg: ModelConfig, tp_size: int, dtype, device):
+        super().__init__()
+        assert cfg.n_q_heads % tp_size == 0
+        self.cfg = cfg
+        self.hq = cfg.n_q_heads // tp_size
+        # kv heads are replicated when tp_size exceeds their count
+        self.hkv = max(1, cfg.n_kv_heads // tp_size)
+        D = cfg.head_dim
+        self.qkv = nn.Parameter(torch.empty((self.hq + 2 * self.hkv) * D, cfg.hidden_size, dtype=dtype, device=device))
+        self.qkv_bias = (
+            nn.Parameter(torch.zeros((self.hq + 2 * self.hkv) * D, dtype=dtype, device=device)) if cfg.qkv_bias else None
+        )
+        self.o = nn.Parameter(torch.empty(cfg.hidden_size, self.hq * D, dtype=dtype, device=device))
+        if cfg.qk_norm:
+            self.q_norm = nn.Parameter(torch.ones(D, dtype=dtype, device=device))
+            self.k_norm = nn.Parameter(torch.ones(D, dtype=dtype, device=device))
+
+    def project_qkv(self, x):
+        T = x.shape[0]
+        D = self.cfg.head_dim
+        qkv = F.linear(x, self.qkv, self.qkv_bias).view(T, self.hq + 2 * self.hkv, D)
+        if self.cfg.qk_norm:
+            q, _ = ops.rmsnorm(qkv[:, :self.hq], self.q_norm, self.cfg.rms_norm_eps)
+            k, _ = ops.rmsnorm(qkv[:, self.hq:self.hq + self.hkv], self.k_norm, self.cfg.rms_norm_eps)
+            qkv = torch.cat([q, k, qkv[:, self.hq + self.hkv:]], 1)
+        return qkv
+
+    def forward(self, x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None):
+        T = x.shape[0]
+        x = _AllReduceBwd.apply(x, tp_group)
+        qkv = self.project_qkv(x)
+        qkv = ops.apply_rope(qkv, positions, rope, self.hq + self.hkv)
+        if sp is not None:
+            attn = sp.attention(qkv, self.hq, self.hkv, cu_seqlens, max_seqlen)
+        else:
+            attn = ops.flash_attn_varlen_qkv(qkv, cu_seqlens, max_seqlen, self.hq, self.hkv)
+        out = F.linear(attn.reshape(T, -1), self.o)
+        return _AllReduceFwd.apply(out, tp_group)
+
+
+class MLP(nn.Module):
+    def __init__(self, hidden, inter, tp_size, dtype, device):
+        super().__init__()
+        assert inter % tp_size == 0
+        f = inter // tp_size
+        self.gate_up = nn.Parameter(torch.empty(2 * f, hidden, dtype=dtype, device=device))
+        self.down = nn.Parameter(torch.empty(hidden, f, dtype=dtype, device=device))
+
+    def forward(self, x, tp_group):
+        x = _AllReduceBwd.apply(x, tp_group)
+        h = ops.swiglu(F.linear(x, self.gate_up))
+        return _AllReduceFwd.apply(F.linear(h, self.down), tp_group)
+
+
+class MoE(nn.Module):
+    """Top-k routed experts (Mixtral / Qwen-MoE). Tokens are sorted by expert and every expert runs its
+    fused gate|up and down GEMMs on a contiguous slab (grouped GEMM by expert-sorted dispatch; the
+    reference uses grouped_gemm at ``realhf/impl/model/modules/moe/experts.py:195-210``). With expert
+    parallelism (``ep_group``) each rank owns n_experts/ep experts and tokens travel by all-to-all."""
+
+    def __init__(self, cfg: ModelConfig, tp_size, dtype, device, ep_size: int = 1, ep_rank: int = 0):
+        super().__init__()
+        self.cfg = cfg
+        self.ep_size, self.ep_rank = ep_size, ep_rank
+        assert cfg.n_experts % ep_size == 0
+        self.n_local = cfg.n_experts // ep_size
+        f = cfg.moe_intermediate_size // tp_size
+        self.router = nn.Parameter(torch.empty(cfg.n_experts, cfg.hidden_size, dtype=dtype, device=device))
+        self.gate_up = nn.Parameter(torch.empty(self.n_local, 2 * f, cfg.hidden_size, dtype=dtype, device=device))
+        self.down = nn.Parameter(torch.empty(self.n_local, cfg.hidden_size, f, dtype=dtype, device=device))
+        self.aux_loss = None
+
+    def _experts(self, xs, counts):
+        outs = []
+        s = 0
+        for e, n in enumerate(counts):
+            if n == 0:
+                continue
+            h = ops.swiglu(F.linear(xs[s:s + n], self.gate_up[e]))
+            outs.append(F.linear(h, self.down[e]))
+            s += n
+        if not outs:
+            return xs.new_zeros(0, self.cfg.hidden_size)
+        return torch.cat(outs, 0)
+
+    def forward(self, x, tp_group, ep_group=None):
+        cfg = self.cfg
+        T, H = x.shape
+        x = _AllReduceBwd.apply(x, tp_group)
+        logits = F.linear(x, self.router).float()
+        probs = torch.softmax(logits, -1)
+        topv, topi = torch.topk(probs, cfg.n_experts_per_tok, -1)
+        if cfg.norm_topk_prob:
+            topv = topv / topv.sum(-1, keepdim=True)
+        if cfg.router_aux_loss_coef > 0 and self.training:
+            frac = torch.zeros(cfg.n_experts, device=x.device).index_add_(
+                0, topi.reshape(-1), torch.ones(topi.numel(), device=x.device)) / max(1, topi.numel())
+            self.aux_loss = cfg.router_aux_loss_coef * cfg.n_experts * (frac * probs.mean(0)).sum()
+        flat_e = topi.reshape(-1)
+        order = torch.argsort(flat_e, stable=True)
+        tok = order // cfg.n_experts_per_tok
+        xs = x[tok]
+        counts = torch.bincount(flat_e, minlength=cfg.n_experts)
+        if ep_group is not None and self.ep_size > 1:
+            from ..parallel.expert_parallel import ep_dispatch_combine
+
+            ys = ep_dispatch_combine(self, xs, counts, ep_group)
+        else:
+            ys = self._experts(xs, counts.tolist())
+        w = topv.reshape(-1)[order].to(ys.dtype).unsqueeze(-1)
+        out = torch.zeros_like(x).index_add_(0, tok, ys * w)
+        return _AllReduceFwd.apply(out, tp_group)
+
+
+class Block(nn.Module):
+    def __init__(self, cfg: ModelConfig, tp_size, dtype, device, ep_size=1, ep_rank=0):
+        super().__init__()
+        self.cfg = cfg
+        self.ln1 = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
+        self.attn = Attention(cfg, tp_size, dtype, device)
+        self.ln2 = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
+        if cfg.n_experts > 0:
+            self.mlp = MoE(cfg, tp_size, dtype, device, ep_size, ep_rank)
+        else:
+            self.mlp = MLP(cfg.hidden_size, cfg.intermediate_size, tp_size, dtype, device)
+
+    def forward(self, h, residual, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None, ep_group=None):
+        cfg = self.cfg
+        x, residual = ops.rmsnorm(h, self.ln1, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+        h = self.attn(x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp)
+        x, residual = ops.rmsnorm(h, self.ln2, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+        if cfg.n_experts > 0:
+            h = self.mlp(x, tp_group, ep_group)
+        else:
+            h = self.mlp(x, tp_group)
+        return h, residual
+
+
+class Transformer(nn.Module):
+    """Packed-sequence decoder. `layer_range` selects a pipeline stage's slice of the layers."""
+
+    def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cpu", tp_size: int = 1, tp_rank: int = 0,
+                 tp_group=None, layer_range: Optional[Tuple[int, int]] = None, has_embed: bool = True,
+                 has_head: bool = True, ep_size: int = 1, ep_rank: int = 0, ep_group=None,
+                 gradient_checkpointing: bool = False):
+        super().__init__()
+        self.cfg = cfg
+        self.dtype = dtype
+        self.tp_size, self.tp_rank, self.tp_group = tp_size, tp_rank, tp_group
+        self.ep_group = ep_group
+        self.layer_range = layer_range or (0, cfg.n_layers)
+        self.has_embed, self.has_head = has_embed, has_head
+        self.gradient_checkpointing = gradient_checkpointing
+        self.sp = None  # Ulysses sequence-parallel context (parallel/ulysses.py)
+        if has_embed:
+            self.embed = nn.Parameter(torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device))
+        self.layers = nn.ModuleList(
+            [Block(cfg, tp_size, dtype, device, ep_size, ep_rank) for _ in range(*self.layer_range)]
+        )
+        if has_head:
+            self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
+            if cfg.is_critic:
+                self.head = nn.Parameter(torch.empty(1, cfg.hidden_size, dtype=dtype, device=device))
+            elif not (cfg.tie_word_embeddings and has_embed):
+                self.head = nn.Parameter(torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device))
+        self._rope: Optional[ops.RotaryTable] = None
+        self.flat: Optional[FlatParams] = None
+
+    # ---------------------------------------------------------------------------- set-up
+    def init_weights(self, seed: int = 0, std: float = 0.02):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for n, p in self.named_parameters():
+            if p.dim() >= 2:
+                # generate in fp32 on host in slabs to bound memory, same values on every device type
+                flat = p.data.view(-1)
+                step = 1 << 24
+                for s in range(0, flat.numel(), step):
+                    e = min(flat.numel(), s + step)
+                    flat[s:e].copy_(torch.randn(e - s, generator=g) * std)
+            elif n.endswith("bias"):
+                p.data.zero_()
+            else:
+                p.data.fill_(0.0 if self.cfg.gemma_norm else 1.0)
+
+    def flatten(self, pad_to: int = 1) -> FlatParams:
+        dev = next(self.parameters()).device
+        self.flat = FlatParams(self, self.dtype, dev, pad_to)
+        return self.flat
+
+    def rope(self, device) -> ops.RotaryTable:
+        if self._rope is None or self._rope.cos.device != torch.device(device):
+            self._rope = ops.RotaryTable(self.cfg.head_dim, self.cfg.max_position_embeddings, self.cfg.rope_theta,
+                                         device, self.cfg.rope_scaling)
+        return self._rope
+
+    @property
+    def head_weight(self) -> torch.Tensor:
+        if hasattr(self, "head"):
+            return self.head
+        return self.embed
+
+    # --------------------------------------------------------------------------- forward
+    def embed_tokens(self, input_ids):
+        h = F.embedding(input_ids, self.embed)
+        if self.cfg.gemma_norm:
+            h = h * math.sqrt(self.cfg.hidden_size)
+        return h
+
+    def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor, cu_seqlens: torch.Tensor,
+                max_seqlen: int, hidden_in: Optional[torch.Tensor] = None,
+                residual_in: Optional[torch.Tensor] = None):
+        """Returns the final-norm hidden states [T, H] on the last stage, else (h, residual)."""
+        if self.has_embed and hidden_in is None:
+            h = self.embed_tokens(input_ids)
+        else:
+            h = hidden_in
+        residual = residual_in
+        rope = self.rope(h.device)
+        for blk in self.layers:
+            if self.gradient_checkpointing and self.training and torch.is_grad_enabled():
+                from torch.utils.checkpoint import checkpoint
+
+                h, residual = checkpoint(blk, h, residual, positions, rope, cu_seqlens, max_seqlen, self.tp_group,
+                                         self.sp, self.ep_group, use_reentrant=False)
+            else:
+                h, residual = blk(h, residual, positions, rope, cu_seqlens, max_seqlen, self.tp_group, self.sp,
+                                  self.ep_group)
+        if not self.has_head:
+            return h, residual
+        x, _ = ops.rmsnorm(h, self.norm, self.cfg.rms_norm_eps, residual, self.cfg.gemma_norm)
+        return x
+
+    def logits(self, hidden: torch.Tensor) -> torch.Tensor:
+        return F.linear(hidden, self.head_weight)
+
+    def values(self, hidden: torch.Tensor) -> torch.Tensor:
+        assert self.cfg.is_critic
+        return F.linear(hidden, self.head).squeeze(-1).float()
+
+    def logprobs(self, hidden, labels, temperature=1.0, chunk=8192, keep_logits=True):
+        """Fused LM head + log-prob + entropy; never materialises fp32 [T, V]."""
+        return ops.lm_head_logprobs(hidden, self.head_weight, labels, temperature, chunk, keep_logits)
+
+    def moe_aux_loss(self):
+        tot = None
+        for blk in self.layers:
+            a = getattr(blk.mlp, "aux_loss", None)
+            if a is not None:
+                tot = a if tot is None else tot + a
+        return tot

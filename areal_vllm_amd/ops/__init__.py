@@ -1,0 +1,24 @@
+"""Hand-written gfx950 (MI355X) kernels and their autograd wrappers."""
+from ._lib import available as hip_available  # noqa: F401
+from .attention import (  # noqa: F401
+    PAGE_SIZE,
+    DecodeWorkspace,
+    alloc_kv_cache,
+    cache_gather,
+    decode_num_splits,
+    flash_attn_varlen,
+    flash_attn_varlen_qkv,
+    paged_attention_decode,
+    rope_and_cache_write_,
+)
+from .logprob import (  # noqa: F401
+    gather_logprobs,
+    gather_logprobs_entropy,
+    lm_head_logprobs,
+    logprob_stats,
+    vocab_parallel_logprobs,
+)
+from .norm_act import RotaryTable, apply_rope, rmsnorm, rope_inplace_, swiglu  # noqa: F401
+from .optim import adam_prepare_, adamw_, scale_, sumsq_  # noqa: F401
+from .rl import gae_1d_packed, gae_2d, gae_padded, merge_intervals, set_intervals, slice_intervals  # noqa: F401
+from .sampling import advance_step_, sample  # noqa: F401

@@ -1,0 +1,112 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+//
+// Everything here assumes a 64-lane wavefront. Kernels are exported with a C ABI
+// (raw pointers + hipStream_t) and called from Python through ctypes, so no
+// framework headers are needed to build them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+#define DEVINL __device__ __forceinline__
+
+#define HIP_RET(expr)                         \
+  do {                                        \
+    hipError_t _e = (expr);                   \
+    if (_e != hipSuccess) return (int)_e;     \
+  } while (0)
+
+DEVINL float bf2f(bf16_t x) { return (float)x; }
+DEVINL bf16_t f2bf(float x) { return (bf16_t)x; }
+
+DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DEVINL float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+DEVINL float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// 16-byte vector load/store of 8 bf16.
+DEVINL bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+DEVINL void st8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+
+// Block-wide sum for blocks of up to 1024 threads; `red` needs 16 floats of LDS.
+DEVINL float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = (lane < nw) ? red[lane] : 0.f;
+  return wave_sum(t);
+}
+DEVINL float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = (lane < nw) ? red[lane] : -INFINITY;
+  return wave_max(t);
+}
+
+// Counter-based RNG (Philox-4x32-10): stateless, reproducible across launches and
+// graph replays when the (seed, offset) pair lives in device memory.
+struct Philox {
+  uint32_t k0, k1;
+  DEVINL static void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+    uint64_t p = (uint64_t)a * b;
+    hi = (uint32_t)(p >> 32);
+    lo = (uint32_t)p;
+  }
+  DEVINL static u32x4 round(u32x4 c, uint32_t k0, uint32_t k1) {
+    uint32_t h0, l0, h1, l1;
+    mulhilo(0xD2511F53u, c[0], h0, l0);
+    mulhilo(0xCD9E8D57u, c[2], h1, l1);
+    u32x4 r;
+    r[0] = h1 ^ c[1] ^ k0;
+    r[1] = l1;
+    r[2] = h0 ^ c[3] ^ k1;
+    r[3] = l0;
+    return r;
+  }
+  DEVINL static u32x4 gen(uint64_t seed, uint64_t subseq, uint64_t offset) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    u32x4 c;
+    c[0] = (uint32_t)offset;
+    c[1] = (uint32_t)(offset >> 32);
+    c[2] = (uint32_t)subseq;
+    c[3] = (uint32_t)(subseq >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      c = round(c, k0, k1);
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    return c;
+  }
+};
+DEVINL float u32_to_unit(uint32_t x) {  // (0, 1]
+  return ((x >> 8) + 1) * (1.0f / 16777216.0f);
+}

@@ -1,0 +1,500 @@
+// Variable-length causal flash attention, forward and backward, for gfx950 (CDNA4).
+//
+// Owns what the reference borrows from flash-attn 2 (flash_attn_varlen_func at
+// realhf/impl/model/modules/attn.py:289 and HF attn_implementation=flash_attention_2 via
+// areal/engine/base_hf_engine.py:291-406): packed [T, H, D] q/k/v with cu_seqlens, GQA,
+// causal masking aligned to the bottom-right corner when q and k lengths differ.
+//
+// Both kernels are built on v_mfma_f32_32x32x16_bf16 and arrange every product so that an
+// accumulator tile feeds the next MFMA as an operand without leaving registers:
+//   forward : S^T = K.Q^T (key in the accumulator rows, query on the lane) so the softmax
+//             row statistics are lane-local; O^T += V^T.P^T takes P from the accumulator
+//             registers as the B operand; V^T fragments come from ds_read_b64_tr_b16.
+//   backward: S = Q.K^T and dP = dO.V^T keep the key on the lane, so P and dS are already
+//             the B operands of dV^T += dO^T.P and dK^T += Q^T.dS; only dS crosses LDS once
+//             (transposed) for dQ = dS.K, which is accumulated with fp32 atomics.
+// LDS tiles use 256-byte rows with the 16-byte-chunk XOR swizzle
+//   off(row, ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))
+// which is conflict-free for both ds_read_b128 row reads and transposed reads.
+#include "common.hpp"
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+DEVINL f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+DEVINL int swz_off(int row, int ch) {  // byte offset of 16-byte chunk `ch` of `row`
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+// Transposed read of a 4-row x 16-col block: every lane supplies the address of
+// (row0 + q, col0 + 4p) with its group-lane index 4q+p and receives column `i` of the four
+// rows. `base` is the LDS tile, rows are 256 bytes, col0 must be a multiple of 16.
+DEVINL bf16x4 tr_read(const char* tile, int row0, int col0, int gl) {
+  const int q = gl >> 2, p = gl & 3;
+  const int ch = (col0 >> 3) + (p >> 1);
+  const char* a = tile + swz_off(row0 + q, ch) + 8 * (p & 1);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
+}
+DEVINL bf16x8 cat4(bf16x4 a, bf16x4 b) {
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+DEVINL bf16x8 lds_row_read(const char* tile, int row, int ch) {
+  return *reinterpret_cast<const bf16x8*>(tile + swz_off(row, ch));
+}
+DEVINL void lds_row_write(char* tile, int row, int ch, bf16x8 v) {
+  *reinterpret_cast<bf16x8*>(tile + swz_off(row, ch)) = v;
+}
+
+// =====================================================================================
+// Forward. grid: (q tiles of 128 rows, Hq, B). block: 256 threads = 4 waves x 32 q rows.
+// KV tile = 64 keys. D = 128.
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    bf16_t* __restrict__ o, float* __restrict__ lse, const int* __restrict__ cu_q,
+    const int* __restrict__ cu_k, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+    int64_t o_stride, int Hq, int Hkv, int total_q, float scale_log2, int causal) {
+  constexpr int D = 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 256];
+  char* ks = smem;
+  char* vs = smem + 64 * 256;
+
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q_beg = cu_q[b], q_len = cu_q[b + 1] - q_beg;
+  const int k_beg = cu_k[b], k_len = cu_k[b + 1] - k_beg;
+  const int ntile_q = (q_len + 127) / 128;
+  if ((int)blockIdx.x >= ntile_q) return;
+  const int qt = ntile_q - 1 - blockIdx.x;  // heaviest (latest) tiles first
+  const int kvh = head / (Hq / Hkv);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, hf = lane >> 5, gl = lane & 15, grp = lane >> 4;
+  const int shift = k_len - q_len;  // bottom-right aligned causal mask
+
+  const int q0 = qt * 128 + wid * 32;  // first q row of this wave (within the sequence)
+  const int my_q = q0 + r;
+  const int my_q_c = my_q < q_len ? my_q : q_len - 1;
+  // Q^T as the B operand: lane (r, hf) holds Q[r][16ks + 8hf + j]
+  bf16x8 qf[8];
+  {
+    const bf16_t* qp = q + (size_t)(q_beg + my_q_c) * q_stride + (size_t)head * D + hf * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) qf[s] = ld8(qp + s * 16);
+  }
+  f32x16 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) oacc[i][j] = 0.f;
+  float m = -INFINITY, l = 0.f;
+
+  // number of kv tiles this block needs (the whole block walks the same range)
+  int k_hi = k_len;
+  if (causal) {
+    const int last_q = min(q_len, qt * 128 + 128) - 1;
+    k_hi = min(k_len, last_q + shift + 1);
+  }
+  const int ntile_k = k_hi > 0 ? (k_hi + 63) / 64 : 0;
+
+  // cooperative tile load: thread -> (row = tid>>4 + 16*i, chunk = tid&15), i = 0..3
+  const int lrow = tid >> 4, lch = tid & 15;
+  bf16x8 kreg[4], vreg[4];
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int key = t * 64 + lrow + 16 * i;
+      key = key < k_len ? key : k_len - 1;
+      kreg[i] = ld8(k + (size_t)(k_beg + key) * k_stride + (size_t)kvh * D + lch * 8);
+      vreg[i] = ld8(v + (size_t)(k_beg + key) * v_stride + (size_t)kvh * D + lch * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lds_row_write(ks, lrow + 16 * i, lch, kreg[i]);
+      lds_row_write(vs, lrow + 16 * i, lch, vreg[i]);
+    }
+  };
+  if (ntile_k > 0) {
+    load_tile(0);
+    store_tile();
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntile_k; ++t) {
+    if (t + 1 < ntile_k) load_tile(t + 1);
+    // ---- S^T = K . Q^T : two 32-key blocks
+    f32x16 sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sacc[kb][j] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        bf16x8 kf = lds_row_read(ks, 32 * kb + r, 2 * s + hf);
+        sacc[kb] = mfma32(kf, qf[s], sacc[kb]);
+      }
+    }
+    // ---- online softmax; lane holds q row `my_q`, keys (reg&3)+8(reg>>2)+4hf of each block
+    const int kbase = t * 64;
+    const bool need_mask = (kbase + 64 > k_len) || (causal && (kbase + 63 > q0 + shift));
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float sv = sacc[kb][j] * scale_log2;
+        if (need_mask) {
+          const int key = kbase + 32 * kb + (j & 3) + 8 * (j >> 2) + 4 * hf;
+          if (key >= k_len || (causal && key > my_q + shift)) sv = -INFINITY;
+        }
+        sacc[kb][j] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = (mn == -INFINITY) ? 1.f : exp2f(m - mn);  // m=-inf -> 0
+    m = mn;
+    float ls = 0.f;
+    bf16x8 pf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float pr = (m == -INFINITY) ? 0.f : exp2f(sacc[kb][j] - m);
+        ls += pr;
+        pf[2 * kb + (j >> 3)][j & 7] = f2bf(pr);
+      }
+    l = l * alpha + ls;
+    if (__any(alpha != 1.f)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) oacc[i][j] *= alpha;
+    }
+    // ---- O^T[d, q] += V^T[d, keys] . P^T[keys, q]
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        // group `grp`: rows = keys 16s + 4hf (+8), cols = d 32db + 16(grp&1)
+        const int col0 = 32 * db + 16 * (grp & 1);
+        bf16x4 a0 = tr_read(vs, 16 * s + 4 * hf, col0, gl);
+        bf16x4 a1 = tr_read(vs, 16 * s + 8 + 4 * hf, col0, gl);
+        oacc[db] = mfma32(cat4(a0, a1), pf[s], oacc[db]);
+      }
+    }
+    __syncthreads();
+    if (t + 1 < ntile_k) store_tile();
+    __syncthreads();
+  }
+  // ---- epilogue
+  l += __shfl_xor(l, 32, 64);
+  const float inv_l = l > 0.f ? 1.f / l : 0.f;
+  if (my_q < q_len) {
+    bf16_t* op = o + (size_t)(q_beg + my_q) * o_stride + (size_t)head * D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = f2bf(oacc[db][4 * g + j] * inv_l);
+        *reinterpret_cast<bf16x4*>(op + 32 * db + 8 * g + 4 * hf) = w;
+      }
+    if (hf == 0 && lse)
+      lse[(size_t)head * total_q + q_beg + my_q] =
+          (l > 0.f) ? (m * 0.6931471805599453f + __logf(l)) : -INFINITY;
+  }
+}
+
+extern "C" int areal_flash_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                               const int* cu_q, const int* cu_k, int B, int max_q, int total_q,
+                               int Hq, int Hkv, int D, int64_t q_stride, int64_t k_stride,
+                               int64_t v_stride, int64_t o_stride, float softmax_scale, int causal,
+                               hipStream_t st) {
+  if (B == 0 || max_q == 0) return 0;
+  if (D != 128) return -1;
+  if (Hq % Hkv != 0) return -2;
+  if ((q_stride | k_stride | v_stride | o_stride) % 8 != 0) return -3;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 != 0) return -4;
+  dim3 grid((max_q + 127) / 128, Hq, B), block(256);
+  hipLaunchKernelGGL(flash_fwd_kernel, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)v, (bf16_t*)o, lse, cu_q, cu_k, q_stride, k_stride, v_stride,
+                     o_stride, Hq, Hkv, total_q, softmax_scale * 1.4426950408889634f, causal);
+  return (int)hipGetLastError();
+}
+
+// =====================================================================================
+// Backward.
+//  pre : delta[h, t] = sum_d dO[t, h, d] * O[t, h, d]
+//  main: grid (key blocks of 128, Hkv, B); block 256 threads = 4 waves x 32 keys. Each wave
+//        keeps its K / V fragments and the dK^T / dV^T accumulators in registers and sweeps
+//        the query heads of the GQA group x 32-row query slices. dQ goes out through fp32
+//        atomics into dq_acc [Tq, Hq, D].
+// =====================================================================================
+__global__ __launch_bounds__(256) void flash_bwd_delta_kernel(
+    const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o, float* __restrict__ delta,
+    int64_t o_stride, int64_t do_stride, int Hq, int total_q) {
+  constexpr int D = 128;
+  // 16 lanes per (token, head)
+  const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  if (idx >= (int64_t)total_q * Hq) return;
+  const int64_t t = idx / Hq;
+  const int h = (int)(idx % Hq);
+  bf16x8 a = ld8(o + t * o_stride + (size_t)h * D + sub * 8);
+  bf16x8 bb = ld8(d_o + t * do_stride + (size_t)h * D + sub * 8);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += bf2f(a[j]) * bf2f(bb[j]);
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (sub == 0) delta[(size_t)h * total_q + t] = s;
+}
+
+__global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ delta,
+    float* __restrict__ dq_acc, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+    const int* __restrict__ cu_q, const int* __restrict__ cu_k, int64_t q_stride, int64_t k_stride,
+    int64_t v_stride, int64_t do_stride, int64_t dk_stride, int64_t dv_stride, int Hq, int Hkv,
+    int total_q, float softmax_scale, int causal) {
+  constexpr int D = 128;
+  // LDS: Q tile [32][256B] | dO tile [32][256B] | K tile [128][256B] | dS^T [128 keys][32 q] bf16
+  //      | lse[32] f32 | delta[32] f32
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qs = smem;
+  char* dos = qs + 32 * 256;
+  char* kts = dos + 32 * 256;
+  char* dss = kts + 128 * 256;           // [128][64 B]
+  float* lse_s = reinterpret_cast<float*>(dss + 128 * 64);
+  float* dl_s = lse_s + 32;
+
+  const int b = blockIdx.z, kvh = blockIdx.y;
+  const int q_beg = cu_q[b], q_len = cu_q[b + 1] - q_beg;
+  const int k_beg = cu_k[b], k_len = cu_k[b + 1] - k_beg;
+  const int kb0 = blockIdx.x * 128;
+  if (kb0 >= k_len) return;
+  const int G = Hq / Hkv;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, hf = lane >> 5, gl = lane & 15, grp = lane >> 4;
+  const int shift = k_len - q_len;
+  const float scale_log2 = softmax_scale * 1.4426950408889634f;
+
+  // this wave's keys: kb0 + 32*wid + r
+  const int my_key = kb0 + 32 * wid + r;
+  const int my_key_c = my_key < k_len ? my_key : k_len - 1;
+  bf16x8 kf[8], vf[8];
+  {
+    const bf16_t* kp = k + (size_t)(k_beg + my_key_c) * k_stride + (size_t)kvh * D + hf * 8;
+    const bf16_t* vp = v + (size_t)(k_beg + my_key_c) * v_stride + (size_t)kvh * D + hf * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { kf[s] = ld8(kp + s * 16); vf[s] = ld8(vp + s * 16); }
+  }
+  // K tile of the block into LDS (for the transposed reads of dQ = dS.K)
+  {
+    const int lrow = tid >> 4, lch = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int key = kb0 + lrow + 16 * i;
+      key = key < k_len ? key : k_len - 1;
+      lds_row_write(kts, lrow + 16 * i, lch,
+                    ld8(k + (size_t)(k_beg + key) * k_stride + (size_t)kvh * D + lch * 8));
+    }
+  }
+  f32x16 dkacc[4], dvacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { dkacc[i][j] = 0.f; dvacc[i][j] = 0.f; }
+
+  // first query row that can see this key block
+  int qs_first = 0;
+  if (causal) {
+    const int fq = kb0 - shift;  // q index with q + shift >= kb0
+    qs_first = fq > 0 ? (fq / 32) * 32 : 0;
+  }
+  const int lrow = tid >> 4, lch = tid & 15;  // 16 rows x 16 chunks per pass, 2 passes for 32 rows
+
+  for (int g = 0; g < G; ++g) {
+    const int head = kvh * G + g;
+    for (int qs0 = qs_first; qs0 < q_len; qs0 += 32) {
+      __syncthreads();  // previous slice fully consumed (Q/dO/dS tiles)
+      // ---- stage Q and dO slices + row constants
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int qi = qs0 + lrow + 16 * i;
+        qi = qi < q_len ? qi : q_len - 1;
+        lds_row_write(qs, lrow + 16 * i, lch,
+                      ld8(q + (size_t)(q_beg + qi) * q_stride + (size_t)head * D + lch * 8));
+        lds_row_write(dos, lrow + 16 * i, lch,
+                      ld8(d_o + (size_t)(q_beg + qi) * do_stride + (size_t)head * D + lch * 8));
+      }
+      if (tid < 32) {
+        int qi = qs0 + tid;
+        const bool ok = qi < q_len;
+        qi = ok ? qi : q_len - 1;
+        // rows past the end get lse = +inf so that p = exp2(-inf) = 0
+        lse_s[tid] = ok ? lse[(size_t)head * total_q + q_beg + qi] * 1.4426950408889634f : INFINITY;
+        dl_s[tid] = ok ? delta[(size_t)head * total_q + q_beg + qi] : 0.f;
+      }
+      __syncthreads();
+      // ---- S = Q.K^T, dP = dO.V^T (rows = q in registers, col = key on the lane)
+      f32x16 sacc, pacc;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { sacc[j] = 0.f; pacc[j] = 0.f; }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        bf16x8 qa = lds_row_read(qs, r, 2 * s + hf);
+        bf16x8 da = lds_row_read(dos, r, 2 * s + hf);
+        sacc = mfma32(qa, kf[s], sacc);
+        pacc = mfma32(da, vf[s], pacc);
+      }
+      // ---- P = exp2(S*c - lse), dS = P * (dP - delta)
+      bf16x8 pfr[2], dsfr[2];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 8 * g4 + 4 * hf);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(dl_s + 8 * g4 + 4 * hf);
+        bf16x4 dsw;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int reg = 4 * g4 + j;
+          const int qrow = qs0 + 8 * g4 + 4 * hf + j;
+          float p = exp2f(sacc[reg] * scale_log2 - l4[j]);
+          if (my_key >= k_len || (causal && my_key > qrow + shift)) p = 0.f;
+          const float ds = p * (pacc[reg] - d4[j]);
+          pfr[reg >> 3][reg & 7] = f2bf(p);
+          dsfr[reg >> 3][reg & 7] = f2bf(ds);
+          dsw[j] = f2bf(ds);
+        }
+        // dS^T[key][q]: this lane's key row, 4 consecutive q -> 8 bytes
+        *reinterpret_cast<bf16x4*>(dss + (32 * wid + r) * 64 + (8 * g4 + 4 * hf) * 2) = dsw;
+      }
+      // ---- dV^T += dO^T.P ; dK^T += Q^T.dS   (A operand from transposed reads)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const int col0 = 32 * db + 16 * (grp & 1);
+          bf16x8 da = cat4(tr_read(dos, 16 * s + 4 * hf, col0, gl),
+                           tr_read(dos, 16 * s + 8 + 4 * hf, col0, gl));
+          dvacc[db] = mfma32(da, pfr[s], dvacc[db]);
+          bf16x8 qa = cat4(tr_read(qs, 16 * s + 4 * hf, col0, gl),
+                           tr_read(qs, 16 * s + 8 + 4 * hf, col0, gl));
+          dkacc[db] = mfma32(qa, dsfr[s], dkacc[db]);
+        }
+      }
+      __syncthreads();  // dS^T of all four waves visible
+      // ---- dQ[32 q x 32 d (block wid)] = dS[32 q x 128 keys] . K[128 keys x 32 d]
+      f32x16 dqacc;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dqacc[j] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        // A = dS: lane (q = r, hf) needs keys 16s + 8hf + j  -> transposed reads of dS^T
+        //   group rows = keys, cols = q block 16(grp&1)
+        const char* a0p = dss + (16 * s + 8 * hf + (gl >> 2)) * 64 + (16 * (grp & 1) + 4 * (gl & 3)) * 2;
+        bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0p));
+        bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0p + 4 * 64));
+        // B = K: lane (d = r, hf) needs K[key 16s + 8hf + j][32 wid + r]
+        const int col0 = 32 * wid + 16 * (grp & 1);
+        bf16x8 kb = cat4(tr_read(kts, 16 * s + 8 * hf, col0, gl),
+                         tr_read(kts, 16 * s + 8 * hf + 4, col0, gl));
+        dqacc = mfma32(cat4(a0, a1), kb, dqacc);
+      }
+      // atomics: lane (d col = r, hf), reg -> q row
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int qrow = qs0 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
+        if (qrow < q_len)
+          atomicAdd(dq_acc + ((size_t)(q_beg + qrow) * Hq + head) * D + 32 * wid + r,
+                    dqacc[reg] * softmax_scale);
+      }
+    }
+  }
+  // ---- epilogue: dK^T / dV^T accumulators: lane (key col = r, hf), reg -> d row
+  if (my_key < k_len) {
+    bf16_t* dkp = dk + (size_t)(k_beg + my_key) * dk_stride + (size_t)kvh * D;
+    bf16_t* dvp = dv + (size_t)(k_beg + my_key) * dv_stride + (size_t)kvh * D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        bf16x4 wk, wv;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wk[j] = f2bf(dkacc[db][4 * g4 + j] * softmax_scale);
+          wv[j] = f2bf(dvacc[db][4 * g4 + j]);
+        }
+        *reinterpret_cast<bf16x4*>(dkp + 32 * db + 8 * g4 + 4 * hf) = wk;
+        *reinterpret_cast<bf16x4*>(dvp + 32 * db + 8 * g4 + 4 * hf) = wv;
+      }
+  }
+}
+
+// dq (bf16, strided) = dq_acc (fp32, [T, Hq, D])
+__global__ __launch_bounds__(256) void flash_bwd_dq_cast_kernel(const float* __restrict__ acc,
+                                                                bf16_t* __restrict__ dq,
+                                                                int64_t dq_stride, int Hq,
+                                                                int64_t total_q) {
+  constexpr int D = 128;
+  const int64_t nvec = total_q * Hq * (D / 8);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % (D / 8));
+    const int64_t th = i / (D / 8);
+    const int h = (int)(th % Hq);
+    const int64_t t = th / Hq;
+    const float* p = acc + (th * D) + c * 8;
+    f32x4 a = *reinterpret_cast<const f32x4*>(p), bq = *reinterpret_cast<const f32x4*>(p + 4);
+    bf16x8 w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w[j] = f2bf(a[j]); w[j + 4] = f2bf(bq[j]); }
+    st8(dq + t * dq_stride + (size_t)h * D + c * 8, w);
+  }
+}
+
+// dq_acc must be zeroed by the caller ([total_q, Hq, D] fp32); delta: [Hq, total_q] fp32.
+extern "C" int areal_flash_bwd(const void* q, const void* k, const void* v, const void* o,
+                               const void* d_o, const float* lse, float* delta, float* dq_acc,
+                               void* dq, void* dk, void* dv, const int* cu_q, const int* cu_k,
+                               int B, int max_k, int total_q, int Hq, int Hkv, int D,
+                               int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                               int64_t o_stride, int64_t do_stride, int64_t dq_stride,
+                               int64_t dk_stride, int64_t dv_stride, float softmax_scale, int causal,
+                               hipStream_t st) {
+  if (B == 0 || total_q == 0) return 0;
+  if (D != 128) return -1;
+  if (Hq % Hkv != 0) return -2;
+  if ((q_stride | k_stride | v_stride | o_stride | do_stride | dq_stride | dk_stride | dv_stride) % 8)
+    return -3;
+  {
+    const int64_t n = (int64_t)total_q * Hq * 16;
+    hipLaunchKernelGGL(flash_bwd_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                       (const bf16_t*)o, (const bf16_t*)d_o, delta, o_stride, do_stride, Hq, total_q);
+  }
+  const size_t lds = 32 * 256 * 2 + 128 * 256 + 128 * 64 + 64 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_RET(hipFuncSetAttribute((const void*)flash_bwd_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  dim3 grid((max_k + 127) / 128, Hkv, B), block(256);
+  hipLaunchKernelGGL(flash_bwd_kernel, grid, block, lds, st, (const bf16_t*)q, (const bf16_t*)k,
+                     (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, dq_acc, (bf16_t*)dk,
+                     (bf16_t*)dv, cu_q, cu_k, q_stride, k_stride, v_stride, do_stride, dk_stride,
+                     dv_stride, Hq, Hkv, total_q, softmax_scale, causal);
+  {
+    const int64_t nvec = (int64_t)total_q * Hq * (D / 8);
+    int64_t g = (nvec + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(flash_bwd_dq_cast_kernel, dim3((unsigned)g), dim3(256), 0, st, dq_acc,
+                       (bf16_t*)dq, dq_stride, Hq, (int64_t)total_q);
+  }
+  return (int)hipGetLastError();
+}

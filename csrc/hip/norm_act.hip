@@ -1,0 +1,335 @@
+// RMSNorm (with fused residual add), SwiGLU and rotary embedding kernels for gfx950.
+//
+// All three are HBM-bound, so every access is a 16-byte (8 x bf16) vector per lane
+// and each row is handled by one 64-lane wave with in-wave shuffles for reductions.
+// These replace the TransformerEngine/apex/flash-attn-Triton ops the reference leans
+// on (realhf/impl/model/modules/mlp.py:319-341, realhf/impl/model/modules/rotary.py).
+#include "common.hpp"
+
+// ----------------------------------------------------------------------------------
+// RMSNorm forward.  y = (x [+ res]) * rsqrt(mean((x+res)^2) + eps) * (w [+ 1 if gemma])
+// When `res` is given, the sum x+res is written to `res_out` (the new residual stream).
+// One wave per row; H % 8 == 0.
+// ----------------------------------------------------------------------------------
+template <int MAXV>  // number of 8-element vectors each lane keeps in registers
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ res, const bf16_t* __restrict__ w,
+    bf16_t* __restrict__ y, bf16_t* __restrict__ res_out, float* __restrict__ rstd_out,
+    int T, int H, float eps, int gemma) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const int nvec = H >> 3;
+  const bf16_t* xr = x + (size_t)row * H;
+  const bf16_t* rr = res ? res + (size_t)row * H : nullptr;
+  float v[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nvec) {
+      bf16x8 a = ld8(xr + c * 8);
+      if (rr) {
+        bf16x8 b = ld8(rr + c * 8);
+        bf16x8 s;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          // the residual stream is stored in bf16, so round before normalising: the
+          // backward pass re-reads the rounded value.
+          s[j] = f2bf(bf2f(a[j]) + bf2f(b[j]));
+          v[i][j] = bf2f(s[j]);
+        }
+        st8(res_out + (size_t)row * H + c * 8, s);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[i][j] = bf2f(a[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+    }
+  }
+  ss = wave_sum(ss);
+  const float rstd = rsqrtf(ss / (float)H + eps);
+  if (lane == 0 && rstd_out) rstd_out[row] = rstd;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nvec) {
+      bf16x8 ww = ld8(w + c * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float wf = bf2f(ww[j]) + (gemma ? 1.f : 0.f);
+        o[j] = f2bf(v[i][j] * rstd * wf);
+      }
+      st8(y + (size_t)row * H + c * 8, o);
+    }
+  }
+}
+
+// RMSNorm backward. dx = rstd * (g - xhat * mean(g * xhat)) [+ dres], g = dy * w.
+// dw partials: each block accumulates its rows' dy*xhat per column in registers,
+// reduces its 4 waves through LDS and writes one partial row; a second kernel sums
+// the partial rows (no atomics: every block would hit the same H floats).
+template <int MAXV>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+    const float* __restrict__ rstd, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+    float* __restrict__ dw_partial, int T, int H, int gemma) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  const int nvec = H >> 3;
+  float dwacc[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwacc[i][j] = 0.f;
+
+  for (int row = blockIdx.x * nw + wid; row < T; row += gridDim.x * nw) {
+    const float rs = rstd[row];
+    float g[MAXV][8], xh[MAXV][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        bf16x8 a = ld8(dy + (size_t)row * H + c * 8);
+        bf16x8 b = ld8(x + (size_t)row * H + c * 8);
+        bf16x8 ww = ld8(w + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dyf = bf2f(a[j]);
+          xh[i][j] = bf2f(b[j]) * rs;
+          g[i][j] = dyf * (bf2f(ww[j]) + (gemma ? 1.f : 0.f));
+          dot += g[i][j] * xh[i][j];
+          dwacc[i][j] += dyf * xh[i][j];
+        }
+      }
+    }
+    dot = wave_sum(dot) / (float)H;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        bf16x8 o;
+        bf16x8 dr;
+        if (dres) dr = ld8(dres + (size_t)row * H + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float d = rs * (g[i][j] - xh[i][j] * dot);
+          if (dres) d += bf2f(dr[j]);
+          o[j] = f2bf(d);
+        }
+        st8(dx + (size_t)row * H + c * 8, o);
+      }
+    }
+  }
+  // cross-wave reduction of dw partials through LDS: smem[nw][H]
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) smem[(size_t)wid * H + c * 8 + j] = dwacc[i][j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nw; ++k) s += smem[(size_t)k * H + c];
+    dw_partial[(size_t)blockIdx.x * H + c] = s;
+  }
+}
+
+__global__ void colsum_partial_kernel(const float* __restrict__ part, bf16_t* __restrict__ out_bf16,
+                                      float* __restrict__ out_f32, int G, int H) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += part[(size_t)g * H + c];
+  if (out_bf16) out_bf16[c] = f2bf(s);
+  if (out_f32) out_f32[c] = s;
+}
+
+extern "C" int areal_rmsnorm_fwd(const void* x, const void* res, const void* w, void* y, void* res_out,
+                                 float* rstd, int T, int H, float eps, int gemma, hipStream_t st) {
+  if (H % 8 != 0 || H > 8 * 64 * 16) return -1;
+  if (T == 0) return 0;
+  const int rows_per_block = 4;
+  dim3 grid((T + rows_per_block - 1) / rows_per_block), block(256);
+  const int nvec = H / 8;
+  const int maxv = (nvec + 63) / 64;
+#define LAUNCH(MV)                                                                              \
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel<MV>, grid, block, 0, st, (const bf16_t*)x,              \
+                     (const bf16_t*)res, (const bf16_t*)w, (bf16_t*)y, (bf16_t*)res_out, rstd,  \
+                     T, H, eps, gemma)
+  if (maxv <= 2) LAUNCH(2);
+  else if (maxv <= 4) LAUNCH(4);
+  else if (maxv <= 8) LAUNCH(8);
+  else LAUNCH(16);
+#undef LAUNCH
+  return (int)hipGetLastError();
+}
+
+// workspace: G*H floats where G = areal_rmsnorm_bwd_nblocks(T)
+extern "C" int areal_rmsnorm_bwd_nblocks(int T) {
+  int g = (T + 3) / 4;
+  return g < 1 ? 1 : (g > 512 ? 512 : g);
+}
+
+extern "C" int areal_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd,
+                                 const void* dres, void* dx, void* dw_bf16, float* dw_f32,
+                                 float* workspace, int T, int H, int gemma, hipStream_t st) {
+  if (H % 8 != 0 || H > 8 * 64 * 16) return -1;
+  if (T == 0) return 0;
+  const int G = areal_rmsnorm_bwd_nblocks(T);
+  const size_t lds = (size_t)4 * H * sizeof(float);
+  if (lds > 160 * 1024) return -2;
+  dim3 grid(G), block(256);
+  const int maxv = (H / 8 + 63) / 64;
+#define LAUNCH(MV)                                                                             \
+  do {                                                                                         \
+    if (lds > 64 * 1024)                                                                       \
+      HIP_RET(hipFuncSetAttribute((const void*)rmsnorm_bwd_kernel<MV>,                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel<MV>, grid, block, lds, st, (const bf16_t*)dy,        \
+                       (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)dres,          \
+                       (bf16_t*)dx, workspace, T, H, gemma);                                   \
+  } while (0)
+  if (maxv <= 2) LAUNCH(2);
+  else if (maxv <= 4) LAUNCH(4);
+  else if (maxv <= 8) LAUNCH(8);
+  else LAUNCH(16);
+#undef LAUNCH
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((H + 255) / 256), dim3(256), 0, st, workspace,
+                     (bf16_t*)dw_bf16, dw_f32, G, H);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------
+// SwiGLU on a fused [T, 2F] gate|up projection: out[t, f] = silu(gu[t, f]) * gu[t, F + f]
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu,
+                                                         bf16_t* __restrict__ out, int64_t T, int F) {
+  const int64_t nvec_row = F >> 3;
+  const int64_t total = T * nvec_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / nvec_row, c = i % nvec_row;
+    bf16x8 g = ld8(gu + t * 2 * F + c * 8);
+    bf16x8 u = ld8(gu + t * 2 * F + F + c * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gf = bf2f(g[j]);
+      const float s = gf / (1.f + __expf(-gf));
+      o[j] = f2bf(s * bf2f(u[j]));
+    }
+    st8(out + t * F + c * 8, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                         const bf16_t* __restrict__ gu,
+                                                         bf16_t* __restrict__ dgu, int64_t T, int F) {
+  const int64_t nvec_row = F >> 3;
+  const int64_t total = T * nvec_row;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / nvec_row, c = i % nvec_row;
+    bf16x8 g = ld8(gu + t * 2 * F + c * 8);
+    bf16x8 u = ld8(gu + t * 2 * F + F + c * 8);
+    bf16x8 d = ld8(dy + t * F + c * 8);
+    bf16x8 dg, du;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
+      const float sig = 1.f / (1.f + __expf(-gf));
+      const float silu = gf * sig;
+      dg[j] = f2bf(df * uf * (sig * (1.f + gf * (1.f - sig))));
+      du[j] = f2bf(df * silu);
+    }
+    st8(dgu + t * 2 * F + c * 8, dg);
+    st8(dgu + t * 2 * F + F + c * 8, du);
+  }
+}
+
+static inline int ew_grid(int64_t total, int block) {
+  int64_t g = (total + block - 1) / block;
+  if (g > 256 * 8) g = 256 * 8;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int areal_swiglu_fwd(const void* gu, void* out, int64_t T, int F, hipStream_t st) {
+  if (F % 8 != 0) return -1;
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid(T * (F / 8), 256)), dim3(256), 0, st,
+                     (const bf16_t*)gu, (bf16_t*)out, T, F);
+  return (int)hipGetLastError();
+}
+extern "C" int areal_swiglu_bwd(const void* dy, const void* gu, void* dgu, int64_t T, int F,
+                                hipStream_t st) {
+  if (F % 8 != 0) return -1;
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_grid(T * (F / 8), 256)), dim3(256), 0, st,
+                     (const bf16_t*)dy, (const bf16_t*)gu, (bf16_t*)dgu, T, F);
+  return (int)hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------
+// Rotary embedding (half-split / "NeoX" layout, as HF Llama/Qwen use), in place on the
+// first `n_rot_heads` heads of a [T, n_heads_total, D] tensor (the fused qkv projection:
+// q heads then k heads are rotated, v heads are left alone). cos/sin come from a host-
+// precomputed fp32 table [max_pos, D/2] so no transcendental runs on device.
+// `sign` = +1 forward, -1 backward (the inverse rotation is the gradient).
+// Each group of D/16 lanes handles one head: a lane rotates 8 (lo, hi) pairs.
+// ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x,
+                                                   const int* __restrict__ pos,
+                                                   const float* __restrict__ cos_t,
+                                                   const float* __restrict__ sin_t, int64_t T,
+                                                   int n_heads_total, int n_rot_heads, int D,
+                                                   float sign, int max_pos) {
+  const int half = D >> 1;
+  const int lanes_per_head = half >> 3;  // 8 for D=128
+  const int64_t total = T * n_rot_heads * lanes_per_head;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int sub = (int)(i % lanes_per_head);
+    const int64_t th = i / lanes_per_head;
+    const int head = (int)(th % n_rot_heads);
+    const int64_t t = th / n_rot_heads;
+    int p = pos[t];
+    p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+    bf16_t* base = x + (t * n_heads_total + head) * D + sub * 8;
+    bf16x8 lo = ld8(base), hi = ld8(base + half);
+    const float* c = cos_t + (size_t)p * half + sub * 8;
+    const float* s = sin_t + (size_t)p * half + sub * 8;
+    f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
+    f32x4 s0 = *reinterpret_cast<const f32x4*>(s), s1 = *reinterpret_cast<const f32x4*>(s + 4);
+    bf16x8 olo, ohi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float cf = j < 4 ? c0[j] : c1[j - 4];
+      const float sf = sign * (j < 4 ? s0[j] : s1[j - 4]);
+      const float a = bf2f(lo[j]), b = bf2f(hi[j]);
+      olo[j] = f2bf(a * cf - b * sf);
+      ohi[j] = f2bf(b * cf + a * sf);
+    }
+    st8(base, olo);
+    st8(base + half, ohi);
+  }
+}
+
+extern "C" int areal_rope_inplace(void* x, const int* pos, const float* cos_t, const float* sin_t,
+                                  int64_t T, int n_heads_total, int n_rot_heads, int D, float sign,
+                                  int max_pos, hipStream_t st) {
+  if (D % 16 != 0) return -1;
+  if (T == 0) return 0;
+  const int64_t total = T * n_rot_heads * (D / 16);
+  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, st, (bf16_t*)x, pos, cos_t,
+                     sin_t, T, n_heads_total, n_rot_heads, D, sign, max_pos);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,226 @@
+// pybind11 module `_runtime`: the C++ host runtime of the framework.
+//   * Scheduler / BlockManager  - continuous-batching rollout engine core (scheduler.hpp)
+//   * ffd_allocate              - first-fit-decreasing micro-batch allocation
+//                                 (semantics of areal/utils/datapack.py:149-184 in the reference)
+//   * partition_balanced        - contiguous k-way partition minimising the largest part
+//                                 (the numba routine the reference uses for DP sequence balancing)
+//   * merge_intervals           - sort + merge of [start, end) intervals
+//                                 (csrc/interval_op/interval_op.cpp:1-29 in the reference)
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <numeric>
+#include <set>
+
+#include "scheduler.hpp"
+
+namespace py = pybind11;
+using namespace areal;
+
+template <typename T>
+static py::array_t<T> to_np(const std::vector<T>& v) {
+  py::array_t<T> a((py::ssize_t)v.size());
+  if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(T));
+  return a;
+}
+
+static py::dict plan_to_dict(const Plan& p) {
+  py::dict d;
+  d["kind"] = p.kind;
+  d["req_ids"] = to_np(p.req_ids);
+  d["input_ids"] = to_np(p.input_ids);
+  d["positions"] = to_np(p.positions);
+  d["slot_mapping"] = to_np(p.slot_mapping);
+  d["temperature"] = to_np(p.temperature);
+  d["top_p"] = to_np(p.top_p);
+  d["top_k"] = to_np(p.top_k);
+  if (p.kind == 1) {
+    d["cu_q"] = to_np(p.cu_q);
+    d["cu_k"] = to_np(p.cu_k);
+    d["max_q"] = p.max_q;
+    d["max_k"] = p.max_k;
+    d["has_prefix"] = p.has_prefix;
+    d["ctx_slots"] = to_np(p.ctx_slots);
+  } else if (p.kind == 2) {
+    d["n_steps"] = p.n_steps;
+    d["context_lens"] = to_np(p.context_lens);
+    d["max_pages"] = p.max_pages;
+    py::array_t<int32_t> bt({(py::ssize_t)p.req_ids.size(), (py::ssize_t)p.max_pages});
+    if (!p.block_tables.empty())
+      std::memcpy(bt.mutable_data(), p.block_tables.data(), p.block_tables.size() * sizeof(int32_t));
+    d["block_tables"] = bt;
+  }
+  return d;
+}
+
+class PyScheduler {
+ public:
+  explicit PyScheduler(const SchedulerConfig& cfg) : s_(cfg) {}
+  int64_t add_request(const std::string& rid, const std::vector<int32_t>& prompt, int max_new_tokens,
+                      int min_new_tokens, float temperature, float top_p, int top_k,
+                      const std::vector<int32_t>& stop_token_ids) {
+    SamplingParams sp;
+    sp.max_new_tokens = max_new_tokens;
+    sp.min_new_tokens = min_new_tokens;
+    sp.temperature = temperature;
+    sp.top_p = top_p;
+    sp.top_k = top_k;
+    sp.stop_token_ids = stop_token_ids;
+    return s_.add_request(rid, prompt, sp);
+  }
+  py::dict schedule() {
+    plan_ = s_.schedule();
+    return plan_to_dict(plan_);
+  }
+  void process_prefill(py::array_t<int64_t, py::array::c_style | py::array::forcecast> toks,
+                       py::array_t<float, py::array::c_style | py::array::forcecast> lps) {
+    if ((size_t)toks.size() < plan_.req_ids.size() || (size_t)lps.size() < plan_.req_ids.size())
+      throw std::runtime_error("process_prefill: output shorter than the batch");
+    s_.process_prefill(plan_, toks.data(), lps.data());
+  }
+  void process_decode(py::array_t<int64_t, py::array::c_style | py::array::forcecast> toks,
+                      py::array_t<float, py::array::c_style | py::array::forcecast> lps) {
+    if (toks.ndim() != 2 || toks.shape(0) < plan_.n_steps || (size_t)toks.shape(1) < plan_.req_ids.size())
+      throw std::runtime_error("process_decode: expected [n_steps, >=batch] outputs");
+    s_.process_decode(plan_, toks.data(), lps.data(), (int)toks.shape(1));
+  }
+  py::list take_finished() {
+    py::list out;
+    for (auto& f : s_.take_finished()) {
+      py::dict d;
+      d["rid"] = f.rid;
+      d["output_tokens"] = f.output_tokens;
+      d["output_logprobs"] = f.output_logprobs;
+      d["output_versions"] = f.output_versions;
+      d["finish_reason"] = f.finish_reason;
+      d["prompt_len"] = f.prompt_len;
+      d["latency"] = f.latency;
+      d["ttft"] = f.ttft;
+      d["itl"] = f.itl;
+      out.append(d);
+    }
+    return out;
+  }
+  Scheduler s_;
+  Plan plan_;
+};
+
+// ------------------------------------------------------------------------------ datapack
+static std::vector<std::vector<int>> ffd_allocate(const std::vector<int64_t>& values, int64_t capacity,
+                                                  int min_groups) {
+  const int n = (int)values.size();
+  for (auto v : values)
+    if (v > capacity) throw std::runtime_error("ffd_allocate: a value exceeds the capacity");
+  if (n < min_groups) throw std::runtime_error("ffd_allocate: fewer values than min_groups");
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return values[a] > values[b]; });
+  std::vector<std::vector<int>> groups;
+  // (sum, group id) ordered by sum: the candidates that can take v are a prefix of this set
+  std::set<std::pair<int64_t, int>> by_sum;
+  for (int idx : order) {
+    const int64_t v = values[idx];
+    if ((int)groups.size() < min_groups || by_sum.empty() || by_sum.begin()->first + v > capacity) {
+      by_sum.insert({v, (int)groups.size()});
+      groups.push_back({idx});
+      continue;
+    }
+    // among groups with room, take the one holding the fewest items (first such on ties)
+    auto end = by_sum.upper_bound({capacity - v, n});
+    auto best = by_sum.begin();
+    for (auto it = by_sum.begin(); it != end; ++it)
+      if (groups[it->second].size() < groups[best->second].size()) best = it;
+    auto node = *best;
+    by_sum.erase(best);
+    groups[node.second].push_back(idx);
+    by_sum.insert({node.first + v, node.second});
+  }
+  return groups;
+}
+
+// Split `lens` (kept in order) into k contiguous parts minimising the maximum part sum.
+// Returns k+1 boundaries. Each part holds at least `min_size` items.
+static std::vector<int> partition_balanced(const std::vector<int64_t>& lens, int k, int min_size) {
+  const int n = (int)lens.size();
+  if (k <= 0 || n < k * std::max(1, min_size)) throw std::runtime_error("partition_balanced: infeasible");
+  min_size = std::max(1, min_size);
+  std::vector<int64_t> pre(n + 1, 0);
+  for (int i = 0; i < n; ++i) pre[i + 1] = pre[i] + lens[i];
+  const int64_t INF = INT64_MAX / 4;
+  std::vector<std::vector<int64_t>> dp(k + 1, std::vector<int64_t>(n + 1, INF));
+  std::vector<std::vector<int>> arg(k + 1, std::vector<int>(n + 1, -1));
+  dp[0][0] = 0;
+  for (int j = 1; j <= k; ++j)
+    for (int i = j * min_size; i <= n - (k - j) * min_size; ++i)
+      for (int s = (j - 1) * min_size; s <= i - min_size; ++s) {
+        if (dp[j - 1][s] >= INF) continue;
+        int64_t c = std::max(dp[j - 1][s], pre[i] - pre[s]);
+        if (c < dp[j][i]) { dp[j][i] = c; arg[j][i] = s; }
+      }
+  std::vector<int> bounds(k + 1);
+  int i = n;
+  for (int j = k; j >= 0; --j) {
+    bounds[j] = i;
+    if (j > 0) i = arg[j][i];
+  }
+  return bounds;
+}
+
+static py::array_t<int64_t> merge_intervals(py::array_t<int64_t, py::array::c_style | py::array::forcecast> iv) {
+  const py::ssize_t n = iv.size() / 2;
+  std::vector<std::pair<int64_t, int64_t>> v(n);
+  for (py::ssize_t i = 0; i < n; ++i) v[i] = {iv.data()[2 * i], iv.data()[2 * i + 1]};
+  std::sort(v.begin(), v.end());
+  std::vector<int64_t> out;
+  for (auto& p : v) {
+    if (!out.empty() && p.first <= out.back()) out.back() = std::max(out.back(), p.second);
+    else { out.push_back(p.first); out.push_back(p.second); }
+  }
+  return to_np(out);
+}
+
+PYBIND11_MODULE(_runtime, m) {
+  m.doc() = "C++ host runtime: rollout scheduler, block manager, sequence packing, interval merging";
+  m.attr("PAGE_SIZE") = PAGE;
+  py::class_<SchedulerConfig>(m, "SchedulerConfig")
+      .def(py::init<>())
+      .def_readwrite("num_pages", &SchedulerConfig::num_pages)
+      .def_readwrite("max_running_requests", &SchedulerConfig::max_running_requests)
+      .def_readwrite("max_prefill_tokens", &SchedulerConfig::max_prefill_tokens)
+      .def_readwrite("context_length", &SchedulerConfig::context_length)
+      .def_readwrite("decode_steps", &SchedulerConfig::decode_steps)
+      .def_readwrite("enable_prefix_cache", &SchedulerConfig::enable_prefix_cache)
+      .def_readwrite("policy", &SchedulerConfig::policy)
+      .def_readwrite("schedule_conservativeness", &SchedulerConfig::schedule_conservativeness);
+  py::class_<PyScheduler>(m, "Scheduler")
+      .def(py::init<const SchedulerConfig&>())
+      .def("add_request", &PyScheduler::add_request, py::arg("rid"), py::arg("prompt"), py::arg("max_new_tokens"),
+           py::arg("min_new_tokens") = 0, py::arg("temperature") = 1.0f, py::arg("top_p") = 1.0f,
+           py::arg("top_k") = 1 << 30, py::arg("stop_token_ids") = std::vector<int32_t>{})
+      .def("schedule", &PyScheduler::schedule)
+      .def("process_prefill", &PyScheduler::process_prefill)
+      .def("process_decode", &PyScheduler::process_decode)
+      .def("take_finished", &PyScheduler::take_finished)
+      .def("pause", [](PyScheduler& s) { s.s_.pause(); })
+      .def("resume", [](PyScheduler& s) { s.s_.resume(); })
+      .def("paused", [](PyScheduler& s) { return s.s_.paused(); })
+      .def("abort_all", [](PyScheduler& s) { return s.s_.abort_all(); })
+      .def("abort", [](PyScheduler& s, const std::string& rid) { return s.s_.abort(rid); })
+      .def("flush_cache", [](PyScheduler& s) { s.s_.flush_cache(); })
+      .def("set_version", [](PyScheduler& s, int v) { s.s_.set_version(v); })
+      .def("version", [](PyScheduler& s) { return s.s_.version(); })
+      .def("num_waiting", [](PyScheduler& s) { return s.s_.num_waiting(); })
+      .def("num_running", [](PyScheduler& s) { return s.s_.num_running(); })
+      .def("num_free_pages", [](PyScheduler& s) { return s.s_.num_free_pages(); })
+      .def("num_total_pages", [](PyScheduler& s) { return s.s_.num_total_pages(); })
+      .def("num_cached_pages", [](PyScheduler& s) { return s.s_.num_cached_pages(); })
+      .def("total_generated", [](PyScheduler& s) { return s.s_.total_generated(); })
+      .def("total_prompt_tokens", [](PyScheduler& s) { return s.s_.total_prompt_tokens(); })
+      .def("total_cached_tokens", [](PyScheduler& s) { return s.s_.total_cached_tokens(); })
+      .def("num_preemptions", [](PyScheduler& s) { return s.s_.num_preemptions(); })
+      .def("has_work", [](PyScheduler& s) { return s.s_.has_work(); });
+  m.def("ffd_allocate", &ffd_allocate, py::arg("values"), py::arg("capacity"), py::arg("min_groups"));
+  m.def("partition_balanced", &partition_balanced, py::arg("lens"), py::arg("k"), py::arg("min_size") = 1);
+  m.def("merge_intervals", &merge_intervals);
+}

@@ -1,0 +1,463 @@
+// Continuous-batching scheduler of the native rollout engine (host side, C++).
+//
+// Owns request state, the paged block manager and the per-step batch plan. The Python model runner
+// asks for a plan (`schedule`), executes it on the GPU (varlen prefill or hipGraph'd multi-step
+// decode), and hands sampled tokens back (`process_prefill` / `process_decode`). Semantics follow the
+// inference-server behaviour the reference relies on (SGLang flags in areal/api/cli_args.py:398-454;
+// abort-on-weight-update protocol in areal/engine/sglang_remote.py:121-309; the slot-refilling
+// generator of realhf/impl/model/nn/real_llm_generate.py:670-888):
+//   * prefill-first scheduling under a token budget (max_prefill_tokens), whole prompts (no chunking),
+//   * decode of all running requests, `decode_steps` tokens per plan,
+//   * preemption by recompute when the page pool runs dry,
+//   * pause / continue and abort-all for interruptible generation: aborted requests return the tokens
+//     generated so far with finish reason "abort", their pages are released and the prefix cache is
+//     flushed; the client re-issues prompt+partial output and the KV is recomputed by prefill under
+//     the new weights,
+//   * every generated token is tagged with the weight version that produced it.
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "block_manager.hpp"
+
+namespace areal {
+
+struct SamplingParams {
+  int max_new_tokens = 16;
+  int min_new_tokens = 0;
+  float temperature = 1.0f;  // <= 0: greedy
+  float top_p = 1.0f;
+  int top_k = 1 << 30;
+  std::vector<int32_t> stop_token_ids;
+};
+
+enum class ReqState { WAITING, RUNNING, FINISHED };
+
+struct Request {
+  int64_t id = 0;
+  std::string rid;
+  std::vector<int32_t> tokens;  // prompt followed by generated tokens
+  int prompt_len = 0;           // length of the ORIGINAL prompt (generated = tokens.size() - prompt_len)
+  SamplingParams sp;
+  std::vector<int> pages;
+  int num_cached = 0;           // tokens whose K/V are in `pages`
+  ReqState state = ReqState::WAITING;
+  std::vector<float> logprobs;
+  std::vector<int32_t> versions;
+  std::string finish_reason;
+  double t_arrive = 0, t_first = 0, t_last = 0, t_finish = 0;
+  std::vector<float> itl;
+  int n_preempted = 0;
+  int n_generated() const { return (int)tokens.size() - prompt_len; }
+};
+
+struct FinishedRequest {
+  std::string rid;
+  std::vector<int32_t> output_tokens;
+  std::vector<float> output_logprobs;
+  std::vector<int32_t> output_versions;
+  std::string finish_reason;
+  int prompt_len = 0;
+  int cached_tokens = 0;
+  double latency = 0, ttft = 0;
+  std::vector<float> itl;
+};
+
+struct Plan {
+  int kind = 0;  // 0 idle, 1 prefill, 2 decode
+  std::vector<int64_t> req_ids;
+  // prefill
+  std::vector<int32_t> input_ids, positions;
+  std::vector<int32_t> cu_q, cu_k;
+  std::vector<int64_t> slot_mapping;  // where the new tokens' K/V go
+  std::vector<int64_t> ctx_slots;     // slots of ALL context tokens (only when a prefix was reused)
+  bool has_prefix = false;
+  int max_q = 0, max_k = 0;
+  // decode
+  int n_steps = 0;
+  std::vector<int32_t> context_lens;
+  std::vector<int32_t> block_tables;  // [B, max_pages]
+  int max_pages = 0;
+  // sampling (both kinds)
+  std::vector<float> temperature, top_p;
+  std::vector<int32_t> top_k;
+};
+
+struct SchedulerConfig {
+  int num_pages = 1024;
+  int max_running_requests = 256;
+  int max_prefill_tokens = 32768;
+  int context_length = 32768;
+  int decode_steps = 1;
+  bool enable_prefix_cache = true;
+  std::string policy = "fcfs";  // "fcfs" | "lpm"
+  float schedule_conservativeness = 1.0f;
+};
+
+inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+class Scheduler {
+ public:
+  explicit Scheduler(const SchedulerConfig& cfg)
+      : cfg_(cfg), bm_(cfg.num_pages, cfg.enable_prefix_cache) {}
+
+  int64_t add_request(const std::string& rid, const std::vector<int32_t>& prompt, const SamplingParams& sp) {
+    auto r = std::make_unique<Request>();
+    r->id = next_id_++;
+    r->rid = rid;
+    r->tokens = prompt;
+    r->prompt_len = (int)prompt.size();
+    r->sp = sp;
+    r->t_arrive = now_s();
+    int64_t id = r->id;
+    if (prompt.empty() || (int)prompt.size() >= cfg_.context_length || sp.max_new_tokens <= 0) {
+      r->finish_reason = "length";
+      finish(*r);
+      return id;
+    }
+    waiting_.push_back(id);
+    reqs_[id] = std::move(r);
+    return id;
+  }
+
+  void pause() { paused_ = true; }
+  void resume() { paused_ = false; }
+  bool paused() const { return paused_; }
+  void set_version(int v) { version_ = v; }
+  int version() const { return version_; }
+
+  // Abort everything in flight (weight update). Returns the number of aborted requests.
+  int abort_all() {
+    int n = 0;
+    std::vector<int64_t> ids;
+    for (auto id : running_) ids.push_back(id);
+    for (auto id : waiting_) ids.push_back(id);
+    running_.clear();
+    waiting_.clear();
+    for (auto id : ids) {
+      auto it = reqs_.find(id);
+      if (it == reqs_.end()) continue;
+      it->second->finish_reason = "abort";
+      release_pages(*it->second, false);
+      finish(*it->second);
+      reqs_.erase(it);
+      ++n;
+    }
+    bm_.flush_cache();
+    return n;
+  }
+
+  bool abort(const std::string& rid) {
+    for (auto& kv : reqs_) {
+      if (kv.second->rid == rid) {
+        int64_t id = kv.first;
+        running_.erase(std::remove(running_.begin(), running_.end(), id), running_.end());
+        waiting_.erase(std::remove(waiting_.begin(), waiting_.end(), id), waiting_.end());
+        kv.second->finish_reason = "abort";
+        release_pages(*kv.second, false);
+        finish(*kv.second);
+        reqs_.erase(id);
+        return true;
+      }
+    }
+    return false;
+  }
+
+  void flush_cache() { bm_.flush_cache(); }
+
+  // ------------------------------------------------------------------------------ planning
+  Plan schedule() {
+    Plan p;
+    if (!paused_ && !waiting_.empty() && (int)running_.size() < cfg_.max_running_requests) {
+      plan_prefill(p);
+      if (p.kind == 1) return p;
+    }
+    if (!running_.empty() && !paused_) plan_decode(p);
+    return p;
+  }
+
+  // ---------------------------------------------------------------------- result handling
+  void process_prefill(const Plan& p, const int64_t* tokens, const float* logprobs) {
+    double t = now_s();
+    for (size_t i = 0; i < p.req_ids.size(); ++i) {
+      auto it = reqs_.find(p.req_ids[i]);
+      if (it == reqs_.end()) continue;
+      Request& r = *it->second;
+      r.num_cached = (int)r.tokens.size();
+      bm_.publish(r.tokens.data(), r.num_cached, r.pages);
+      append_token(r, (int32_t)tokens[i], logprobs[i], t);
+    }
+    sweep_finished();
+  }
+
+  // tokens / logprobs are [n_steps, B_padded] row-major with row stride `stride`.
+  void process_decode(const Plan& p, const int64_t* tokens, const float* logprobs, int stride) {
+    double t = now_s();
+    for (size_t i = 0; i < p.req_ids.size(); ++i) {
+      auto it = reqs_.find(p.req_ids[i]);
+      if (it == reqs_.end()) continue;
+      Request& r = *it->second;
+      for (int s = 0; s < p.n_steps; ++s) {
+        if (r.state == ReqState::FINISHED) break;
+        r.num_cached = (int)r.tokens.size();  // the consumed token's K/V is now cached
+        append_token(r, (int32_t)tokens[(size_t)s * stride + i], logprobs[(size_t)s * stride + i], t);
+      }
+    }
+    sweep_finished();
+  }
+
+  std::vector<FinishedRequest> take_finished() {
+    std::vector<FinishedRequest> out;
+    out.swap(finished_);
+    return out;
+  }
+
+  int num_waiting() const { return (int)waiting_.size(); }
+  int num_running() const { return (int)running_.size(); }
+  int num_free_pages() const { return bm_.num_free(); }
+  int num_total_pages() const { return bm_.num_total(); }
+  int num_cached_pages() const { return bm_.num_cached(); }
+  int64_t total_generated() const { return total_generated_; }
+  int64_t total_prompt_tokens() const { return total_prompt_; }
+  int64_t total_cached_tokens() const { return total_cached_; }
+  int64_t num_preemptions() const { return n_preempt_; }
+  bool has_work() const { return !waiting_.empty() || !running_.empty(); }
+
+ private:
+  static int pages_for(int ntok) { return (ntok + PAGE - 1) / PAGE; }
+
+  void fill_sampling(Plan& p, const Request& r) {
+    p.temperature.push_back(r.sp.temperature);
+    p.top_p.push_back(r.sp.top_p);
+    p.top_k.push_back(r.sp.top_k);
+  }
+
+  void plan_prefill(Plan& p) {
+    int budget = cfg_.max_prefill_tokens;
+    int reserve = (int)(running_.size() * cfg_.schedule_conservativeness);
+    if (cfg_.policy == "lpm" && waiting_.size() > 1) sort_waiting_lpm();
+    std::vector<int64_t> admitted;
+    while (!waiting_.empty() && (int)(running_.size() + admitted.size()) < cfg_.max_running_requests) {
+      int64_t id = waiting_.front();
+      Request& r = *reqs_[id];
+      int n = (int)r.tokens.size();
+      std::vector<int> pages;
+      int matched = bm_.match_prefix(r.tokens.data(), n, pages);
+      int new_tok = n - matched;
+      if (new_tok > budget && !admitted.empty()) {
+        bm_.release_all(pages);
+        break;
+      }
+      // pages for the whole context plus the first generated token
+      int need = pages_for(n + 1) - (int)pages.size();
+      if (need > bm_.num_free() - reserve) {
+        bm_.release_all(pages);
+        if (admitted.empty() && running_.empty() && need <= bm_.num_free()) {
+          // nothing else is running: ignore the reserve so a single large request can proceed
+        } else if (admitted.empty() && running_.empty()) {
+          // can never fit in the page pool: fail the request instead of stalling the queue
+          waiting_.pop_front();
+          r.finish_reason = "length";
+          finish(r);
+          reqs_.erase(id);
+          continue;
+        } else {
+          break;
+        }
+        matched = bm_.match_prefix(r.tokens.data(), n, pages);
+        new_tok = n - matched;
+        need = pages_for(n + 1) - (int)pages.size();
+      }
+      if (!bm_.allocate(need, pages)) {
+        bm_.release_all(pages);
+        break;
+      }
+      waiting_.pop_front();
+      r.pages = std::move(pages);
+      r.num_cached = matched;
+      r.state = ReqState::RUNNING;
+      total_prompt_ += new_tok;
+      total_cached_ += matched;
+      budget -= new_tok;
+      admitted.push_back(id);
+      if (matched > 0) p.has_prefix = true;
+      if (budget <= 0) break;
+    }
+    if (admitted.empty()) return;
+    p.kind = 1;
+    p.cu_q.push_back(0);
+    p.cu_k.push_back(0);
+    for (auto id : admitted) {
+      Request& r = *reqs_[id];
+      int n = (int)r.tokens.size();
+      int start = r.num_cached;
+      for (int t = start; t < n; ++t) {
+        p.input_ids.push_back(r.tokens[t]);
+        p.positions.push_back(t);
+        p.slot_mapping.push_back((int64_t)r.pages[t / PAGE] * PAGE + t % PAGE);
+      }
+      p.cu_q.push_back(p.cu_q.back() + (n - start));
+      p.cu_k.push_back(p.cu_k.back() + n);
+      p.max_q = std::max(p.max_q, n - start);
+      p.max_k = std::max(p.max_k, n);
+      p.req_ids.push_back(id);
+      fill_sampling(p, r);
+      running_.push_back(id);
+    }
+    if (p.has_prefix) {
+      for (auto id : admitted) {
+        Request& r = *reqs_[id];
+        int n = (int)r.tokens.size();
+        for (int t = 0; t < n; ++t) p.ctx_slots.push_back((int64_t)r.pages[t / PAGE] * PAGE + t % PAGE);
+      }
+    }
+  }
+
+  void plan_decode(Plan& p) {
+    int k = std::max(1, cfg_.decode_steps);
+    // make sure every running request owns pages for the next k positions; preempt from the back
+    size_t i = 0;
+    while (i < running_.size()) {
+      Request& r = *reqs_[running_[i]];
+      int last_pos = (int)r.tokens.size() - 1 + (k - 1);
+      last_pos = std::min(last_pos, cfg_.context_length - 1);
+      int need = pages_for(last_pos + 1) - (int)r.pages.size();
+      if (need > 0 && !bm_.allocate(need, r.pages)) {
+        if (running_.size() == 1) break;  // cannot preempt the only request; it will hit the length cap
+        preempt_last();
+        if (i >= running_.size()) break;
+        continue;
+      }
+      ++i;
+    }
+    if (running_.empty()) return;
+    p.kind = 2;
+    p.n_steps = k;
+    int max_pages = 0;
+    for (auto id : running_) max_pages = std::max(max_pages, (int)reqs_[id]->pages.size());
+    p.max_pages = max_pages;
+    p.block_tables.assign(running_.size() * (size_t)max_pages, 0);
+    size_t row = 0;
+    for (auto id : running_) {
+      Request& r = *reqs_[id];
+      int pos = (int)r.tokens.size() - 1;
+      p.req_ids.push_back(id);
+      p.input_ids.push_back(r.tokens.back());
+      p.positions.push_back(pos);
+      p.context_lens.push_back(pos + 1);
+      p.slot_mapping.push_back((int64_t)r.pages[pos / PAGE] * PAGE + pos % PAGE);
+      std::copy(r.pages.begin(), r.pages.end(), p.block_tables.begin() + row * max_pages);
+      fill_sampling(p, r);
+      ++row;
+    }
+  }
+
+  void preempt_last() {
+    int64_t id = running_.back();
+    running_.pop_back();
+    Request& r = *reqs_[id];
+    release_pages(r, false);
+    r.state = ReqState::WAITING;
+    r.num_cached = 0;
+    r.n_preempted++;
+    ++n_preempt_;
+    waiting_.push_front(id);
+  }
+
+  void sort_waiting_lpm() {
+    // longest-prefix-match first among the head of the queue (bounded work per step)
+    size_t n = std::min<size_t>(waiting_.size(), 128);
+    std::vector<std::pair<int, int64_t>> keyed;
+    for (size_t i = 0; i < n; ++i) {
+      Request& r = *reqs_[waiting_[i]];
+      std::vector<int> pages;
+      int m = bm_.match_prefix(r.tokens.data(), (int)r.tokens.size(), pages);
+      bm_.release_all(pages);
+      keyed.emplace_back(-m, waiting_[i]);
+    }
+    std::stable_sort(keyed.begin(), keyed.end(),
+                     [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (size_t i = 0; i < n; ++i) waiting_[i] = keyed[i].second;
+  }
+
+  void append_token(Request& r, int32_t tok, float lp, double t) {
+    r.tokens.push_back(tok);
+    r.logprobs.push_back(lp);
+    r.versions.push_back(version_);
+    ++total_generated_;
+    if (r.t_first == 0) r.t_first = t;
+    else r.itl.push_back((float)(t - r.t_last));
+    r.t_last = t;
+    int gen = r.n_generated();
+    bool stop_tok = false;
+    if (gen >= r.sp.min_new_tokens)
+      for (auto s : r.sp.stop_token_ids)
+        if (s == tok) { stop_tok = true; break; }
+    if (stop_tok) {
+      r.finish_reason = "stop";
+      r.state = ReqState::FINISHED;
+    } else if (gen >= r.sp.max_new_tokens || (int)r.tokens.size() >= cfg_.context_length) {
+      r.finish_reason = "length";
+      r.state = ReqState::FINISHED;
+    }
+  }
+
+  void sweep_finished() {
+    std::vector<int64_t> keep;
+    for (auto id : running_) {
+      Request& r = *reqs_[id];
+      if (r.state == ReqState::FINISHED) {
+        release_pages(r, true);
+        finish(r);
+        reqs_.erase(id);
+      } else {
+        keep.push_back(id);
+      }
+    }
+    running_.swap(keep);
+  }
+
+  void release_pages(Request& r, bool publish) {
+    if (publish && r.num_cached > 0) bm_.publish(r.tokens.data(), r.num_cached, r.pages);
+    bm_.release_all(r.pages);
+    r.pages.clear();
+  }
+
+  void finish(Request& r) {
+    FinishedRequest f;
+    r.t_finish = now_s();
+    f.rid = r.rid;
+    f.output_tokens.assign(r.tokens.begin() + r.prompt_len, r.tokens.end());
+    f.output_logprobs = r.logprobs;
+    f.output_versions = r.versions;
+    f.finish_reason = r.finish_reason;
+    f.prompt_len = r.prompt_len;
+    f.latency = r.t_finish - r.t_arrive;
+    f.ttft = r.t_first > 0 ? r.t_first - r.t_arrive : 0;
+    f.itl = r.itl;
+    r.state = ReqState::FINISHED;
+    finished_.push_back(std::move(f));
+  }
+
+  SchedulerConfig cfg_;
+  BlockManager bm_;
+  std::unordered_map<int64_t, std::unique_ptr<Request>> reqs_;
+  std::deque<int64_t> waiting_;
+  std::vector<int64_t> running_;
+  std::vector<FinishedRequest> finished_;
+  int64_t next_id_ = 1;
+  bool paused_ = false;
+  int version_ = 0;
+  int64_t total_generated_ = 0, total_prompt_ = 0, total_cached_ = 0, n_preempt_ = 0;
+};
+
+}  // namespace areal
