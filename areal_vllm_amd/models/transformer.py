@@ -131,20 +131,23 @@ class Attention(nn.Module):
             self.k_norm = nn.Parameter(torch.ones(D, dtype=dtype, device=device))
 
     def project_qkv(self, x):
+        """Fused q|k|v projection, returned 2-D [T, (hq + 2 hkv) * D] (not a view, RoPE runs in place)."""
         T = x.shape[0]
         D = self.cfg.head_dim
-        qkv = F.linear(x, self.qkv, self.qkv_bias).view(T, self.hq + 2 * self.hkv, D)
+        qkv = F.linear(x, self.qkv, self.qkv_bias)
         if self.cfg.qk_norm:
-            q, _ = ops.rmsnorm(qkv[:, :self.hq], self.q_norm, self.cfg.rms_norm_eps)
-            k, _ = ops.rmsnorm(qkv[:, self.hq:self.hq + self.hkv], self.k_norm, self.cfg.rms_norm_eps)
-            qkv = torch.cat([q, k, qkv[:, self.hq + self.hkv:]], 1)
+            q3 = qkv.view(T, self.hq + 2 * self.hkv, D)
+            q, _ = ops.rmsnorm(q3[:, :self.hq], self.q_norm, self.cfg.rms_norm_eps)
+            k, _ = ops.rmsnorm(q3[:, self.hq:self.hq + self.hkv], self.k_norm, self.cfg.rms_norm_eps)
+            qkv = torch.cat([q, k, q3[:, self.hq + self.hkv:]], 1).view(T, -1)
         return qkv
 
     def forward(self, x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None):
         T = x.shape[0]
+        D = self.cfg.head_dim
         x = _AllReduceBwd.apply(x, tp_group)
         qkv = self.project_qkv(x)
-        qkv = ops.apply_rope(qkv, positions, rope, self.hq + self.hkv)
+        qkv = ops.apply_rope(qkv, positions, rope, self.hq + self.hkv, D).view(T, self.hq + 2 * self.hkv, D)
         if sp is not None:
             attn = sp.attention(qkv, self.hq, self.hkv, cu_seqlens, max_seqlen)
         else:

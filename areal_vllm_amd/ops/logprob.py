@@ -106,9 +106,25 @@ def _bwd_inplace(logits, labels, temperature, lse, ez, dlogp, dent, vocab_start=
     return logits
 
 
+def _aligned_copy(logits: torch.Tensor) -> torch.Tensor:
+    """Copy of `logits` whose rows start on 16-byte boundaries (row stride padded to 8 elements)."""
+    T, V = logits.shape
+    Vp = (V + 7) // 8 * 8
+    buf = torch.empty(T, Vp, dtype=logits.dtype, device=logits.device)[:, :V]
+    buf.copy_(logits)
+    return buf
+
+
+def _is_aligned(logits: torch.Tensor) -> bool:
+    eb = logits.element_size()
+    return logits.stride(1) == 1 and (logits.stride(0) * eb) % 16 == 0 and logits.data_ptr() % 16 == 0
+
+
 class _LogitsLogprobFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels, temperature, want_entropy):
+        if logits.is_cuda and not _is_aligned(logits):
+            logits = _aligned_copy(logits)
         logp, ent, lse, ez = _fwd(logits, labels, temperature)
         ctx.save_for_backward(logits, labels, lse, ez)
         ctx.temperature = temperature
@@ -117,7 +133,7 @@ class _LogitsLogprobFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogp, dent):
         logits, labels, lse, ez = ctx.saved_tensors
-        g = logits.clone()
+        g = _aligned_copy(logits)
         _bwd_inplace(g, labels, ctx.temperature, lse, ez,
                      dlogp.contiguous().float() if dlogp is not None else None,
                      dent.contiguous().float() if dent is not None else None)

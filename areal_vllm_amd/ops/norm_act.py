@@ -200,14 +200,17 @@ def rope_inplace_(x: torch.Tensor, positions: torch.Tensor, table: RotaryTable, 
 
 
 class _RopeFn(torch.autograd.Function):
+    """In-place RoPE on the 2-D output of the fused qkv GEMM (viewed as [T, heads, D] internally)."""
+
     @staticmethod
-    def forward(ctx, qkv, positions, table, n_rot_heads):
+    def forward(ctx, qkv2d, positions, table, n_rot_heads, head_dim):
         ctx.table = table
         ctx.n_rot = n_rot_heads
+        ctx.head_dim = head_dim
         ctx.save_for_backward(positions)
-        ctx.mark_dirty(qkv)
-        rope_inplace_(qkv, positions, table, n_rot_heads, 1.0)
-        return qkv
+        ctx.mark_dirty(qkv2d)
+        rope_inplace_(qkv2d.view(qkv2d.shape[0], -1, head_dim), positions, table, n_rot_heads, 1.0)
+        return qkv2d
 
     @staticmethod
     def backward(ctx, d):
@@ -215,10 +218,11 @@ class _RopeFn(torch.autograd.Function):
         # The incoming gradient is the freshly allocated dqkv of the attention backward and has
         # no other consumer, so the inverse rotation is applied in place.
         d = d.contiguous()
-        rope_inplace_(d, positions, ctx.table, ctx.n_rot, -1.0)
-        return d, None, None, None
+        rope_inplace_(d.view(d.shape[0], -1, ctx.head_dim), positions, ctx.table, ctx.n_rot, -1.0)
+        return d, None, None, None, None
 
 
-def apply_rope(qkv: torch.Tensor, positions: torch.Tensor, table: RotaryTable, n_rot_heads: int) -> torch.Tensor:
-    """Differentiable in-place RoPE on the q and k heads of a fused [T, Hq+2Hkv, D] projection."""
-    return _RopeFn.apply(qkv, positions, table, n_rot_heads)
+def apply_rope(qkv2d: torch.Tensor, positions: torch.Tensor, table: RotaryTable, n_rot_heads: int,
+               head_dim: int) -> torch.Tensor:
+    """Differentiable in-place RoPE on the q and k heads of a fused [T, (Hq+2Hkv)*D] projection."""
+    return _RopeFn.apply(qkv2d, positions, table, n_rot_heads, head_dim)

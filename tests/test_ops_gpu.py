@@ -1,0 +1,362 @@
+"""Numerics of every HIP kernel against a plain PyTorch fp32 reference of the same op (GPU only).
+
+Mirrors the reference's native-extension tests (realhf/tests/cpp_extensions/test_cugae.py,
+test_interval_ops.py) and extends them to the kernels the reference borrows from external libraries.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import areal_vllm_amd.ops as ops
+from areal_vllm_amd.ops import attention as A
+from areal_vllm_amd.ops import logprob as LP
+from areal_vllm_amd.ops import norm_act as NA
+from areal_vllm_amd.ops import optim as OP
+from areal_vllm_amd.ops import rl as RL
+from areal_vllm_amd.ops import sampling as SM
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(a, b, atol, rtol, name=""):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).float().mean().item()
+    assert bad < 1e-3, f"{name}: max err {err.max().item():.4g}, frac bad {bad:.4g}"
+
+
+def test_native_library_loaded():
+    assert ops.hip_available()
+    with open("/proc/self/maps") as f:
+        assert "libareal_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("T,H", [(7, 1536), (1024, 1536), (333, 3584), (65, 5120), (40, 128)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_rmsnorm_fwd_bwd(T, H, with_res):
+    torch.manual_seed(0)
+    x = torch.randn(T, H, device=DEV).bfloat16().requires_grad_(True)
+    r = torch.randn(T, H, device=DEV).bfloat16().requires_grad_(True) if with_res else None
+    w = (1 + 0.1 * torch.randn(H, device=DEV)).bfloat16().requires_grad_(True)
+    y, s = ops.rmsnorm(x, w, 1e-6, r)
+    gy = torch.randn_like(y)
+    gs = torch.randn_like(s)
+    if with_res:
+        (y.float() * gy.float()).sum().add((s.float() * gs.float()).sum()).backward()
+    else:
+        (y.float() * gy.float()).sum().backward()
+    # fp32 reference
+    xf = x.detach().float().requires_grad_(True)
+    rf = r.detach().float().requires_grad_(True) if with_res else None
+    wf = w.detach().float().requires_grad_(True)
+    sf = (xf + rf).detach().bfloat16().float() + ((xf + rf) - (xf + rf).detach()) if with_res else xf
+    yf = sf * torch.rsqrt(sf.pow(2).mean(-1, keepdim=True) + 1e-6) * wf
+    loss = (yf * gy.float()).sum()
+    if with_res:
+        loss = loss + (sf * gs.float()).sum()
+    loss.backward()
+    _close(y, yf, 2e-2, 2e-2, "y")
+    _close(x.grad, xf.grad, 3e-2, 3e-2, "dx")
+    _close(w.grad, wf.grad, 0.5 + 0.02 * math.sqrt(T), 3e-2, "dw")
+    if with_res:
+        _close(r.grad, rf.grad, 3e-2, 3e-2, "dres")
+
+
+@pytest.mark.parametrize("T,F", [(5, 8960), (1000, 8960), (77, 256)])
+def test_swiglu(T, F):
+    torch.manual_seed(1)
+    gu = torch.randn(T, 2 * F, device=DEV).bfloat16().requires_grad_(True)
+    out = ops.swiglu(gu)
+    g = torch.randn_like(out)
+    out.backward(g)
+    guf = gu.detach().float().requires_grad_(True)
+    ref = torch.nn.functional.silu(guf[:, :F]) * guf[:, F:]
+    ref.backward(g.float())
+    _close(out, ref, 1e-2, 1e-2, "swiglu")
+    _close(gu.grad, guf.grad, 2e-2, 2e-2, "dswiglu")
+
+
+@pytest.mark.parametrize("D", [128, 64])
+def test_rope_roundtrip_and_ref(D):
+    torch.manual_seed(2)
+    T, Hq, Hkv = 300, 12, 2
+    tab = ops.RotaryTable(D, 4096, 1e6, DEV)
+    x = torch.randn(T, Hq + 2 * Hkv, D, device=DEV).bfloat16()
+    pos = torch.randint(0, 4096, (T,), device=DEV, dtype=torch.int32)
+    ref = NA._rope_ref(x.clone().cpu(), pos.cpu(), ops.RotaryTable(D, 4096, 1e6, "cpu"), Hq + Hkv, 1.0)
+    y = x.clone()
+    ops.rope_inplace_(y, pos, tab, Hq + Hkv, 1.0)
+    _close(y.cpu(), ref, 2e-2, 2e-2, "rope")
+    assert torch.equal(y[:, Hq + Hkv:], x[:, Hq + Hkv:])
+    ops.rope_inplace_(y, pos, tab, Hq + Hkv, -1.0)
+    _close(y, x, 3e-2, 3e-2, "rope inverse")
+
+
+def _rand_seqlens(B, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, (B,), generator=g).tolist()
+
+
+@pytest.mark.parametrize("Hq,Hkv,lens", [
+    (12, 2, [1, 33, 128, 200, 65]),
+    (4, 4, [257, 64]),
+    (28, 4, [700, 1, 129]),
+    (8, 1, [1024]),
+])
+def test_flash_attn_fwd_bwd(Hq, Hkv, lens):
+    torch.manual_seed(3)
+    D = 128
+    T = sum(lens)
+    cu = torch.tensor([0] + np.cumsum(lens).tolist(), dtype=torch.int32, device=DEV)
+    qkv = (0.5 * torch.randn(T, Hq + 2 * Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
+    out = ops.flash_attn_varlen_qkv(qkv, cu, max(lens), Hq, Hkv)
+    g = torch.randn_like(out)
+    out.backward(g)
+    qf = qkv.detach().float().cpu().requires_grad_(True)
+    ref, _ = A.attention_varlen_ref(qf[:, :Hq], qf[:, Hq:Hq + Hkv], qf[:, Hq + Hkv:], cu.cpu(), cu.cpu(),
+                                    1.0 / math.sqrt(D), True)
+    ref.backward(g.float().cpu())
+    _close(out.cpu(), ref, 2e-2, 2e-2, "attn out")
+    _close(qkv.grad[:, :Hq].cpu(), qf.grad[:, :Hq], 3e-2, 5e-2, "dq")
+    _close(qkv.grad[:, Hq:Hq + Hkv].cpu(), qf.grad[:, Hq:Hq + Hkv], 3e-2, 5e-2, "dk")
+    _close(qkv.grad[:, Hq + Hkv:].cpu(), qf.grad[:, Hq + Hkv:], 3e-2, 5e-2, "dv")
+
+
+def test_flash_attn_prefix_extend():
+    """q shorter than k (cached prefix): causal mask aligned bottom-right."""
+    torch.manual_seed(4)
+    D, Hq, Hkv = 128, 12, 2
+    lq, lk = [5, 70, 1], [100, 70, 300]
+    cu_q = torch.tensor([0] + np.cumsum(lq).tolist(), dtype=torch.int32, device=DEV)
+    cu_k = torch.tensor([0] + np.cumsum(lk).tolist(), dtype=torch.int32, device=DEV)
+    q = torch.randn(sum(lq), Hq, D, device=DEV).bfloat16() * 0.5
+    k = torch.randn(sum(lk), Hkv, D, device=DEV).bfloat16() * 0.5
+    v = torch.randn(sum(lk), Hkv, D, device=DEV).bfloat16()
+    out, lse = ops.flash_attn_varlen(q, k, v, cu_q, cu_k, max(lq))
+    ref, lse_ref = A.attention_varlen_ref(q.cpu(), k.cpu(), v.cpu(), cu_q.cpu(), cu_k.cpu(), 1 / math.sqrt(D), True)
+    _close(out.cpu(), ref, 2e-2, 2e-2, "extend out")
+    _close(lse.cpu(), lse_ref, 2e-2, 1e-2, "lse")
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(12, 2, 128), (28, 4, 128), (8, 8, 128), (16, 2, 64)])
+@pytest.mark.parametrize("nsplit", [1, 4])
+def test_paged_decode_and_cache_write(Hq, Hkv, D, nsplit):
+    torch.manual_seed(5)
+    B = 9
+    ctx = [1, 31, 32, 33, 64, 100, 257, 500, 77]
+    max_pages = (max(ctx) + 31) // 32
+    num_pages = 1 + sum((c + 31) // 32 for c in ctx)
+    kc, vc = ops.alloc_kv_cache(num_pages, Hkv, D, torch.bfloat16, DEV)
+    tab = ops.RotaryTable(D, 2048, 1e4, DEV)
+    bt = torch.zeros(B, max_pages, dtype=torch.int32, device=DEV)
+    nxt = 1
+    ks, vs = [], []
+    for b, c in enumerate(ctx):
+        n = (c + 31) // 32
+        pages = torch.arange(nxt, nxt + n, dtype=torch.int32)
+        nxt += n
+        bt[b, :n] = pages.to(DEV)
+        qkv = torch.randn(c, Hq + 2 * Hkv, D, device=DEV).bfloat16()
+        pos = torch.arange(c, dtype=torch.int32, device=DEV)
+        slots = (pages.long()[pos.cpu().long() // 32] * 32 + pos.cpu().long() % 32).to(DEV)
+        ref_qkv = NA._rope_ref(qkv.clone().cpu(), pos.cpu(), ops.RotaryTable(D, 2048, 1e4, "cpu"), Hq + Hkv, 1.0)
+        ops.rope_and_cache_write_(qkv, pos, slots, tab, kc, vc, Hq, Hkv)
+        _close(qkv.cpu(), ref_qkv, 2e-2, 2e-2, "rope in cache write")
+        ks.append(qkv[:, Hq:Hq + Hkv].clone())
+        vs.append(qkv[:, Hq + Hkv:].clone())
+        kg, vg = ops.cache_gather(kc, vc, slots)
+        assert torch.equal(kg, ks[-1]) and torch.equal(vg, vs[-1])
+    q = torch.randn(B, Hq, D, device=DEV).bfloat16()
+    cl = torch.tensor(ctx, dtype=torch.int32, device=DEV)
+    out = ops.paged_attention_decode(q, kc, vc, bt, cl, nsplit=nsplit)
+    ref = A.paged_decode_ref(q.cpu(), kc.cpu(), vc.cpu(), bt.cpu(), cl.cpu(), 1 / math.sqrt(D))
+    _close(out.cpu(), ref, 2e-2, 2e-2, "paged decode")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("V", [151936, 1000, 517])
+def test_logprob_entropy_fwd_bwd(dtype, V):
+    torch.manual_seed(6)
+    T = 37
+    Vp = (V + 7) // 8 * 8
+    base = (3 * torch.randn(T, Vp, device=DEV)).to(dtype)
+    logits = base[:, :V].detach().requires_grad_(True)
+    labels = torch.randint(0, V, (T,), device=DEV)
+    temp = 0.7
+    logp, ent = ops.gather_logprobs_entropy(logits, labels, temp)
+    gl, ge = torch.randn(T, device=DEV), torch.randn(T, device=DEV)
+    ((logp * gl).sum() + (ent * ge).sum()).backward()
+    lf = logits.detach().float().requires_grad_(True)
+    ls = torch.log_softmax(lf / temp, -1)
+    ref_lp = ls.gather(-1, labels.unsqueeze(-1)).squeeze(-1)
+    ref_ent = -(ls.exp() * ls).sum(-1)
+    ((ref_lp * gl).sum() + (ref_ent * ge).sum()).backward()
+    _close(logp, ref_lp, 1e-3, 1e-4, "logp")
+    _close(ent, ref_ent, 1e-3, 1e-3, "entropy")
+    tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+    _close(logits.grad, lf.grad, tol * lf.grad.abs().max().item(), 2e-2, "dlogits")
+
+
+def test_lm_head_logprobs_matches_unfused():
+    torch.manual_seed(7)
+    T, H, V = 300, 256, 4096
+    h = torch.randn(T, H, device=DEV).bfloat16().requires_grad_(True)
+    w = (0.05 * torch.randn(V, H, device=DEV)).bfloat16().requires_grad_(True)
+    labels = torch.randint(0, V, (T,), device=DEV)
+    lp, ent = ops.lm_head_logprobs(h, w, labels, 1.0, chunk=128)
+    g = torch.randn(T, device=DEV)
+    (lp * g).sum().backward()
+    hf, wf = h.detach().float().requires_grad_(True), w.detach().float().requires_grad_(True)
+    lg = (hf @ wf.t()).detach().bfloat16().float() + ((hf @ wf.t()) - (hf @ wf.t()).detach())
+    ls = torch.log_softmax(lg, -1)
+    ref = ls.gather(-1, labels.unsqueeze(-1)).squeeze(-1)
+    (ref * g).sum().backward()
+    _close(lp, ref, 2e-3, 1e-3, "fused logp")
+    _close(h.grad, hf.grad, 2e-2 * hf.grad.abs().max().item(), 5e-2, "dh")
+    _close(w.grad, wf.grad, 2e-2 * wf.grad.abs().max().item(), 5e-2, "dw")
+
+
+@pytest.mark.parametrize("max_seqlen", [32, 128, 512, 5000])
+@pytest.mark.parametrize("bs", [2, 4, 33])
+@pytest.mark.parametrize("gamma,lam", [(0.9, 0.5), (1.0, 1.0), (0.99, 0.95)])
+def test_gae_1d_packed(max_seqlen, bs, gamma, lam):
+    torch.manual_seed(8)
+    seqlens = torch.randint(1, max_seqlen, (bs,), dtype=torch.int32)
+    total = int(seqlens.sum())
+    rewards = torch.randn(total)
+    values = torch.randn(total + bs)
+    bootstrap = torch.rand(bs) > 0.5
+    cu = torch.nn.functional.pad(seqlens.cumsum(0), (1, 0)).int()
+    adv, ret = ops.gae_1d_packed(rewards.to(DEV), values.to(DEV), cu.to(DEV), bootstrap.to(DEV), gamma, lam)
+    radv, rret = RL.gae_1d_packed_ref(rewards.double(), values.double(), cu, bootstrap, gamma, lam)
+    scale = max(1.0, radv.abs().max().item())
+    assert torch.allclose(adv.cpu().double(), radv, atol=2e-4 * scale), (adv.cpu() - radv).abs().max()
+    assert torch.allclose(ret.cpu().double(), rret, atol=2e-4 * scale)
+
+
+def test_gae_padded_and_2d():
+    torch.manual_seed(9)
+    B, S = 7, 300
+    r, v = torch.randn(B, S), torch.randn(B, S)
+    ne = torch.rand(B) > 0.5
+    adv, ret = ops.gae_padded(r.to(DEV), v.to(DEV), ne.to(DEV), 0.99, 0.9)
+    radv, rret = RL.gae_padded_ref(r, v, ne, 0.99, 0.9)
+    assert torch.allclose(adv.cpu(), radv, atol=1e-3) and torch.allclose(ret.cpu(), rret, atol=1e-3)
+    # segmented
+    H = 200
+    rewards, values = torch.randn(B, H), torch.randn(B, H + 1)
+    done = torch.zeros(B, H + 1, dtype=torch.bool)
+    idx, cu, flags = [], [0], []
+    for b in range(B):
+        ts = sorted(np.random.RandomState(b).choice(np.arange(2, H - 1), size=b % 4, replace=False).tolist())
+        for t in ts:
+            done[b, t] = True
+            idx.append(t)
+            flags.append(bool((t + b) % 2))
+        cu.append(len(idx))
+    idx_t = torch.tensor(idx, dtype=torch.int32)
+    cu_t = torch.tensor(cu, dtype=torch.int32)
+    fl_t = torch.tensor(flags, dtype=torch.bool)
+    for overlapped in (True, False):
+        a, rt = ops.gae_2d(rewards.to(DEV), values.to(DEV), done.to(DEV), idx_t.to(DEV), cu_t.to(DEV), fl_t.to(DEV),
+                           3, 0.97, 0.8, overlapped)
+        ra, rr = RL.gae_2d_ref(rewards, values, done, idx_t, cu_t, fl_t, 0 if overlapped else 1, 0.97, 0.8)
+        assert torch.allclose(a.cpu(), ra, atol=1e-3), (a.cpu() - ra).abs().max()
+        assert torch.allclose(rt.cpu(), rr, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_interval_ops(dtype):
+    torch.manual_seed(10)
+    n = 1 << 20
+    flat = torch.randn(n, device=DEV).to(dtype)
+    rs = np.random.RandomState(0)
+    starts = np.sort(rs.choice(n - 5000, 700, replace=False))
+    iv = np.stack([starts, starts + rs.randint(1, 4000, 700)], 1)
+    iv = ops.merge_intervals(iv)
+    packed = ops.slice_intervals(flat, iv)
+    ref = torch.cat([flat[s:e] for s, e in iv])
+    assert torch.equal(packed, ref)
+    flat2 = torch.zeros_like(flat)
+    ops.set_intervals(packed, flat2, iv)
+    for s, e in iv[:50]:
+        assert torch.equal(flat2[s:e], flat[s:e])
+    mask = torch.zeros(n, dtype=torch.bool, device=DEV)
+    for s, e in iv:
+        mask[s:e] = True
+    assert flat2[~mask].abs().sum() == 0
+
+
+@pytest.mark.parametrize("gdtype", [torch.bfloat16, torch.float32])
+def test_adamw_and_norm(gdtype):
+    torch.manual_seed(11)
+    n = 1_000_003
+    p0 = torch.randn(n, device=DEV)
+    g = torch.randn(n, device=DEV).to(gdtype)
+    master, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    state = torch.zeros(8, device=DEV)
+    ref_p = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref_p], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1)
+    for step in range(3):
+        state[0] = 0
+        ops.sumsq_(g, state)
+        norm_ref = g.float().norm()
+        ops.adam_prepare_(state, 1.0, 1.0, 0.9, 0.95)
+        ops.adamw_(master, m, v, g, shadow, state, 1e-3, 0.9, 0.95, 1e-8, 0.1)
+        assert abs(state[1].item() - norm_ref.item()) / norm_ref.item() < 1e-3
+        ref_p.grad = g.float() * min(1.0, 1.0 / (norm_ref.item() + 1e-6))
+        opt.step()
+    _close(master, ref_p.detach(), 1e-5, 1e-4, "adam master")
+    _close(shadow, ref_p.detach(), 1e-2, 1e-2, "adam shadow")
+    # non-finite gradient: the update is skipped
+    before = master.clone()
+    state[0] = float("inf")
+    ops.adam_prepare_(state, 1.0, 1.0, 0.9, 0.95)
+    ops.adamw_(master, m, v, g, shadow, state, 1e-3, 0.9, 0.95, 1e-8, 0.1)
+    assert torch.equal(before, master) and state[3].item() == 0.0
+    x = torch.randn(1000, device=DEV)
+    y = x.clone()
+    ops.scale_(y, 0.5)
+    assert torch.allclose(y, x * 0.5)
+
+
+def test_sampling_distribution_and_filters():
+    torch.manual_seed(12)
+    V = 1000
+    B = 512
+    row = torch.randn(V, device=DEV) * 2
+    logits = row.unsqueeze(0).repeat(B, 1).bfloat16()
+    probs = torch.softmax(logits[0].float(), -1)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    counts = torch.zeros(V, device=DEV)
+    for it in range(40):
+        tok, lp = ops.sample(logits, None, None, None, seed=123, step=step)
+        counts += torch.bincount(tok, minlength=V).float()
+        ref_lp = torch.log_softmax(logits[0].float(), -1)[tok]
+        assert torch.allclose(lp, ref_lp, atol=1e-3)
+    assert step.item() == 40
+    emp = counts / counts.sum()
+    assert (emp - probs).abs().max().item() < 0.02
+    top = probs.topk(5).indices
+    assert ((emp[top] - probs[top]).abs() / probs[top]).max().item() < 0.15
+    # greedy
+    temp0 = torch.zeros(B, device=DEV)
+    tok, _ = ops.sample(logits, temp0, None, None, seed=1, step=step)
+    assert (tok == logits[0].float().argmax()).all()
+    # top-k = 3 / top-p = 0.5
+    t1 = torch.ones(B, device=DEV)
+    k3 = torch.full((B,), 3, dtype=torch.int32, device=DEV)
+    p1 = torch.ones(B, device=DEV)
+    tok, _ = ops.sample(logits, t1, k3, p1, seed=5, step=step)
+    assert set(tok.tolist()) <= set(probs.topk(3).indices.tolist())
+    kall = torch.full((B,), V, dtype=torch.int32, device=DEV)
+    p5 = torch.full((B,), 0.5, device=DEV)
+    tok, _ = ops.sample(logits, t1, kall, p5, seed=6, step=step)
+    sp, si = torch.sort(probs, descending=True)
+    nucleus = set(si[: int(((torch.cumsum(sp, 0) - sp) < 0.5).sum())].tolist())
+    assert set(tok.tolist()) <= nucleus
