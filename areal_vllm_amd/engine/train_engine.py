@@ -1,0 +1,480 @@
+"""Native SPMD train engine: packed micro-batches -> HIP-kernel transformer -> ZeRO-sharded AdamW.
+
+Implements the reference's ``TrainEngine`` contract (``areal/api/engine_api.py:39-155``) with the
+behaviour of its FSDP engine (``areal/engine/base_hf_engine.py:116-558``, ``areal/engine/fsdp_engine.py:
+265-729``): token-budget micro-batching, global-token-mean loss scaling, grad-norm clipping with
+skip-on-non-finite, HF-format save/load, per-rank optimizer state files, weight upload to rollout
+engines (disk / collective / in-process). Parallelism (dp x cp x tp, pipeline stages via
+``parallel/pipeline.py``) comes from the allocation mode.
+
+Loss functions receive a ``LogitsProxy`` instead of a dense ``[T, V]`` tensor: ``proxy.logprobs_entropy(
+labels, temperature)`` runs the fused LM-head + log-prob kernel, ``proxy.materialize()`` returns dense
+logits for loss functions written against the reference's signature.
+"""
+import dataclasses
+import gc
+import math
+import os
+import time
+from concurrent.futures import Future
+from typing import Any, Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..api.alloc_mode import ParallelStrategy
+from ..api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
+from ..api.engine_api import Scheduling, TrainEngine
+from ..api.io_struct import FinetuneSpec, ParamSpec, SaveLoadMeta, WeightUpdateMeta
+from ..models import hf_io
+from ..models.config import PRESETS, ModelConfig, preset
+from ..models.transformer import ALIGN, FlatParams, Transformer
+from ..parallel import comm
+from ..parallel.grid import ProcessGrid, init_distributed
+from ..parallel.zero import ShardedAdamW, lr_lambda
+from ..utils import datapack, logging, name_resolve, names
+from ..utils.data import (
+    MicroBatchList,
+    amend_position_ids,
+    pad_mb_list,
+    repad_packed,
+    split_padded_tensor_dict_into_mb_list,
+    unpack_sequence,
+)
+
+logger = logging.getLogger("train-engine")
+
+
+class LogitsProxy:
+    """Lazy view of the LM-head output for one packed micro-batch (padding rows already stripped)."""
+
+    def __init__(self, model: Transformer, hidden: torch.Tensor, chunk: int, keep_logits: bool, tp_group=None):
+        self.model = model
+        self.hidden = hidden
+        self.chunk = chunk
+        self.keep_logits = keep_logits
+        self.tp_group = tp_group
+        self._dense = None
+
+    @property
+    def shape(self):
+        return (self.hidden.shape[0], self.model.cfg.vocab_size)
+
+    @property
+    def device(self):
+        return self.hidden.device
+
+    def logprobs_entropy(self, labels: torch.Tensor, temperature: float = 1.0):
+        return self.model.logprobs(self.hidden, labels, temperature, self.chunk, self.keep_logits)
+
+    def logprobs(self, labels: torch.Tensor, temperature: float = 1.0):
+        return self.logprobs_entropy(labels, temperature)[0]
+
+    def values(self):
+        return self.model.values(self.hidden)
+
+    def materialize(self) -> torch.Tensor:
+        if self._dense is None:
+            self._dense = self.model.logits(self.hidden)
+        return self._dense
+
+
+def _resolve_model_config(path: str, is_critic: bool) -> ModelConfig:
+    if path and os.path.isdir(path) and os.path.exists(os.path.join(path, "config.json")):
+        return ModelConfig.from_pretrained(path, is_critic=is_critic)
+    key = (path or "").lower()
+    if key in PRESETS:
+        return preset(key, is_critic=is_critic)
+    aliases = {"qwen/qwen2.5-1.5b-instruct": "qwen2-1.5b", "qwen/qwen2-1.5b-instruct": "qwen2-1.5b",
+               "qwen/qwen2-1.5b": "qwen2-1.5b", "qwen/qwen2.5-1.5b": "qwen2-1.5b",
+               "qwen/qwen2.5-7b-instruct": "qwen2.5-7b", "qwen/qwen2.5-7b": "qwen2.5-7b",
+               "qwen/qwen2.5-32b-instruct": "qwen2.5-32b", "qwen/qwen2.5-32b": "qwen2.5-32b"}
+    if key in aliases:
+        return preset(aliases[key], is_critic=is_critic)
+    raise FileNotFoundError(f"model path '{path}' is neither a HF checkpoint directory nor a known preset")
+
+
+class NativeTrainEngine(TrainEngine):
+    def __init__(self, config: TrainEngineConfig):
+        self.config = config
+        self.optimizer_config: Optional[OptimizerConfig] = config.optimizer
+        self.model: Optional[Transformer] = None
+        self.optimizer: Optional[ShardedAdamW] = None
+        self.grid: Optional[ProcessGrid] = None
+        self.model_config: Optional[ModelConfig] = None
+        self.is_critic = False
+        self._version = 0
+        self._lr_step = 0
+        self._total_steps = 1
+        self.initialized = False
+        self.own_global_group = False
+        self.device = torch.device("cpu")
+        self._weight_update_group = None
+        self._local_rollout_engine = None
+        self._training = True
+
+    # ------------------------------------------------------------------ process groups
+    def create_process_group(self, parallel_strategy: Optional[ParallelStrategy] = None):
+        from ..platforms import current_platform
+
+        if not dist.is_initialized():
+            init_distributed()
+            self.own_global_group = True
+        if current_platform.device_type == "cuda":
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if parallel_strategy is None:
+            parallel_strategy = ParallelStrategy(data_parallel_size=dist.get_world_size())
+        self.parallel_strategy = parallel_strategy
+        assert parallel_strategy.world_size == dist.get_world_size(), (
+            f"parallel strategy {parallel_strategy} needs {parallel_strategy.world_size} ranks, "
+            f"world has {dist.get_world_size()}")
+        self.grid = ProcessGrid(parallel_strategy)
+        self.rank = dist.get_rank()
+        self.world_size = dist.get_world_size()
+
+    @property
+    def data_parallel_group(self):
+        return self.grid.group("dp")
+
+    @property
+    def data_parallel_rank(self) -> int:
+        return self.grid.rank_in("dp")
+
+    @property
+    def data_parallel_world_size(self) -> int:
+        return self.grid.dp
+
+    def current_data_parallel_head(self) -> int:
+        return self.grid.dp_head_global_rank()
+
+    def is_data_parallel_head(self) -> bool:
+        return self.grid.is_dp_head()
+
+    @property
+    def context_and_model_parallel_group(self):
+        return self.grid.group("mp")
+
+    def get_scheduling_config(self) -> Scheduling:
+        return Scheduling(cpu=4, gpu=1, mem=32 * 1024, type="worker")
+
+    # --------------------------------------------------------------------- initialisation
+    def initialize(self, addr: Optional[str] = None, ft_spec: Optional[FinetuneSpec] = None):
+        if self.grid is None:
+            self.create_process_group()
+        cfg = self.config
+        dtype = getattr(torch, cfg.dtype)
+        mc = _resolve_model_config(cfg.path, self.is_critic)
+        self.model_config = mc
+        g = self.grid
+        tik = time.perf_counter()
+        if g.pp > 1:
+            from ..parallel.pipeline import stage_layer_range
+
+            lr = stage_layer_range(mc.n_layers, g.pp, g.coord.pp)
+        else:
+            lr = (0, mc.n_layers)
+        self.model = Transformer(
+            mc, dtype=dtype, device=self.device, tp_size=g.tp, tp_rank=g.coord.tp, tp_group=g.group("tp"),
+            layer_range=lr, has_embed=g.coord.pp == 0, has_head=g.coord.pp == g.pp - 1,
+            ep_size=g.ep, ep_rank=g.rank_in("ep"), ep_group=g.group("ep"),
+            gradient_checkpointing=cfg.gradient_checkpointing,
+        )
+        if g.cp > 1:
+            from ..parallel.ulysses import UlyssesContext
+
+            self.model.sp = UlyssesContext(g.group("cp"), g.cp, g.coord.cp)
+        flat = self.model.flatten(pad_to=g.dp * g.cp)
+        if cfg.init_from_scratch or not (cfg.path and os.path.isdir(cfg.path)):
+            # same seed on every dp replica; tp/pp shards draw from different streams
+            self.model.init_weights(seed=1 + 1000 * g.coord.tp + 100000 * g.coord.pp)
+            if self.is_critic and cfg.init_critic_from_actor:
+                pass
+        else:
+            hf_io.load_hf_weights(self.model, cfg.path, strict=not (self.is_critic and cfg.init_critic_from_actor))
+        if self.optimizer_config is not None and self.optimizer_config.type != "empty":
+            flat.alloc_main_grad()
+            mp_groups = tuple(x for x in (g.group("tp"), g.group("pp")) if x is not None)
+            self.optimizer = ShardedAdamW(flat, self.optimizer_config, dp_group=g.group("dp_cp"), mp_groups=mp_groups,
+                                          replicated_ranges=self._tp_replicated_ranges() if g.tp > 1 else None)
+            self._total_steps = max(1, ft_spec.total_train_steps if ft_spec is not None else 1)
+        self.initialized = True
+        logger.info(f"model {mc.family} ({flat.numel / 1e6:.1f}M params on this rank) ready in "
+                    f"{time.perf_counter() - tik:.2f}s")
+
+    def _tp_replicated_ranges(self) -> List[Tuple[int, int]]:
+        rep = []
+        for n, (o, numel) in self.model.flat.offsets.items():
+            leaf = n.split(".")[-1]
+            if leaf in ("ln1", "ln2", "norm", "q_norm", "k_norm", "embed", "head", "router"):
+                rep.append((o, o + numel))
+        rep.sort()
+        merged: List[List[int]] = []
+        for a, b in rep:
+            if merged and a <= merged[-1][1] + ALIGN:
+                merged[-1][1] = max(merged[-1][1], b)
+            else:
+                merged.append([a, b])
+        return [(a, b) for a, b in merged]
+
+    def destroy(self):
+        self.model = None
+        self.optimizer = None
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        if self.own_global_group and dist.is_initialized():
+            dist.destroy_process_group()
+        self.initialized = False
+
+    def train(self, mode: bool = True):
+        self._training = mode
+        if self.model is not None:
+            self.model.train(mode)
+        return self
+
+    def set_version(self, version: int):
+        self._version = version
+
+    def get_version(self) -> int:
+        return self._version
+
+    # ------------------------------------------------------------------------ LR schedule
+    def current_lr(self) -> float:
+        oc = self.optimizer_config
+        return oc.lr * lr_lambda(self._lr_step, self._total_steps, oc)
+
+    def step_lr_scheduler(self):
+        self._lr_step += 1
+
+    # ------------------------------------------------------------------- micro-batching
+    def prepare_mb_list(self, input_: Dict[str, Any]) -> MicroBatchList:
+        assert "attention_mask" in input_ and "input_ids" in input_
+        input_ = amend_position_ids(dict(input_))
+        mb_list = split_padded_tensor_dict_into_mb_list(input_, self.config.mb_spec, group=self.grid.group("dp"))
+        align = 1
+        if self.grid.cp > 1:
+            align = self.grid.cp
+        if self.grid.tp > 1 and self.config.native.sequence_parallel:
+            align = math.lcm(align, self.grid.tp)
+        mb_list = pad_mb_list(mb_list, pad_value=0.0, pad_to_maximum=self.config.pad_to_maximum, align_to=align)
+        return mb_list.to(self.device)
+
+    def _run_model(self, mb: Dict[str, Any]) -> torch.Tensor:
+        """Packed (padded-to-page) micro-batch -> final hidden states [T_padded, H]."""
+        ids = mb["input_ids"]
+        pos = mb["position_ids"].to(torch.int32)
+        cu = mb["cu_seqlens"].to(torch.int32)
+        if self.grid.pp > 1:
+            raise RuntimeError("pipeline stages are driven by parallel.pipeline.PipelineRunner")
+        return self.model(ids, pos, cu, int(mb["max_seqlen"]))
+
+    def _proxy(self, hidden: torch.Tensor, pad_len: int) -> LogitsProxy:
+        if pad_len > 0:
+            hidden = hidden[: hidden.shape[0] - pad_len]
+        nc = self.config.native
+        return LogitsProxy(self.model, hidden, nc.logprob_chunk, nc.keep_logits, self.grid.group("tp"))
+
+    @staticmethod
+    def _unpadded(mb_padded: Dict[str, Any], pad_len: int, old_cu: torch.Tensor) -> Dict[str, Any]:
+        if pad_len == 0:
+            return mb_padded
+        total = int(old_cu[-1])
+        out = {}
+        for k, v in mb_padded.items():
+            if k == "cu_seqlens":
+                out[k] = old_cu
+            elif k == "max_seqlen":
+                lens = old_cu[1:] - old_cu[:-1]
+                out[k] = int(lens.max()) if lens.numel() else 0
+            elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == total + pad_len:
+                out[k] = v[:total]
+            else:
+                out[k] = v
+        return out
+
+    # ------------------------------------------------------------------------ train_batch
+    def train_batch(self, input_: Dict[str, Any], loss_fn: Callable, loss_weight_fn: Callable) -> Dict[str, float]:
+        assert self.optimizer is not None, "engine was initialised without an optimizer"
+        self.train(True)
+        if self.grid.pp > 1:
+            from ..parallel.pipeline import pipeline_train_batch
+
+            return pipeline_train_batch(self, input_, loss_fn, loss_weight_fn)
+        self.model.flat.main_grad.zero_()
+        mb_list = self.prepare_mb_list(input_)
+        weights = [loss_weight_fn(mb) for mb in mb_list.mbs]
+        total_w = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=self.device) for w in weights]).sum()
+        comm.all_reduce_sum(total_w, self.grid.group("dp"))
+        assert float(total_w) > 0, "total loss weight must be positive"
+        for i, (pmb, pad_len, old_cu) in enumerate(zip(mb_list.padded_mbs, mb_list.padding_lengths,
+                                                       mb_list.old_cu_seqlens_list)):
+            hidden = self._run_model(pmb)
+            proxy = self._proxy(hidden, pad_len)
+            mb = self._unpadded(pmb, pad_len, old_cu)
+            loss = loss_fn(proxy, mb)
+            scale = torch.as_tensor(weights[i], dtype=torch.float32, device=self.device) / total_w
+            aux = self.model.moe_aux_loss()
+            if aux is not None:
+                loss = loss + aux
+            (loss * scale).backward()
+        lr = self.current_lr()
+        self.optimizer.step(lr=lr)
+        return dict(update_successful=float(self.optimizer.update_successful()), grad_norm=self.optimizer.grad_norm(),
+                    lr=lr)
+
+    @torch.no_grad()
+    def eval_batch(self, input_: Dict[str, Any], loss_fn: Callable, loss_weight_fn: Callable) -> Optional[torch.Tensor]:
+        self.train(False)
+        mb_list = self.prepare_mb_list(input_)
+        weights = [loss_weight_fn(mb) for mb in mb_list.mbs]
+        total_w = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=self.device) for w in weights]).sum()
+        comm.all_reduce_sum(total_w, self.grid.group("dp"))
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        for i, (pmb, pad_len, old_cu) in enumerate(zip(mb_list.padded_mbs, mb_list.padding_lengths,
+                                                       mb_list.old_cu_seqlens_list)):
+            proxy = self._proxy(self._run_model(pmb), pad_len)
+            loss = loss_fn(proxy, self._unpadded(pmb, pad_len, old_cu))
+            total += loss.float() * torch.as_tensor(weights[i], dtype=torch.float32, device=self.device) / total_w
+        comm.all_reduce_sum(total, self.grid.group("dp"))
+        return total
+
+    @torch.no_grad()
+    def forward(self, input_: Dict[str, Any], output_seqlens: Optional[List[int]] = None,
+                post_hook: Optional[Callable] = None, aggregate_fn: Callable = torch.cat) -> Any:
+        """No-grad forward over micro-batches. `post_hook(proxy, mb)` maps the LM-head proxy to a per-token
+        tensor; results are re-ordered to the input order and re-padded to [B, S]."""
+        self.train(False)
+        if self.grid.pp > 1:
+            from ..parallel.pipeline import pipeline_forward
+
+            return pipeline_forward(self, input_, output_seqlens, post_hook, aggregate_fn)
+        B, S = input_["attention_mask"].shape
+        mb_list = self.prepare_mb_list(input_)
+        if output_seqlens is None:
+            output_seqlens = input_["attention_mask"].sum(-1).long().tolist()
+        results = []
+        for pmb, pad_len, old_cu in zip(mb_list.padded_mbs, mb_list.padding_lengths, mb_list.old_cu_seqlens_list):
+            proxy = self._proxy(self._run_model(pmb), pad_len)
+            mb = self._unpadded(pmb, pad_len, old_cu)
+            out = post_hook(proxy, mb) if post_hook is not None else proxy.materialize()
+            results.append(out)
+        res = aggregate_fn(results)
+        lens_fwd = [output_seqlens[i] for i in mb_list.forward_indices]
+        seqs = unpack_sequence(res, lens=lens_fwd)
+        ordered = [seqs[i] for i in mb_list.backward_indices]
+        out = res.new_zeros(B, S, *res.shape[1:])
+        for b, s in enumerate(ordered):
+            out[b, : s.shape[0]] = s
+        return out
+
+    # ----------------------------------------------------------------------- save / load
+    def save(self, meta: SaveLoadMeta):
+        if meta.weight_format != "hf":
+            raise NotImplementedError(f"weight format {meta.weight_format} (use 'hf')")
+        g = self.grid
+        # one writer per pipeline stage: dp rank 0, cp rank 0, tp rank 0 (tp shards are gathered)
+        writer = g.coord.dp == 0 and g.coord.cp == 0 and g.coord.tp == 0
+        tag = f"-stage{g.coord.pp}" if g.pp > 1 else ""
+        participate = g.coord.dp == 0 and g.coord.cp == 0
+        wm = {}
+        if participate:
+            wm = hf_io.save_hf_checkpoint(self.model, meta.path, stage_tag=tag, write=writer)
+        if dist.is_initialized() and g.pp > 1:
+            maps = [None] * dist.get_world_size()
+            dist.all_gather_object(maps, wm if writer else {})
+        else:
+            maps = [wm]
+        if self.rank == g.ranks[g.index_of(g.pp - 1, 0, 0, 0)] or (g.pp == 1 and writer):
+            hf_io.finalize_hf_checkpoint(meta.path, self.model_config, maps, meta.tokenizer)
+            if meta.processor is not None:
+                meta.processor.save_pretrained(meta.path)
+        if meta.with_optim and self.optimizer is not None:
+            os.makedirs(meta.path, exist_ok=True)
+            torch.save(dict(optim=self.optimizer.state_dict(), lr_step=self._lr_step),
+                       os.path.join(meta.path, f"optim_world_size_{self.world_size}_rank_{self.rank}.pt"))
+        if dist.is_initialized():
+            dist.barrier()
+
+    def load(self, meta: SaveLoadMeta):
+        if meta.weight_format != "hf":
+            raise NotImplementedError(f"weight format {meta.weight_format} (use 'hf')")
+        hf_io.load_hf_weights(self.model, meta.path)
+        if self.optimizer is not None:
+            self.optimizer.resync_master_from_params()
+            if meta.with_optim:
+                p = os.path.join(meta.path, f"optim_world_size_{self.world_size}_rank_{self.rank}.pt")
+                sd = torch.load(p, map_location="cpu", weights_only=True)
+                self.optimizer.load_state_dict(sd["optim"])
+                self._lr_step = int(sd["lr_step"])
+        if dist.is_initialized():
+            dist.barrier()
+
+    # ---------------------------------------------------------------------- weight upload
+    def get_param_specs(self, weight_chunked_mem_mb: int = 1024) -> List[List[ParamSpec]]:
+        """HF-named parameter specs grouped (FFD) into chunks of about `weight_chunked_mem_mb`."""
+        specs = [ParamSpec(name=n, shape=tuple(t.shape), dtype=str(t.dtype).replace("torch.", ""))
+                 for n, t in self._iter_full_hf_params(meta_only=True)]
+        sizes = [s.size for s in specs]
+        cap = max(max(sizes), weight_chunked_mem_mb * 1024 * 1024)
+        groups = datapack.ffd_allocate(sizes, cap, 1)
+        return [[specs[i] for i in sorted(g)] for g in sorted(groups, key=lambda g: min(g))]
+
+    def _iter_full_hf_params(self, meta_only: bool = False):
+        if meta_only and self.grid.tp == 1:
+            yield from hf_io.native_to_hf_state(self.model, gather=False)
+        else:
+            yield from hf_io.native_to_hf_state(self.model, gather=True)
+
+    def connect_local_engine(self, engine):
+        """Register a rollout engine living in this process (colocated mode)."""
+        self._local_rollout_engine = engine
+
+    def upload_weights(self, meta: WeightUpdateMeta):
+        if meta.type == "inproc":
+            assert self._local_rollout_engine is not None, "no in-process rollout engine connected"
+            self._local_rollout_engine.load_weights_from_trainer(self.model, version=self._version + 1)
+        elif meta.type == "disk":
+            self._upload_disk(meta)
+        elif meta.type in ("nccl", "xgmi"):
+            self._upload_collective(meta)
+        else:
+            raise NotImplementedError(f"Unknown weight update type {meta.type}")
+
+    def _upload_disk(self, meta: WeightUpdateMeta):
+        self.save(SaveLoadMeta(path=meta.path, weight_format="hf", with_optim=False))
+        if self.rank == 0:
+            key = names.update_weights_from_disk(self.config.experiment_name, self.config.trial_name, self._version)
+            name_resolve.add(key, str(time.time_ns()), keepalive_ttl=120, replace=True)
+        if dist.is_initialized():
+            dist.barrier()
+
+    def _init_weight_update_group(self, meta: WeightUpdateMeta):
+        from ..utils.distributed import init_custom_process_group
+
+        if self.rank == 0 and self._weight_update_group is None:
+            ws = meta.alloc_mode.gen.world_size + 1
+            self._weight_update_group = init_custom_process_group(
+                backend="nccl" if self.device.type == "cuda" else "gloo",
+                init_method=f"tcp://{meta.nccl_master_address}:{meta.nccl_master_port}", world_size=ws, rank=0,
+                group_name=meta.nccl_group_name)
+
+    def _upload_collective(self, meta: WeightUpdateMeta):
+        """Rank 0 of the trainer broadcasts every (HF-named, full) parameter into the rollout group, chunk
+        by chunk in the order of `meta.nccl_param_specs` (protocol of ``fsdp_engine.py:399-433``)."""
+        self._init_weight_update_group(meta)
+        full = dict(self._iter_full_hf_params())
+        for chunk in meta.nccl_param_specs:
+            if self.rank == 0:
+                for spec in chunk:
+                    t = full[spec.name].contiguous()
+                    dist.broadcast(t, src=0, group=self._weight_update_group)
+            if dist.is_initialized():
+                dist.barrier()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+
+
+# Names used by scripts written against the reference API.
+FSDPEngine = NativeTrainEngine
+MegatronEngine = NativeTrainEngine

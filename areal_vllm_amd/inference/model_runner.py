@@ -1,0 +1,282 @@
+"""GPU execution of scheduler plans for the native rollout engine.
+
+* prefill: packed varlen forward (flash kernel) with fused RoPE + paged-cache write, then sampling of
+  the first token of every request;
+* decode: `n_steps` tokens per plan; one step = embedding -> L x (RMSNorm, fused qkv GEMM, fused
+  RoPE + cache write, paged-KV MFMA attention, o GEMM, RMSNorm, gate|up GEMM, SwiGLU, down GEMM) ->
+  final norm -> LM head -> fused sampler -> device-side `advance_step`. The whole multi-step body is
+  captured once per batch-size bucket into a hipGraph (``torch.cuda.CUDAGraph``) and replayed, so a
+  decode plan costs one host launch (the reference relies on SGLang's CUDA-graph decode and on
+  ``realhf/impl/model/utils/cuda_graph.py:69-220`` for its own generator).
+
+All block tables have the engine-wide maximum width, so graphs only depend on the batch bucket.
+"""
+import math
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+from ..models.config import ModelConfig
+from ..models.transformer import Transformer
+from ..ops.attention import PAGE_SIZE
+from ..utils import logging
+
+logger = logging.getLogger("model-runner")
+
+DEFAULT_BUCKETS = [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 320, 384, 512, 768, 1024]
+
+
+class ModelRunner:
+    def __init__(self, model: Transformer, num_pages: int, max_context: int, max_batch: int, decode_steps: int = 1,
+                 use_graph: bool = True, seed: int = 1, buckets: Optional[List[int]] = None):
+        self.model = model
+        self.cfg: ModelConfig = model.cfg
+        self.device = next(model.parameters()).device
+        self.dtype = model.dtype
+        self.num_pages = num_pages
+        self.max_context = max_context
+        self.max_pages = (max_context + PAGE_SIZE - 1) // PAGE_SIZE
+        self.max_batch = max_batch
+        self.decode_steps = decode_steps
+        self.use_graph = use_graph and self.device.type == "cuda"
+        self.seed = seed
+        self.buckets = sorted(b for b in (buckets or DEFAULT_BUCKETS) if b <= max_batch)
+        if not self.buckets or self.buckets[-1] < max_batch:
+            self.buckets.append(max_batch)
+        cfg = self.cfg
+        self.hq = model.layers[0].attn.hq
+        self.hkv = model.layers[0].attn.hkv
+        self.kv = [ops.alloc_kv_cache(num_pages, self.hkv, cfg.head_dim, self.dtype, self.device)
+                   for _ in model.layers]
+        self.rope = model.rope(self.device)
+        self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.graphs: Dict[int, Any] = {}
+        self.static: Dict[int, Dict[str, torch.Tensor]] = {}
+        self._graph_pool = None
+        self.V = cfg.vocab_size
+        self.n_prefill_tokens = 0
+        self.n_decode_tokens = 0
+
+    # ------------------------------------------------------------------------ model pieces
+    def _layer(self, blk, h, residual, positions, slots, attn_fn):
+        cfg = self.cfg
+        x, residual = ops.rmsnorm(h, blk.ln1, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+        qkv = blk.attn.project_qkv(x)
+        attn = attn_fn(blk, qkv)
+        h = F.linear(attn.reshape(attn.shape[0], -1), blk.attn.o)
+        if self.model.tp_size > 1:
+            torch.distributed.all_reduce(h, group=self.model.tp_group)
+        x, residual = ops.rmsnorm(h, blk.ln2, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+        if cfg.n_experts > 0:
+            h = blk.mlp(x, None, self.model.ep_group)
+        else:
+            h = F.linear(ops.swiglu(F.linear(x, blk.mlp.gate_up)), blk.mlp.down)
+        if self.model.tp_size > 1:
+            torch.distributed.all_reduce(h, group=self.model.tp_group)
+        return h, residual
+
+    def _final_logits(self, h, residual) -> torch.Tensor:
+        cfg = self.cfg
+        x, _ = ops.rmsnorm(h, self.model.norm, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+        return F.linear(x, self.model.head_weight)
+
+    # ----------------------------------------------------------------------------- prefill
+    @torch.no_grad()
+    def prefill(self, plan: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray]:
+        dev = self.device
+        ids = torch.from_numpy(plan["input_ids"]).to(dev, non_blocking=True).long()
+        pos = torch.from_numpy(plan["positions"]).to(dev, non_blocking=True)
+        slots = torch.from_numpy(plan["slot_mapping"]).to(dev, non_blocking=True)
+        cu_q = torch.from_numpy(plan["cu_q"]).to(dev, non_blocking=True)
+        cu_k = torch.from_numpy(plan["cu_k"]).to(dev, non_blocking=True)
+        has_prefix = bool(plan["has_prefix"])
+        ctx_slots = torch.from_numpy(plan["ctx_slots"]).to(dev, non_blocking=True) if has_prefix else None
+        max_q = int(plan["max_q"])
+        B = len(plan["req_ids"])
+        T = ids.numel()
+        hq, hkv, D = self.hq, self.hkv, self.cfg.head_dim
+        self.n_prefill_tokens += T
+
+        h = self.model.embed_tokens(ids)
+        residual = None
+        for li, blk in enumerate(self.model.layers):
+            kc, vc = self.kv[li]
+
+            def attn_fn(blk_, qkv2d, kc=kc, vc=vc):
+                qkv = qkv2d.view(T, hq + 2 * hkv, D)
+                ops.rope_and_cache_write_(qkv, pos, slots, self.rope, kc, vc, hq, hkv)
+                q = qkv[:, :hq]
+                if has_prefix:
+                    k, v = ops.cache_gather(kc, vc, ctx_slots)
+                    out, _ = ops.flash_attn_varlen(q, k, v, cu_q, cu_k, max_q)
+                else:
+                    out, _ = ops.flash_attn_varlen(q, qkv[:, hq:hq + hkv], qkv[:, hq + hkv:], cu_q, cu_q, max_q)
+                return out
+
+            h, residual = self._layer(blk, h, residual, pos, slots, attn_fn)
+        last = (cu_q[1:] - 1).long()
+        logits = self._final_logits(h[last], residual[last])
+        temp = torch.from_numpy(plan["temperature"]).to(dev)
+        top_p = torch.from_numpy(plan["top_p"]).to(dev)
+        top_k = torch.from_numpy(np.minimum(plan["top_k"], self.V).astype(np.int32)).to(dev)
+        filt = bool((plan["top_k"] < self.V).any() or (plan["top_p"] < 1.0).any())
+        tok, lp = ops.sample(logits, temp, top_k if filt else None, top_p if filt else None, self.seed,
+                             self.step_counter)
+        return tok.cpu().numpy(), lp.cpu().numpy()
+
+    # ------------------------------------------------------------------------------ decode
+    def _bucket(self, b: int) -> int:
+        for x in self.buckets:
+            if x >= b:
+                return x
+        raise RuntimeError(f"decode batch {b} exceeds the largest bucket {self.buckets[-1]}")
+
+    def _alloc_static(self, Bp: int) -> Dict[str, torch.Tensor]:
+        dev = self.device
+        k = self.decode_steps
+        nsplit = ops.decode_num_splits(Bp, self.hkv, 4096)
+        st = dict(
+            input_ids=torch.zeros(Bp, dtype=torch.int64, device=dev),
+            positions=torch.zeros(Bp, dtype=torch.int32, device=dev),
+            context_lens=torch.ones(Bp, dtype=torch.int32, device=dev),
+            slots=torch.zeros(Bp, dtype=torch.int64, device=dev),
+            block_tables=torch.zeros(Bp, self.max_pages, dtype=torch.int32, device=dev),
+            temperature=torch.ones(Bp, dtype=torch.float32, device=dev),
+            top_p=torch.ones(Bp, dtype=torch.float32, device=dev),
+            top_k=torch.full((Bp,), self.V, dtype=torch.int32, device=dev),
+            out_tokens=torch.zeros(k, Bp, dtype=torch.int64, device=dev),
+            out_logprobs=torch.zeros(k, Bp, dtype=torch.float32, device=dev),
+        )
+        st["nsplit"] = nsplit
+        st["ws"] = ops.DecodeWorkspace(Bp, self.hq, self.cfg.head_dim, nsplit, dev) if nsplit > 1 else None
+        # pinned host mirrors for one-shot uploads
+        if dev.type == "cuda":
+            st["h_i64"] = torch.zeros(2, Bp, dtype=torch.int64).pin_memory()
+            st["h_i32"] = torch.zeros(3, Bp, dtype=torch.int32).pin_memory()
+            st["h_f32"] = torch.zeros(2, Bp, dtype=torch.float32).pin_memory()
+            st["h_bt"] = torch.zeros(Bp, self.max_pages, dtype=torch.int32).pin_memory()
+        return st
+
+    def _decode_body(self, st: Dict[str, torch.Tensor], filtered: bool):
+        """`decode_steps` decode iterations on the static buffers (captured into a graph)."""
+        hq, hkv, D = self.hq, self.hkv, self.cfg.head_dim
+        Bp = st["input_ids"].numel()
+        qkv_stride = (hq + 2 * hkv) * D
+        for s in range(self.decode_steps):
+            h = self.model.embed_tokens(st["input_ids"])
+            residual = None
+            for li, blk in enumerate(self.model.layers):
+                kc, vc = self.kv[li]
+
+                def attn_fn(blk_, qkv2d, kc=kc, vc=vc):
+                    qkv = qkv2d.view(Bp, hq + 2 * hkv, D)
+                    ops.rope_and_cache_write_(qkv, st["positions"], st["slots"], self.rope, kc, vc, hq, hkv)
+                    return ops.paged_attention_decode(qkv[:, :hq], kc, vc, st["block_tables"], st["context_lens"],
+                                                      nsplit=st["nsplit"], workspace=st["ws"],
+                                                      q_row_stride=qkv_stride)
+
+                h, residual = self._layer(blk, h, residual, st["positions"], st["slots"], attn_fn)
+            logits = self._final_logits(h, residual)
+            ops.sample(logits, st["temperature"], st["top_k"] if filtered else None, st["top_p"] if filtered else None,
+                       self.seed, self.step_counter, bump_step=True, out_tokens=st["out_tokens"][s],
+                       out_logprobs=st["out_logprobs"][s])
+            ops.advance_step_(st["out_tokens"][s], st["input_ids"], st["positions"], st["context_lens"], st["slots"],
+                              st["block_tables"])
+
+    def _get_graph(self, Bp: int, filtered: bool):
+        key = (Bp, filtered)
+        if key in self.graphs:
+            return self.graphs[key], self.static[Bp]
+        if Bp not in self.static:
+            self.static[Bp] = self._alloc_static(Bp)
+        st = self.static[Bp]
+        if not self.use_graph:
+            self.graphs[key] = None
+            return None, st
+        # warm up eagerly on a side stream (allocator + hipBLASLt workspaces), then capture
+        saved = {k: st[k].clone() for k in ("input_ids", "positions", "context_lens", "slots")}
+        step_saved = self.step_counter.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._decode_body(st, filtered)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for k, v in saved.items():
+            st[k].copy_(v)
+        g = torch.cuda.CUDAGraph()
+        if self._graph_pool is None:
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=self._graph_pool):
+            self._decode_body(st, filtered)
+        for k, v in saved.items():
+            st[k].copy_(v)
+        self.step_counter.copy_(step_saved)
+        self.graphs[key] = g
+        logger.info(f"captured decode graph: batch bucket {Bp}, {self.decode_steps} step(s), "
+                    f"kv splits {st['nsplit']}, filtered={filtered}")
+        return g, st
+
+    @torch.no_grad()
+    def decode(self, plan: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray]:
+        B = len(plan["req_ids"])
+        assert int(plan["n_steps"]) == self.decode_steps
+        Bp = self._bucket(B)
+        filtered = bool((plan["top_k"] < self.V).any() or (plan["top_p"] < 1.0).any())
+        g, st = self._get_graph(Bp, filtered)
+        mp = int(plan["max_pages"])
+        assert mp <= self.max_pages, "request context exceeds the engine's context length"
+        if self.device.type == "cuda":
+            hi64, hi32, hf32, hbt = st["h_i64"], st["h_i32"], st["h_f32"], st["h_bt"]
+            hi64.zero_(); hi32.zero_(); hbt.zero_()
+            hi32[1].fill_(1)
+            hf32[0].fill_(1.0); hf32[1].fill_(1.0)
+            hi32[2].fill_(self.V)
+            hi64[0, :B] = torch.from_numpy(plan["input_ids"].astype(np.int64))
+            hi64[1, :B] = torch.from_numpy(plan["slot_mapping"])
+            hi32[0, :B] = torch.from_numpy(plan["positions"])
+            hi32[1, :B] = torch.from_numpy(plan["context_lens"])
+            hi32[2, :B] = torch.from_numpy(np.minimum(plan["top_k"], self.V).astype(np.int32))
+            hf32[0, :B] = torch.from_numpy(plan["temperature"])
+            hf32[1, :B] = torch.from_numpy(plan["top_p"])
+            hbt[:B, :mp] = torch.from_numpy(plan["block_tables"])
+            st["input_ids"].copy_(hi64[0], non_blocking=True)
+            st["slots"].copy_(hi64[1], non_blocking=True)
+            st["positions"].copy_(hi32[0], non_blocking=True)
+            st["context_lens"].copy_(hi32[1], non_blocking=True)
+            st["top_k"].copy_(hi32[2], non_blocking=True)
+            st["temperature"].copy_(hf32[0], non_blocking=True)
+            st["top_p"].copy_(hf32[1], non_blocking=True)
+            st["block_tables"].copy_(hbt, non_blocking=True)
+        else:
+            for name, src, fill in (("input_ids", plan["input_ids"].astype(np.int64), 0),
+                                    ("slots", plan["slot_mapping"], 0), ("positions", plan["positions"], 0),
+                                    ("context_lens", plan["context_lens"], 1),
+                                    ("top_k", np.minimum(plan["top_k"], self.V).astype(np.int32), self.V),
+                                    ("temperature", plan["temperature"], 1.0), ("top_p", plan["top_p"], 1.0)):
+                st[name].fill_(fill)
+                st[name][:B] = torch.from_numpy(src)
+            st["block_tables"].zero_()
+            st["block_tables"][:B, :mp] = torch.from_numpy(plan["block_tables"])
+        if g is not None:
+            g.replay()
+        else:
+            self._decode_body(st, filtered)
+        self.n_decode_tokens += B * self.decode_steps
+        toks = st["out_tokens"].cpu().numpy()
+        lps = st["out_logprobs"].cpu().numpy()
+        return toks, lps
+
+    def warmup(self, batch_sizes: Optional[List[int]] = None):
+        """Capture decode graphs ahead of time for the given batch sizes."""
+        for b in batch_sizes or []:
+            self._get_graph(self._bucket(b), False)
+
+    def reset_graphs(self):
+        self.graphs.clear()
+
+    def kv_cache_bytes(self) -> int:
+        return sum(k.numel() * k.element_size() + v.numel() * v.element_size() for k, v in self.kv)

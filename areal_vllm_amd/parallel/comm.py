@@ -1,0 +1,69 @@
+"""Collective helpers that work on both RCCL (GPU) and gloo (CPU tests).
+
+gloo lacks reduce_scatter_tensor, so the CPU path emulates it with an all-reduce and a slice; the
+numerical result is the same, which is what the gloo fake-cluster tests rely on.
+"""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def group_size(group) -> int:
+    if not dist.is_initialized():
+        return 1
+    return dist.get_world_size(group)
+
+
+def group_rank(group) -> int:
+    if not dist.is_initialized():
+        return 0
+    return dist.get_rank(group)
+
+
+def _is_nccl(t: torch.Tensor) -> bool:
+    return t.is_cuda
+
+
+def reduce_scatter_sum(out_shard: torch.Tensor, full: torch.Tensor, group) -> None:
+    """out_shard = sum over ranks of full[rank_slice]."""
+    n = group_size(group)
+    if n == 1:
+        if out_shard.data_ptr() != full.data_ptr():
+            out_shard.copy_(full[: out_shard.numel()])
+        return
+    if _is_nccl(full):
+        dist.reduce_scatter_tensor(out_shard, full, op=dist.ReduceOp.SUM, group=group)
+    else:
+        tmp = full.clone()
+        dist.all_reduce(tmp, group=group)
+        r = group_rank(group)
+        out_shard.copy_(tmp[r * out_shard.numel():(r + 1) * out_shard.numel()])
+
+
+def all_gather_flat(full: torch.Tensor, shard: torch.Tensor, group) -> None:
+    """full = concat over ranks of shard (shard may alias full's own slice)."""
+    n = group_size(group)
+    if n == 1:
+        if shard.data_ptr() != full.data_ptr():
+            full[: shard.numel()].copy_(shard)
+        return
+    if _is_nccl(full):
+        dist.all_gather_into_tensor(full, shard, group=group)
+    else:
+        parts = [torch.empty_like(shard) for _ in range(n)]
+        dist.all_gather(parts, shard.clone(), group=group)
+        for i, p in enumerate(parts):
+            full[i * shard.numel():(i + 1) * shard.numel()].copy_(p)
+
+
+def all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
+    if group_size(group) > 1:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def all_reduce_max(t: torch.Tensor, group) -> torch.Tensor:
+    if group_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
