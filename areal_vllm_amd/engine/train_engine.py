@@ -433,7 +433,7 @@ class NativeTrainEngine(TrainEngine):
     def upload_weights(self, meta: WeightUpdateMeta):
         if meta.type == "inproc":
             assert self._local_rollout_engine is not None, "no in-process rollout engine connected"
-            self._local_rollout_engine.load_weights_from_trainer(self.model, version=self._version + 1)
+            self._local_rollout_engine.load_weights_from_trainer(self.model, version=None)
         elif meta.type == "disk":
             self._upload_disk(meta)
         elif meta.type in ("nccl", "xgmi"):

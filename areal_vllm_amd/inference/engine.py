@@ -1,0 +1,453 @@
+"""Native rollout engine: paged-KV continuous batching with interruptible generation.
+
+``NativeInferenceEngine`` owns the weights (its own copy of the flat parameter buffer), the paged KV
+cache, the C++ scheduler (``csrc/runtime/scheduler.hpp``) and a step loop thread. It replaces the
+SGLang / vLLM servers the reference launches (``areal/launcher/sglang_server.py``,
+``realhf/impl/model/backend/{sglang,vllm}.py``) and offers two front ends:
+
+* in-process (``LocalInferenceEngine`` in ``engine/local_engine.py``; the reference's experimental
+  ``areal/experimental/sglang_engine.py``), used when rollout and training share a GPU;
+* HTTP (``inference/server.py``) with the REST verbs the reference's client speaks.
+
+Control verbs: ``pause`` / ``resume`` (stop scheduling between steps), ``abort_all`` (finish everything
+in flight with reason "abort", release pages, flush the prefix cache), weight loading from the trainer's
+flat buffer (device copy on a side stream), from an HF checkpoint directory, or from named tensors.
+Each generated token carries the weight version that sampled it.
+"""
+import asyncio
+import dataclasses
+import queue
+import threading
+import time
+import traceback
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from ..api.cli_args import InferenceServerConfig
+from ..models import hf_io
+from ..models.config import ModelConfig
+from ..models.transformer import Transformer
+from ..ops.attention import PAGE_SIZE
+from ..utils import logging
+from .model_runner import ModelRunner
+
+logger = logging.getLogger("inference-engine")
+
+try:
+    from areal_vllm_amd._C import _runtime
+except ImportError as e:  # pragma: no cover
+    _runtime = None
+    _runtime_err = e
+
+
+@dataclasses.dataclass
+class GenerationResult:
+    rid: str
+    output_tokens: List[int]
+    output_logprobs: List[float]
+    output_versions: List[int]
+    finish_reason: str  # stop | length | abort
+    prompt_len: int = 0
+    latency: float = 0.0
+    ttft: float = 0.0
+    itl: List[float] = dataclasses.field(default_factory=list)
+
+
+def _kv_bytes_per_page(cfg: ModelConfig, n_layers: int, hkv: int, elt: int = 2) -> int:
+    return n_layers * 2 * hkv * PAGE_SIZE * cfg.head_dim * elt
+
+
+class NativeInferenceEngine:
+    def __init__(self, config: InferenceServerConfig, model_config: Optional[ModelConfig] = None,
+                 device: Optional[torch.device] = None, tp_size: int = 1, tp_rank: int = 0, tp_group=None,
+                 num_pages: Optional[int] = None, kv_cache_gb: Optional[float] = None):
+        if _runtime is None:
+            raise RuntimeError(f"C++ runtime extension missing ({_runtime_err}); run `python build_ext.py`")
+        self.config = config
+        self.device = device or (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available()
+                                 else torch.device("cpu"))
+        self.dtype = getattr(torch, config.dtype)
+        from ..engine.train_engine import _resolve_model_config
+
+        self.model_config = model_config or _resolve_model_config(config.model_path, False)
+        self.tp_size, self.tp_rank, self.tp_group = tp_size, tp_rank, tp_group
+        self._num_pages_arg = num_pages
+        self._kv_cache_gb = kv_cache_gb
+        self.model: Optional[Transformer] = None
+        self.runner: Optional[ModelRunner] = None
+        self.sched = None
+        self._req_q: "queue.Queue" = queue.Queue()
+        self._ctrl_q: "queue.Queue" = queue.Queue()
+        self._waiters: Dict[str, Any] = {}
+        self._lock = threading.Lock()
+        self._wake = threading.Event()
+        self._stop = threading.Event()
+        self._thread: Optional[threading.Thread] = None
+        self._version = 0
+        self._paused = False
+        self.stats = dict(prefill_steps=0, decode_steps=0, prefill_time=0.0, decode_time=0.0, gen_tokens=0,
+                          prompt_tokens=0, aborted=0)
+        self._copy_stream = None
+
+    # ------------------------------------------------------------------------------ set-up
+    def initialize(self, load_weights: bool = True):
+        cfg, mc = self.config, self.model_config
+        self.model = Transformer(mc, dtype=self.dtype, device=self.device, tp_size=self.tp_size, tp_rank=self.tp_rank,
+                                 tp_group=self.tp_group)
+        self.model.requires_grad_(False)
+        self.model.eval()
+        self.model.flatten()
+        import os
+
+        if load_weights and cfg.model_path and os.path.isdir(cfg.model_path):
+            hf_io.load_hf_weights(self.model, cfg.model_path)
+        else:
+            self.model.init_weights(seed=1 + 1000 * self.tp_rank)
+        ctx = int(cfg.context_length or mc.max_position_embeddings)
+        hkv = self.model.layers[0].attn.hkv
+        per_page = _kv_bytes_per_page(mc, len(self.model.layers), hkv, 2)
+        if self._num_pages_arg is not None:
+            num_pages = int(self._num_pages_arg)
+        elif self._kv_cache_gb is not None:
+            num_pages = int(self._kv_cache_gb * 1024**3 // per_page)
+        elif self.device.type == "cuda":
+            free, total = torch.cuda.mem_get_info(self.device)
+            budget = max(0, free - (1.0 - float(cfg.mem_fraction_static or 0.9)) * total)
+            num_pages = int(budget // per_page)
+        else:
+            num_pages = 256
+        num_pages = max(8, num_pages)
+        max_running = int(cfg.max_running_requests or 256)
+        self.decode_steps = max(1, int(cfg.num_continuous_decode_steps))
+        self.runner = ModelRunner(self.model, num_pages, ctx, max_running, decode_steps=self.decode_steps,
+                                  use_graph=not cfg.disable_cuda_graph, seed=int(cfg.random_seed),
+                                  buckets=cfg.cuda_graph_bs)
+        sc = _runtime.SchedulerConfig()
+        sc.num_pages = num_pages
+        sc.max_running_requests = max_running
+        sc.max_prefill_tokens = int(cfg.max_prefill_tokens)
+        sc.context_length = ctx
+        sc.decode_steps = self.decode_steps
+        sc.enable_prefix_cache = not cfg.disable_radix_cache
+        sc.policy = cfg.schedule_policy if cfg.schedule_policy in ("fcfs", "lpm") else "fcfs"
+        sc.schedule_conservativeness = float(cfg.schedule_conservativeness)
+        self.sched = _runtime.Scheduler(sc)
+        self.num_pages = num_pages
+        logger.info(f"rollout engine ready: {num_pages} KV pages ({num_pages * per_page / 2**30:.1f} GiB), "
+                    f"context {ctx}, max running {max_running}, decode steps/plan {self.decode_steps}")
+        self._thread = threading.Thread(target=self._loop, daemon=True, name="rollout-engine-loop")
+        self._thread.start()
+        return self
+
+    def destroy(self):
+        self._stop.set()
+        self._wake.set()
+        if self._thread is not None:
+            self._thread.join(timeout=30)
+        self.runner = None
+        self.model = None
+
+    # -------------------------------------------------------------------------- step loop
+    def _loop(self):
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        try:
+            while not self._stop.is_set():
+                self._drain_control()
+                self._drain_requests()
+                if self._paused or not self.sched.has_work():
+                    self._deliver()
+                    self._wake.wait(timeout=0.01)
+                    self._wake.clear()
+                    continue
+                plan = self.sched.schedule()
+                kind = plan["kind"]
+                if kind == 0:
+                    self._deliver()
+                    self._wake.wait(timeout=0.002)
+                    self._wake.clear()
+                    continue
+                t0 = time.perf_counter()
+                if kind == 1:
+                    toks, lps = self.runner.prefill(plan)
+                    self.sched.process_prefill(toks, lps)
+                    self.stats["prefill_steps"] += 1
+                    self.stats["prefill_time"] += time.perf_counter() - t0
+                else:
+                    toks, lps = self.runner.decode(plan)
+                    self.sched.process_decode(toks, lps)
+                    self.stats["decode_steps"] += 1
+                    self.stats["decode_time"] += time.perf_counter() - t0
+                self._deliver()
+        except Exception:
+            traceback.print_exc()
+            self._fail_all("engine loop crashed")
+
+    def _drain_requests(self):
+        while True:
+            try:
+                rid, prompt, sp = self._req_q.get_nowait()
+            except queue.Empty:
+                return
+            self.sched.add_request(rid, prompt, sp["max_new_tokens"], sp["min_new_tokens"], sp["temperature"],
+                                   sp["top_p"], sp["top_k"], sp["stop_token_ids"])
+
+    def _drain_control(self):
+        while True:
+            try:
+                fn, done = self._ctrl_q.get_nowait()
+            except queue.Empty:
+                return
+            try:
+                res = fn()
+                done.put((True, res))
+            except Exception as e:  # surfaced to the caller
+                traceback.print_exc()
+                done.put((False, e))
+
+    def _deliver(self):
+        for f in self.sched.take_finished():
+            res = GenerationResult(rid=f["rid"], output_tokens=list(f["output_tokens"]),
+                                   output_logprobs=list(f["output_logprobs"]),
+                                   output_versions=list(f["output_versions"]), finish_reason=f["finish_reason"],
+                                   prompt_len=f["prompt_len"], latency=f["latency"], ttft=f["ttft"], itl=list(f["itl"]))
+            self.stats["gen_tokens"] += len(res.output_tokens)
+            if res.finish_reason == "abort":
+                self.stats["aborted"] += 1
+            with self._lock:
+                w = self._waiters.pop(res.rid, None)
+            if w is not None:
+                w(res)
+
+    def _fail_all(self, msg):
+        with self._lock:
+            ws = list(self._waiters.items())
+            self._waiters.clear()
+        for rid, w in ws:
+            w(GenerationResult(rid=rid, output_tokens=[], output_logprobs=[], output_versions=[],
+                               finish_reason="abort"))
+
+    def _control(self, fn: Callable, timeout: float = 600.0):
+        """Run `fn` on the loop thread between two steps and return its result."""
+        if self._thread is None or not self._thread.is_alive() or threading.current_thread() is self._thread:
+            return fn()
+        done: "queue.Queue" = queue.Queue()
+        self._ctrl_q.put((fn, done))
+        self._wake.set()
+        ok, res = done.get(timeout=timeout)
+        if not ok:
+            raise res
+        return res
+
+    # ------------------------------------------------------------------------ request API
+    def submit(self, rid: str, input_ids: List[int], *, max_new_tokens: int, min_new_tokens: int = 0,
+               temperature: float = 1.0, top_p: float = 1.0, top_k: int = 1 << 30,
+               stop_token_ids: Optional[List[int]] = None, greedy: bool = False,
+               callback: Optional[Callable[[GenerationResult], None]] = None):
+        sp = dict(max_new_tokens=int(max_new_tokens), min_new_tokens=int(min_new_tokens),
+                  temperature=0.0 if greedy else float(temperature), top_p=float(top_p),
+                  top_k=int(min(top_k, 1 << 30)), stop_token_ids=[int(x) for x in (stop_token_ids or [])])
+        with self._lock:
+            if rid in self._waiters:
+                raise ValueError(f"duplicate request id {rid}")
+            self._waiters[rid] = callback or (lambda r: None)
+        self._req_q.put((rid, [int(t) for t in input_ids], sp))
+        self._wake.set()
+
+    async def agenerate_once(self, rid: str, input_ids: List[int], **sampling) -> GenerationResult:
+        loop = asyncio.get_running_loop()
+        fut = loop.create_future()
+
+        def cb(res):
+            loop.call_soon_threadsafe(lambda: fut.done() or fut.set_result(res))
+
+        self.submit(rid, input_ids, callback=cb, **sampling)
+        return await fut
+
+    def generate_blocking(self, prompts: List[List[int]], **sampling) -> List[GenerationResult]:
+        """Synchronous helper: run all prompts to completion (no interruption handling)."""
+        out: List[Optional[GenerationResult]] = [None] * len(prompts)
+        ev = threading.Event()
+        remaining = [len(prompts)]
+        lock = threading.Lock()
+
+        def mk(i):
+            def cb(res):
+                out[i] = res
+                with lock:
+                    remaining[0] -= 1
+                    if remaining[0] == 0:
+                        ev.set()
+            return cb
+
+        base = f"blk-{time.monotonic_ns()}"
+        for i, p in enumerate(prompts):
+            self.submit(f"{base}-{i}", p, callback=mk(i), **sampling)
+        if prompts:
+            ev.wait()
+        return out  # type: ignore
+
+    # ------------------------------------------------------------------------ control API
+    def pause(self):
+        def f():
+            self._paused = True
+            self.sched.pause()
+        self._control(f)
+
+    def resume(self):
+        def f():
+            self._paused = False
+            self.sched.resume()
+        self._control(f)
+        self._wake.set()
+
+    def abort_all(self) -> int:
+        def f():
+            n = self.sched.abort_all()
+            self._deliver()
+            return n
+        return self._control(f)
+
+    def flush_cache(self):
+        self._control(lambda: self.sched.flush_cache())
+
+    def get_version(self) -> int:
+        return self._version
+
+    def set_version(self, v: int):
+        def f():
+            self._version = int(v)
+            self.sched.set_version(int(v))
+        self._control(f)
+
+    # ------------------------------------------------------------------------ weight loading
+    def _after_weight_change(self, version: Optional[int]):
+        self.sched.flush_cache()
+        if version is not None:
+            self._version = int(version)
+            self.sched.set_version(int(version))
+
+    def load_weights_from_trainer(self, trainer_model: Transformer, version: Optional[int] = None,
+                                  abort_running: bool = True):
+        """Colocated update: one device-to-device copy of the flat bf16 buffer on a side stream, applied
+        between two engine steps; running requests are aborted first (their KV is stale)."""
+        src = trainer_model.flat.flat
+
+        def f():
+            if abort_running:
+                self.sched.abort_all()
+                self._deliver()
+            dst = self.model.flat.flat
+            assert dst.numel() == src.numel(), "trainer and rollout parameter layouts differ"
+            if self.device.type == "cuda":
+                if self._copy_stream is None:
+                    self._copy_stream = torch.cuda.Stream(device=self.device)
+                self._copy_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._copy_stream):
+                    dst.copy_(src, non_blocking=True)
+                torch.cuda.current_stream().wait_stream(self._copy_stream)
+            else:
+                dst.copy_(src)
+            self._after_weight_change(version)
+        self._control(f)
+
+    def load_weights_from_disk(self, path: str, version: Optional[int] = None, abort_running: bool = True):
+        def f():
+            if abort_running:
+                self.sched.abort_all()
+                self._deliver()
+            hf_io.load_hf_weights(self.model, path)
+            self._after_weight_change(version)
+        self._control(f)
+
+    def load_named_tensors(self, tensors: Dict[str, torch.Tensor], version: Optional[int] = None,
+                           abort_running: bool = True, finalize: bool = True):
+        """Assign HF-named full tensors (weight updates received through a collective)."""
+        def f():
+            if abort_running:
+                self.sched.abort_all()
+                self._deliver()
+            assign_hf_named_tensors(self.model, tensors)
+            if finalize:
+                self._after_weight_change(version)
+        self._control(f)
+
+    # ----------------------------------------------------------------------------- metrics
+    def metrics(self) -> Dict[str, float]:
+        s = self.sched
+        total = max(1, s.num_total_pages())
+        return {
+            "num_running_reqs": s.num_running(), "num_queue_reqs": s.num_waiting(),
+            "token_usage": 1.0 - s.num_free_pages() / total, "num_used_pages": total - s.num_free_pages(),
+            "cached_pages": s.num_cached_pages(), "gen_tokens_total": s.total_generated(),
+            "prompt_tokens_total": s.total_prompt_tokens(), "cached_tokens_total": s.total_cached_tokens(),
+            "preemptions_total": s.num_preemptions(), "weight_version": self._version,
+            **{k: float(v) for k, v in self.stats.items()},
+        }
+
+
+def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]):
+    """Copy HF-named FULL tensors into the (possibly tensor-parallel) native parameters."""
+    cfg = model.cfg
+    D = cfg.head_dim
+    tp, tr = model.tp_size, model.tp_rank
+    params = dict(model.named_parameters())
+    lo_layer, _ = model.layer_range
+
+    def rows(t, lo, hi):
+        return t[lo:hi]
+
+    for li, blk in enumerate(model.layers):
+        i = lo_layer + li
+        names = hf_io.hf_names_for_layer(cfg, i)
+        pre = f"layers.{li}."
+        hq, hkv = blk.attn.hq, blk.attn.hkv
+        hq_lo = tr * hq
+        hkv_lo = (tr * hkv) if cfg.n_kv_heads >= tp else tr // (tp // cfg.n_kv_heads)
+        for key, hf_list in names.items():
+            p = params[pre + key]
+            if key == "attn.qkv" or key == "attn.qkv_bias":
+                offs = [0, hq * D, (hq + hkv) * D]
+                sizes = [hq * D, hkv * D, hkv * D]
+                los = [hq_lo * D, hkv_lo * D, hkv_lo * D]
+                for n, o, s, lo in zip(hf_list, offs, sizes, los):
+                    if n in tensors:
+                        p.data[o:o + s].copy_(tensors[n][lo:lo + s])
+            elif key == "attn.o":
+                if hf_list[0] in tensors:
+                    p.data.copy_(tensors[hf_list[0]][:, hq_lo * D:(hq_lo + hq) * D])
+            elif key == "mlp.gate_up":
+                f = p.shape[0] // 2
+                for j, n in enumerate(hf_list):
+                    if n in tensors:
+                        p.data[j * f:(j + 1) * f].copy_(tensors[n][tr * f:(tr + 1) * f])
+            elif key == "mlp.down":
+                if hf_list[0] in tensors:
+                    f = p.shape[1]
+                    p.data.copy_(tensors[hf_list[0]][:, tr * f:(tr + 1) * f])
+            else:
+                if hf_list[0] in tensors:
+                    p.data.copy_(tensors[hf_list[0]])
+        if cfg.n_experts > 0:
+            gu, dn = params[pre + "mlp.gate_up"], params[pre + "mlp.down"]
+            f = gu.shape[1] // 2
+            for le in range(gu.shape[0]):
+                e = blk.mlp.ep_rank * blk.mlp.n_local + le
+                gn, un, dnn = hf_io.hf_expert_names(cfg, i, e)
+                if gn in tensors:
+                    gu.data[le, :f].copy_(tensors[gn][tr * f:(tr + 1) * f])
+                if un in tensors:
+                    gu.data[le, f:].copy_(tensors[un][tr * f:(tr + 1) * f])
+                if dnn in tensors:
+                    dn.data[le].copy_(tensors[dnn][:, tr * f:(tr + 1) * f])
+    if model.has_embed and "model.embed_tokens.weight" in tensors:
+        params["embed"].data.copy_(tensors["model.embed_tokens.weight"])
+    if model.has_head:
+        if "model.norm.weight" in tensors:
+            params["norm"].data.copy_(tensors["model.norm.weight"])
+        if "head" in params:
+            for n in ("lm_head.weight", "score.weight"):
+                if n in tensors:
+                    params["head"].data.copy_(tensors[n])

@@ -210,7 +210,7 @@ class ModelRunner:
         g = torch.cuda.CUDAGraph()
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
-        with torch.cuda.graph(g, pool=self._graph_pool):
+        with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
             self._decode_body(st, filtered)
         for k, v in saved.items():
             st[k].copy_(v)

@@ -148,6 +148,9 @@ def init_distributed(backend: Optional[str] = None, timeout=DIST_TIMEOUT):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+        # single-node run: keep gloo off hostname resolution (container hostnames may not resolve)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if backend == "nccl":
