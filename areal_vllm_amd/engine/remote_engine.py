@@ -1,0 +1,238 @@
+"""HTTP rollout client: the ``InferenceEngine`` API against one or many native rollout servers.
+
+Behaviour of the reference's ``RemoteSGLangEngine`` (``areal/engine/sglang_remote.py:83-480``): server
+discovery through ``AREAL_LLM_SERVER_ADDRS`` or the name-resolve ``gen_servers`` subtree, round-robin
+scheduling with request-id affinity, interruptible ``agenerate`` (abort -> append partial output ->
+re-issue), and the pause -> update (disk or collective) -> continue weight-update protocol driven from
+trainer rank 0.
+"""
+import asyncio
+import os
+import shutil
+import time
+from concurrent.futures import Future, ProcessPoolExecutor, ThreadPoolExecutor
+from typing import Any, Callable, Dict, List, Optional
+
+import aiohttp
+import requests
+
+from ..api.cli_args import InferenceEngineConfig
+from ..api.engine_api import InferenceEngine
+from ..api.io_struct import ModelRequest, ModelResponse, WeightUpdateMeta
+from ..api.workflow_api import WorkflowExecutor
+from ..utils import logging, name_resolve, names
+from ..utils.http import arequest_with_retry, get_default_connector
+from .local_engine import interruptible_generate
+
+logger = logging.getLogger("remote-engine")
+RID_CACHE_SIZE = 128
+
+
+class RemoteInferenceEngine(InferenceEngine):
+    def __init__(self, config: InferenceEngineConfig):
+        self.config = config
+        self.rid_to_address: Dict[str, str] = {}
+        self.rid_queue: List[str] = []
+        self.addresses: List[str] = []
+        self.server_idx = 0
+        self.distributed_weight_update_initialized = False
+        self._version = 0
+        self.workflow_executor = WorkflowExecutor(config, self)
+        self.executor = None
+
+    # ------------------------------------------------------------------------------ set-up
+    def _discover(self) -> List[str]:
+        env = os.getenv("AREAL_LLM_SERVER_ADDRS")
+        if env:
+            return [a for a in env.split(",") if a]
+        if self.config.experiment_name and self.config.trial_name:
+            key = names.gen_servers(self.config.experiment_name, self.config.trial_name)
+            deadline = time.time() + self.config.setup_timeout
+            while time.time() < deadline:
+                addrs = name_resolve.get_subtree(key)
+                if addrs:
+                    return sorted(addrs)
+                time.sleep(0.5)
+        return []
+
+    def _wait_for_server(self, address: str):
+        base = f"http://{address}"
+        tik = time.time()
+        while time.time() - tik < self.config.setup_timeout:
+            try:
+                if requests.get(f"{base}/health", timeout=30).status_code == 200:
+                    return
+            except requests.exceptions.RequestException:
+                pass
+            time.sleep(0.5)
+        raise RuntimeError(f"server {address} did not become healthy within {self.config.setup_timeout}s")
+
+    def initialize(self, addr: Optional[str] = None, ft_spec=None, train_data_parallel_size: Optional[int] = None,
+                   **kwargs):
+        self.addresses = [addr] if addr else self._discover()
+        if not self.addresses:
+            raise RuntimeError("No configured rollout servers (set AREAL_LLM_SERVER_ADDRS or register them in "
+                               "name_resolve).")
+        logger.info("Waiting for server ready...")
+        for a in self.addresses:
+            self._wait_for_server(a)
+        logger.info("Servers are all ready!")
+        self.executor = ThreadPoolExecutor(max_workers=1)
+        self.workflow_executor.initialize(logger=logger, train_data_parallel_size=train_data_parallel_size)
+        return self
+
+    def destroy(self):
+        self.workflow_executor.destroy()
+        if self.executor is not None:
+            self.executor.shutdown(wait=False)
+
+    def set_version(self, version: int):
+        self._version = version
+        self.workflow_executor.notify_version_changed()
+
+    def get_version(self) -> int:
+        return self._version
+
+    # -------------------------------------------------------------------------- scheduling
+    def choose_server(self) -> str:
+        if self.config.schedule_policy == "round_robin":
+            s = self.addresses[self.server_idx]
+            self.server_idx = (self.server_idx + 1) % len(self.addresses)
+            return s
+        raise NotImplementedError("Only round-robin scheduling is implemented.")
+
+    def _server_for(self, rid: str) -> str:
+        if rid in self.rid_to_address:
+            return self.rid_to_address[rid]
+        addr = self.choose_server()
+        if len(self.rid_queue) >= RID_CACHE_SIZE:
+            self.rid_to_address.pop(self.rid_queue.pop(0), None)
+        self.rid_to_address[rid] = addr
+        self.rid_queue.append(rid)
+        return addr
+
+    async def agenerate(self, req: ModelRequest) -> ModelResponse:
+        g = req.gconfig
+        if g.stop and req.tokenizer is None:
+            raise ValueError("stop strings need a tokenizer on the request")
+        addr = self._server_for(req.rid)
+
+        async def gen_once(rid, ids, max_new, min_new):
+            payload = {
+                "rid": rid, "input_ids": ids, "return_logprob": True, "stream": False,
+                "sampling_params": {"top_p": g.top_p, "top_k": g.top_k, "max_new_tokens": max_new,
+                                    "min_new_tokens": min_new, "temperature": 0.0 if g.greedy else g.temperature,
+                                    "stop_token_ids": g.stop_token_ids, "frequency_penalty": g.frequency_penalty},
+            }
+            result = await arequest_with_retry(addr=addr, endpoint="/generate", payload=payload, method="POST",
+                                               max_retries=self.config.request_retries,
+                                               timeout=self.config.request_timeout)
+            meta = result["meta_info"]
+            lps = meta["output_token_logprobs"]
+            toks = [x[1] for x in lps]
+            vers = meta.get("output_versions") or [self._version] * len(toks)
+            return dict(output_tokens=toks, output_logprobs=[x[0] for x in lps], output_versions=vers,
+                        finish_reason=meta["finish_reason"]["type"])
+
+        return await interruptible_generate(req, gen_once, self.workflow_executor.paused.is_set, abort_sleep=0.5)
+
+    # ----------------------------------------------------------------------- weight update
+    def update_weights(self, meta: WeightUpdateMeta) -> Future:
+        for a in self.addresses:
+            requests.post(f"http://{a}/pause_generation", timeout=self.config.request_timeout).raise_for_status()
+        next_version = self._version + 1
+        if meta.type == "disk":
+            fut = self.executor.submit(_update_from_disk, self.config.experiment_name, self.config.trial_name,
+                                       self._version, self.addresses, meta.path, self.config.request_retries,
+                                       self.config.request_timeout, next_version)
+        elif meta.type in ("nccl", "xgmi"):
+            fut = self.executor.submit(_update_from_distributed, meta, self.addresses, self.config.request_retries,
+                                       self.config.request_timeout, not self.distributed_weight_update_initialized,
+                                       next_version)
+            self.distributed_weight_update_initialized = True
+        else:
+            raise NotImplementedError(f"Unsupported weight update type: {meta.type}")
+
+        def done(_f):
+            for a in self.addresses:
+                try:
+                    requests.post(f"http://{a}/continue_generation", timeout=self.config.request_timeout)
+                except requests.exceptions.RequestException as e:
+                    logger.warning(f"continue_generation failed on {a}: {e}")
+            if meta.type == "disk" and meta.path and os.path.isdir(meta.path):
+                shutil.rmtree(meta.path, ignore_errors=True)
+
+        fut.add_done_callback(done)
+        return fut
+
+    def submit(self, data, workflow=None, workflow_builder=None) -> None:
+        return self.workflow_executor.submit(data, workflow, workflow_builder)
+
+    def wait(self, count, timeout=None, should_accept=None):
+        return self.workflow_executor.wait(count, timeout=timeout, should_accept=should_accept)
+
+    def rollout_batch(self, data, workflow=None, workflow_builder=None, should_accept=None):
+        return self.workflow_executor.rollout_batch(data, workflow, workflow_builder, should_accept)
+
+    def prepare_batch(self, dataloader, workflow=None, workflow_builder=None, should_accept=None):
+        return self.workflow_executor.prepare_batch(dataloader, workflow, workflow_builder, should_accept)
+
+    def pause(self):
+        return self.workflow_executor.pause()
+
+    def resume(self):
+        return self.workflow_executor.resume()
+
+
+def _post_all(addresses, endpoint, payload, retries, timeout):
+    async def run():
+        async with aiohttp.ClientSession(timeout=aiohttp.ClientTimeout(total=timeout),
+                                         connector=get_default_connector()) as session:
+            return await asyncio.gather(*[
+                arequest_with_retry(addr=a, session=session, endpoint=endpoint, payload=payload, method="POST",
+                                    max_retries=retries, timeout=timeout) for a in addresses])
+
+    return asyncio.run(run())
+
+
+def _update_from_disk(experiment_name, trial_name, model_version, addresses, path, retries, timeout, next_version):
+    key = names.update_weights_from_disk(experiment_name, trial_name, model_version)
+    save_ts = int(name_resolve.wait(key, timeout=120))
+    load_ts = time.time_ns()
+    logger.info(f"Begin update weights from {path}, responded in {(load_ts - save_ts) / 1e6:.2f} ms")
+    res = _post_all(addresses, "/update_weights_from_disk",
+                    dict(model_path=str(path), abort_all_requests=True, version=next_version), retries, timeout)
+    for r in res:
+        assert r.get("success"), r
+    logger.info(f"Loading weights done in {(time.time_ns() - load_ts) / 1e6:.2f} ms")
+    return True
+
+
+def _update_from_distributed(meta: WeightUpdateMeta, addresses, retries, timeout, init_group, next_version):
+    if init_group:
+        tp = meta.alloc_mode.gen.tp_size if meta.alloc_mode is not None else 1
+        world = (meta.alloc_mode.gen.world_size if meta.alloc_mode is not None else len(addresses)) + 1
+
+        async def init_all():
+            async with aiohttp.ClientSession(timeout=aiohttp.ClientTimeout(total=timeout),
+                                             connector=get_default_connector()) as session:
+                return await asyncio.gather(*[
+                    arequest_with_retry(addr=a, session=session, endpoint="/init_weights_update_group", method="POST",
+                                        payload=dict(master_address=meta.nccl_master_address,
+                                                     master_port=str(meta.nccl_master_port), rank_offset=1 + i * tp,
+                                                     world_size=world, backend="nccl" if meta.type != "gloo" else "gloo",
+                                                     group_name=meta.nccl_group_name),
+                                        max_retries=retries, timeout=timeout) for i, a in enumerate(addresses)])
+
+        for r in asyncio.run(init_all()):
+            assert r.get("success"), r
+    for chunk in meta.nccl_param_specs:
+        payload = dict(names=[s.name for s in chunk], dtypes=[s.dtype for s in chunk],
+                       shapes=[list(s.shape) for s in chunk], group_name=meta.nccl_group_name,
+                       abort_all_requests=True, version=next_version)
+        for r in _post_all(addresses, "/update_weights_from_distributed", payload, retries, timeout):
+            assert r.get("success"), r
+    return True
+
+
+RemoteSGLangEngine = RemoteInferenceEngine  # name used by the reference's scripts

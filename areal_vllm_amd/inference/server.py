@@ -1,0 +1,253 @@
+"""HTTP front end of the native rollout engine.
+
+Speaks the REST verbs the reference's clients use against SGLang (``areal/engine/sglang_remote.py:83-119,
+251-309, 368-480``; ``realhf/system/gserver_manager.py:158-173``):
+
+  GET  /health, /health_generate, /get_model_info, /get_server_info, /metrics (Prometheus text)
+  POST /generate {input_ids, sampling_params, return_logprob, stream:false, rid}
+  POST /pause_generation, /continue_generation, /flush_cache, /abort_request {rid}
+  POST /update_weights_from_disk {model_path, abort_all_requests}
+  POST /init_weights_update_group {master_address, master_port, rank_offset, world_size, backend, group_name}
+  POST /update_weights_from_distributed {names, dtypes, shapes, group_name, abort_all_requests}
+  POST /set_version {version}
+
+``/generate`` answers with ``meta_info.finish_reason.type`` in {stop, length, abort},
+``meta_info.output_token_logprobs`` as ``[(logprob, token_id, None), ...]`` and, beyond SGLang,
+``meta_info.output_versions`` (weight version per token).
+
+Run: ``python -m areal_vllm_amd.inference.server --model-path <dir|preset> --host H --port P [flags]``;
+flags are the fields of ``InferenceServerConfig``.
+"""
+import argparse
+import asyncio
+import dataclasses
+import os
+import sys
+import time
+import typing
+import uuid
+from typing import Any, Dict, List, Optional
+
+import torch
+from aiohttp import web
+
+from ..api.cli_args import InferenceServerConfig
+from ..utils import logging
+from .engine import NativeInferenceEngine
+
+logger = logging.getLogger("inference-server")
+
+
+def _finish(reason: str) -> Dict[str, Any]:
+    if reason == "abort":
+        return {"type": "abort", "message": "Abort by weight update or pause"}
+    return {"type": reason}
+
+
+class InferenceServer:
+    def __init__(self, engine: NativeInferenceEngine):
+        self.engine = engine
+        self.update_group = None
+        self.start_time = time.time()
+        self.app = web.Application(client_max_size=1024**3)
+        r = self.app.router
+        r.add_get("/health", self.health)
+        r.add_get("/health_generate", self.health)
+        r.add_get("/get_model_info", self.model_info)
+        r.add_get("/get_server_info", self.server_info)
+        r.add_get("/metrics", self.metrics)
+        r.add_post("/generate", self.generate)
+        r.add_post("/pause_generation", self.pause)
+        r.add_post("/continue_generation", self.resume)
+        r.add_post("/flush_cache", self.flush_cache)
+        r.add_post("/abort_request", self.abort_request)
+        r.add_post("/update_weights_from_disk", self.update_from_disk)
+        r.add_post("/init_weights_update_group", self.init_update_group)
+        r.add_post("/update_weights_from_distributed", self.update_from_distributed)
+        r.add_post("/set_version", self.set_version)
+
+    async def health(self, req):
+        return web.Response(text="OK")
+
+    async def model_info(self, req):
+        return web.json_response({"model_path": self.engine.config.model_path, "is_generation": True,
+                                  "weight_version": self.engine.get_version()})
+
+    async def server_info(self, req):
+        return web.json_response({**dataclasses.asdict(self.engine.config), "version": "native",
+                                  "uptime": time.time() - self.start_time, **self.engine.metrics()})
+
+    async def metrics(self, req):
+        m = self.engine.metrics()
+        lines = []
+        alias = {"num_running_reqs": "sglang:num_running_reqs", "num_queue_reqs": "sglang:num_queue_reqs",
+                 "token_usage": "sglang:token_usage", "num_used_pages": "sglang:num_used_tokens"}
+        for k, v in m.items():
+            name = alias.get(k, f"areal:{k}")
+            if k == "num_used_pages":
+                v = v * 32
+            lines.append(f"# TYPE {name} gauge")
+            lines.append(f'{name}{{model_name="{self.engine.config.model_path}"}} {float(v)}')
+        return web.Response(text="\n".join(lines) + "\n", content_type="text/plain")
+
+    async def generate(self, req):
+        body = await req.json()
+        ids = body.get("input_ids")
+        if ids is None:
+            return web.json_response({"error": "this server takes token ids (`input_ids`)"}, status=400)
+        sp = body.get("sampling_params", {}) or {}
+        rid = body.get("rid") or uuid.uuid4().hex
+        temp = float(sp.get("temperature", 1.0))
+        res = await self.engine.agenerate_once(
+            f"{rid}-{uuid.uuid4().hex[:8]}", ids, max_new_tokens=int(sp.get("max_new_tokens", 128)),
+            min_new_tokens=int(sp.get("min_new_tokens", 0)), temperature=temp, top_p=float(sp.get("top_p", 1.0)),
+            top_k=int(sp.get("top_k", 1 << 30)) if int(sp.get("top_k", -1)) > 0 else 1 << 30,
+            stop_token_ids=sp.get("stop_token_ids") or [], greedy=temp <= 0.0)
+        meta = {
+            "id": rid, "finish_reason": _finish(res.finish_reason), "prompt_tokens": res.prompt_len,
+            "completion_tokens": len(res.output_tokens),
+            "output_token_logprobs": [(lp, t, None) for lp, t in zip(res.output_logprobs, res.output_tokens)],
+            "output_versions": res.output_versions, "weight_version": self.engine.get_version(),
+            "e2e_latency": res.latency, "ttft": res.ttft,
+        }
+        return web.json_response({"text": "", "output_ids": res.output_tokens, "meta_info": meta})
+
+    async def _offload(self, fn, *a, **k):
+        return await asyncio.get_running_loop().run_in_executor(None, lambda: fn(*a, **k))
+
+    async def pause(self, req):
+        await self._offload(self.engine.pause)
+        return web.json_response({"success": True})
+
+    async def resume(self, req):
+        await self._offload(self.engine.resume)
+        return web.json_response({"success": True})
+
+    async def flush_cache(self, req):
+        await self._offload(self.engine.flush_cache)
+        return web.json_response({"success": True})
+
+    async def abort_request(self, req):
+        body = await req.json()
+        n = await self._offload(self.engine.abort_all) if not body.get("rid") else 0
+        return web.json_response({"success": True, "aborted": n})
+
+    async def set_version(self, req):
+        body = await req.json()
+        await self._offload(self.engine.set_version, int(body["version"]))
+        return web.json_response({"success": True})
+
+    async def update_from_disk(self, req):
+        body = await req.json()
+        path = body["model_path"]
+        abort = bool(body.get("abort_all_requests", body.get("abort_all_request", True)))
+        t0 = time.perf_counter()
+        try:
+            await self._offload(self.engine.load_weights_from_disk, path, body.get("version"), abort)
+        except Exception as e:
+            return web.json_response({"success": False, "message": repr(e)})
+        return web.json_response({"success": True, "message": f"loaded in {time.perf_counter() - t0:.2f}s",
+                                  "num_paused_requests": 0})
+
+    async def init_update_group(self, req):
+        body = await req.json()
+
+        def f():
+            from ..utils.distributed import init_custom_process_group
+
+            rank = int(body["rank_offset"]) + self.engine.tp_rank
+            self.update_group = init_custom_process_group(
+                backend=body.get("backend", "nccl"), world_size=int(body["world_size"]), rank=rank,
+                init_method=f"tcp://{body['master_address']}:{body['master_port']}", group_name=body["group_name"])
+            return True
+
+        try:
+            await self._offload(f)
+        except Exception as e:
+            return web.json_response({"success": False, "message": repr(e)})
+        return web.json_response({"success": True, "message": "Succeeded to initialize custom process group."})
+
+    async def update_from_distributed(self, req):
+        body = await req.json()
+        names, dtypes, shapes = body["names"], body["dtypes"], body["shapes"]
+        abort = bool(body.get("abort_all_requests", True))
+
+        def f():
+            import torch.distributed as dist
+
+            dev = self.engine.device
+            tensors = {}
+            for n, dt, sh in zip(names, dtypes, shapes):
+                t = torch.empty(sh, dtype=getattr(torch, dt.replace("torch.", "")), device=dev)
+                dist.broadcast(t, src=0, group=self.update_group)
+                tensors[n] = t
+            self.engine.load_named_tensors(tensors, version=body.get("version"), abort_running=abort)
+            return True
+
+        try:
+            await self._offload(f)
+        except Exception as e:
+            return web.json_response({"success": False, "message": repr(e)})
+        return web.json_response({"success": True, "message": "Succeeded to update parameter online."})
+
+
+def _add_config_args(parser: argparse.ArgumentParser):
+    hints = typing.get_type_hints(InferenceServerConfig)
+    for f in dataclasses.fields(InferenceServerConfig):
+        name = "--" + f.name.replace("_", "-")
+        tp = hints[f.name]
+        origin = typing.get_origin(tp)
+        args = [a for a in typing.get_args(tp) if a is not type(None)]
+        base = args[0] if origin is typing.Union and args else tp
+        if base is bool:
+            parser.add_argument(name, action="store_true", default=f.default)
+        elif typing.get_origin(base) in (list, typing.List):
+            parser.add_argument(name, nargs="*", type=int, default=None)
+        else:
+            parser.add_argument(name, type=base if base in (int, float, str) else str, default=f.default)
+
+
+def parse_server_args(argv: Optional[List[str]] = None):
+    p = argparse.ArgumentParser("native rollout server")
+    p.add_argument("--host", default="127.0.0.1")
+    p.add_argument("--port", type=int, default=30000)
+    p.add_argument("--tp-size", type=int, default=1)
+    p.add_argument("--base-gpu-id", type=int, default=0)
+    p.add_argument("--nnodes", type=int, default=1)
+    p.add_argument("--node-rank", type=int, default=0)
+    p.add_argument("--dist-init-addr", default=None)
+    p.add_argument("--tokenizer-path", default=None)
+    p.add_argument("--device", default=None)
+    p.add_argument("--kv-cache-gb", type=float, default=None)
+    p.add_argument("--num-pages", type=int, default=None)
+    _add_config_args(p)
+    args, _unknown = p.parse_known_args(argv)
+    cfg_kwargs = {f.name: getattr(args, f.name) for f in dataclasses.fields(InferenceServerConfig)}
+    return args, InferenceServerConfig(**cfg_kwargs)
+
+
+def build_engine(args, cfg: InferenceServerConfig) -> NativeInferenceEngine:
+    if args.device:
+        dev = torch.device(args.device)
+    elif torch.cuda.is_available():
+        dev = torch.device("cuda", args.base_gpu_id if args.base_gpu_id < torch.cuda.device_count() else 0)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
+    if args.tp_size > 1:
+        raise NotImplementedError("multi-GPU tensor-parallel serving is launched through inference.tp_worker")
+    eng = NativeInferenceEngine(cfg, device=dev, num_pages=args.num_pages, kv_cache_gb=args.kv_cache_gb)
+    eng.initialize(load_weights=True)
+    return eng
+
+
+def main(argv: Optional[List[str]] = None):
+    args, cfg = parse_server_args(argv)
+    engine = build_engine(args, cfg)
+    server = InferenceServer(engine)
+    logger.info(f"serving on {args.host}:{args.port}")
+    web.run_app(server.app, host=args.host, port=args.port, print=None, access_log=None)
+
+
+if __name__ == "__main__":
+    main()

@@ -212,11 +212,10 @@ extern "C" int areal_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
 // ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu,
                                                          bf16_t* __restrict__ out, int64_t T, int F) {
-  const int64_t nvec_row = F >> 3;
-  const int64_t total = T * nvec_row;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = i / nvec_row, c = i % nvec_row;
+  const int nvec_row = F >> 3;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nvec_row) return;
+  for (int64_t t = blockIdx.y; t < T; t += gridDim.y) {
     bf16x8 g = ld8(gu + t * 2 * F + c * 8);
     bf16x8 u = ld8(gu + t * 2 * F + F + c * 8);
     bf16x8 o;
@@ -233,11 +232,10 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dy,
                                                          const bf16_t* __restrict__ gu,
                                                          bf16_t* __restrict__ dgu, int64_t T, int F) {
-  const int64_t nvec_row = F >> 3;
-  const int64_t total = T * nvec_row;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = i / nvec_row, c = i % nvec_row;
+  const int nvec_row = F >> 3;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nvec_row) return;
+  for (int64_t t = blockIdx.y; t < T; t += gridDim.y) {
     bf16x8 g = ld8(gu + t * 2 * F + c * 8);
     bf16x8 u = ld8(gu + t * 2 * F + F + c * 8);
     bf16x8 d = ld8(dy + t * F + c * 8);
@@ -265,16 +263,19 @@ static inline int ew_grid(int64_t total, int block) {
 extern "C" int areal_swiglu_fwd(const void* gu, void* out, int64_t T, int F, hipStream_t st) {
   if (F % 8 != 0) return -1;
   if (T == 0) return 0;
-  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid(T * (F / 8), 256)), dim3(256), 0, st,
-                     (const bf16_t*)gu, (bf16_t*)out, T, F);
+  const int gx = (F / 8 + 255) / 256;
+  const int gy = (int)(T < 8192 ? T : 8192);
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)gu, (bf16_t*)out, T, F);
   return (int)hipGetLastError();
 }
 extern "C" int areal_swiglu_bwd(const void* dy, const void* gu, void* dgu, int64_t T, int F,
                                 hipStream_t st) {
   if (F % 8 != 0) return -1;
   if (T == 0) return 0;
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_grid(T * (F / 8), 256)), dim3(256), 0, st,
-                     (const bf16_t*)dy, (const bf16_t*)gu, (bf16_t*)dgu, T, F);
+  const int gx = (F / 8 + 255) / 256;
+  const int gy = (int)(T < 8192 ? T : 8192);
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)gu,
+                     (bf16_t*)dgu, T, F);
   return (int)hipGetLastError();
 }
 
@@ -294,13 +295,11 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ x,
                                                    float sign, int max_pos) {
   const int half = D >> 1;
   const int lanes_per_head = half >> 3;  // 8 for D=128
-  const int64_t total = T * n_rot_heads * lanes_per_head;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int sub = (int)(i % lanes_per_head);
-    const int64_t th = i / lanes_per_head;
-    const int head = (int)(th % n_rot_heads);
-    const int64_t t = th / n_rot_heads;
+  const int per_tok = n_rot_heads * lanes_per_head;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (head, sub) of one token
+  if (i >= per_tok) return;
+  const int head = i / lanes_per_head, sub = i - head * lanes_per_head;
+  for (int64_t t = blockIdx.y; t < T; t += gridDim.y) {
     int p = pos[t];
     p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
     bf16_t* base = x + (t * n_heads_total + head) * D + sub * 8;
@@ -328,8 +327,11 @@ extern "C" int areal_rope_inplace(void* x, const int* pos, const float* cos_t, c
                                   int max_pos, hipStream_t st) {
   if (D % 16 != 0) return -1;
   if (T == 0) return 0;
-  const int64_t total = T * n_rot_heads * (D / 16);
-  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, st, (bf16_t*)x, pos, cos_t,
-                     sin_t, T, n_heads_total, n_rot_heads, D, sign, max_pos);
+  const int per_tok = n_rot_heads * (D / 16);
+  const int bs = per_tok >= 256 ? 256 : ((per_tok + 63) / 64) * 64;
+  const int gx = (per_tok + bs - 1) / bs;
+  const int gy = (int)(T < 16384 ? T : 16384);
+  hipLaunchKernelGGL(rope_kernel, dim3(gx, gy), dim3(bs), 0, st, (bf16_t*)x, pos, cos_t, sin_t, T,
+                     n_heads_total, n_rot_heads, D, sign, max_pos);
   return (int)hipGetLastError();
 }
