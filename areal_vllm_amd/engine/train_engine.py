@@ -47,36 +47,60 @@ logger = logging.getLogger("train-engine")
 
 
 class LogitsProxy:
-    """Lazy view of the LM-head output for one packed micro-batch (padding rows already stripped)."""
+    """Lazy view of the LM-head output for one packed micro-batch.
 
-    def __init__(self, model: Transformer, hidden: torch.Tensor, chunk: int, keep_logits: bool, tp_group=None):
+    `hidden` holds the final-norm states of the PADDED packed stream (this rank's token slice when
+    `sp`, a Ulysses context, is given). Labels and results are in un-padded packed coordinates: with
+    sequence parallelism the labels are padded, sliced to the local tokens, and the per-token results
+    are all-gathered back, so loss functions never see the partition."""
+
+    def __init__(self, model: Transformer, hidden: torch.Tensor, chunk: int, keep_logits: bool, tp_group=None,
+                 sp=None, pad_len: int = 0):
         self.model = model
+        self.sp = sp
+        self.pad_len = pad_len
+        if sp is None and pad_len > 0:
+            hidden = hidden[: hidden.shape[0] - pad_len]
         self.hidden = hidden
         self.chunk = chunk
         self.keep_logits = keep_logits
         self.tp_group = tp_group
         self._dense = None
+        self.n_tokens = hidden.shape[0] * (sp.size if sp is not None else 1) - (pad_len if sp is not None else 0)
 
     @property
     def shape(self):
-        return (self.hidden.shape[0], self.model.cfg.vocab_size)
+        return (self.n_tokens, 1 if self.model.cfg.is_critic else self.model.cfg.vocab_size)
 
     @property
     def device(self):
         return self.hidden.device
 
+    def _localize(self, t: torch.Tensor) -> torch.Tensor:
+        if self.sp is None:
+            return t
+        if self.pad_len:
+            t = torch.nn.functional.pad(t, (0, self.pad_len))
+        return self.sp.local_slice(t)
+
+    def _globalize(self, t: torch.Tensor) -> torch.Tensor:
+        if self.sp is None:
+            return t
+        return self.sp.gather_tokens(t)[: self.n_tokens]
+
     def logprobs_entropy(self, labels: torch.Tensor, temperature: float = 1.0):
-        return self.model.logprobs(self.hidden, labels, temperature, self.chunk, self.keep_logits)
+        lp, ent = self.model.logprobs(self.hidden, self._localize(labels), temperature, self.chunk, self.keep_logits)
+        return self._globalize(lp), self._globalize(ent)
 
     def logprobs(self, labels: torch.Tensor, temperature: float = 1.0):
         return self.logprobs_entropy(labels, temperature)[0]
 
     def values(self):
-        return self.model.values(self.hidden)
+        return self._globalize(self.model.values(self.hidden))
 
     def materialize(self) -> torch.Tensor:
         if self._dense is None:
-            self._dense = self.model.logits(self.hidden)
+            self._dense = self._globalize(self.model.logits(self.hidden))
         return self._dense
 
 
@@ -101,6 +125,7 @@ class NativeTrainEngine(TrainEngine):
         self.optimizer_config: Optional[OptimizerConfig] = config.optimizer
         self.model: Optional[Transformer] = None
         self.optimizer: Optional[ShardedAdamW] = None
+        self.expert_optimizer: Optional[ShardedAdamW] = None  # routed experts under expert parallelism
         self.grid: Optional[ProcessGrid] = None
         self.model_config: Optional[ModelConfig] = None
         self.is_critic = False
@@ -184,10 +209,17 @@ class NativeTrainEngine(TrainEngine):
             from ..parallel.ulysses import UlyssesContext
 
             self.model.sp = UlyssesContext(g.group("cp"), g.cp, g.coord.cp)
-        flat = self.model.flatten(pad_to=g.dp * g.cp)
+        edp = max(1, (g.dp // g.ep) * g.cp)
+        flat = self.model.flatten(pad_to=g.dp * g.cp, expert_pad_to=edp if g.ep > 1 else None)
         if cfg.init_from_scratch or not (cfg.path and os.path.isdir(cfg.path)):
             # same seed on every dp replica; tp/pp shards draw from different streams
             self.model.init_weights(seed=1 + 1000 * g.coord.tp + 100000 * g.coord.pp)
+            if g.pp > 1:
+                from ..parallel.pipeline import sync_tied_embedding_weights
+
+                sync_tied_embedding_weights(self)
+            if g.tp > 1:  # parameters replicated over tp (norms, embeddings, router) must start identical
+                self._replica_sync(flat.flat, self._tp_replicated_ranges(), "first")
             if self.is_critic and cfg.init_critic_from_actor:
                 pass
         else:
@@ -196,26 +228,75 @@ class NativeTrainEngine(TrainEngine):
             flat.alloc_main_grad()
             mp_groups = tuple(x for x in (g.group("tp"), g.group("pp")) if x is not None)
             self.optimizer = ShardedAdamW(flat, self.optimizer_config, dp_group=g.group("dp_cp"), mp_groups=mp_groups,
-                                          replicated_ranges=self._tp_replicated_ranges() if g.tp > 1 else None)
+                                          replicated_ranges=self._norm_ranges())
+            fe = self.model.flat_experts
+            if fe is not None:
+                fe.alloc_main_grad()
+                emp = tuple(x for x in (g.group("tp"), g.group("pp"), g.group("ep")) if x is not None)
+                self.expert_optimizer = ShardedAdamW(fe, self.optimizer_config, dp_group=g.group("edp"), mp_groups=emp)
             self._total_steps = max(1, ft_spec.total_train_steps if ft_spec is not None else 1)
         self.initialized = True
         logger.info(f"model {mc.family} ({flat.numel / 1e6:.1f}M params on this rank) ready in "
                     f"{time.perf_counter() - tik:.2f}s")
 
-    def _tp_replicated_ranges(self) -> List[Tuple[int, int]]:
+    def _kv_replication(self) -> int:
+        return max(1, self.grid.tp // self.model_config.n_kv_heads)
+
+    def _kv_ranges(self) -> List[Tuple[int, int, int]]:
+        """Flat ranges of the K/V rows of every fused qkv weight / bias (replicated `kv_rep` times)."""
+        D = self.model_config.head_dim
+        kv_rep = self._kv_replication()
+        out = []
+        for n, (o, numel) in self.model.flat.offsets.items():
+            if n.split(".")[-1] in ("qkv", "qkv_bias"):
+                attn = self.model.layers[0].attn
+                per_row = numel // ((attn.hq + 2 * attn.hkv) * D)
+                out.append((o + attn.hq * D * per_row, o + numel, kv_rep))
+        return out
+
+    def _tp_replicated_ranges(self) -> List[Tuple[int, int, int]]:
+        """(lo, hi, replication) flat ranges of parameters that more than one tp rank holds."""
         rep = []
         for n, (o, numel) in self.model.flat.offsets.items():
-            leaf = n.split(".")[-1]
-            if leaf in ("ln1", "ln2", "norm", "q_norm", "k_norm", "embed", "head", "router"):
-                rep.append((o, o + numel))
-        rep.sort()
-        merged: List[List[int]] = []
-        for a, b in rep:
-            if merged and a <= merged[-1][1] + ALIGN:
-                merged[-1][1] = max(merged[-1][1], b)
-            else:
-                merged.append([a, b])
-        return [(a, b) for a, b in merged]
+            if n.split(".")[-1] in ("ln1", "ln2", "norm", "q_norm", "k_norm", "embed", "head", "router"):
+                rep.append((o, o + numel, self.grid.tp))
+        if self._kv_replication() > 1:
+            rep += self._kv_ranges()
+        return sorted(rep)
+
+    def _norm_ranges(self) -> List[Tuple[int, int, float]]:
+        """Ranges whose squared-norm contribution must be down-weighted: tp replicas count once, and the
+        last pipeline stage's copy of a tied embedding counts zero times (the first stage counts it)."""
+        g = self.grid
+        ranges = self._tp_replicated_ranges() if g.tp > 1 else []
+        mc = self.model_config
+        if g.pp > 1 and mc.tie_word_embeddings and not mc.is_critic and g.is_last_stage():
+            o, numel = self.model.flat.offsets["head"]
+            ranges = [r for r in ranges if r[0] != o] + [(o, o + numel, float("inf"))]
+        return sorted(ranges)
+
+    def _replica_sync(self, flat: torch.Tensor, ranges: List[Tuple[int, int, int]], op: str):
+        """Make replicated ranges consistent inside every set of `rep` neighbouring tp ranks: `sum` adds
+        the replicas' values (gradients), `first` copies the first replica's values (initial weights)."""
+        g = self.grid
+        if g.tp == 1 or not ranges:
+            return
+        for rep in sorted({r for _, _, r in ranges}):
+            sel = [(a, b) for a, b, r in ranges if r == rep]
+            packed = torch.cat([flat[a:b] for a, b in sel])
+            allp = comm.all_gather_cat(packed.unsqueeze(0), g.group("tp"))
+            s0 = (g.coord.tp // rep) * rep
+            packed = allp[s0:s0 + rep].sum(0) if op == "sum" else allp[s0]
+            o = 0
+            for a, b in sel:
+                flat[a:b].copy_(packed[o:o + (b - a)])
+                o += b - a
+
+    def _sync_replicated_kv_grads(self):
+        """When tp exceeds the KV heads, `kv_rep` neighbouring ranks hold the same K/V projection but each
+        sees only the gradient that flows through its own query heads: sum them inside every replica set."""
+        if self.grid.tp > 1 and self._kv_replication() > 1:
+            self._replica_sync(self.model.flat.main_grad, self._kv_ranges(), "sum")
 
     def destroy(self):
         self.model = None
@@ -260,20 +341,21 @@ class NativeTrainEngine(TrainEngine):
         mb_list = pad_mb_list(mb_list, pad_value=0.0, pad_to_maximum=self.config.pad_to_maximum, align_to=align)
         return mb_list.to(self.device)
 
-    def _run_model(self, mb: Dict[str, Any]) -> torch.Tensor:
-        """Packed (padded-to-page) micro-batch -> final hidden states [T_padded, H]."""
+    def _run_model(self, mb: Dict[str, Any], hidden_in=None, residual_in=None):
+        """Packed (padded) micro-batch -> final hidden states [T_padded (/cp), H]; on a pipeline stage
+        that is not the last, the (h, residual) pair handed to the next stage."""
         ids = mb["input_ids"]
         pos = mb["position_ids"].to(torch.int32)
         cu = mb["cu_seqlens"].to(torch.int32)
-        if self.grid.pp > 1:
-            raise RuntimeError("pipeline stages are driven by parallel.pipeline.PipelineRunner")
-        return self.model(ids, pos, cu, int(mb["max_seqlen"]))
+        sp = self.model.sp
+        if sp is not None:
+            ids, pos = sp.local_slice(ids), sp.local_slice(pos)
+        return self.model(ids, pos, cu, int(mb["max_seqlen"]), hidden_in, residual_in)
 
     def _proxy(self, hidden: torch.Tensor, pad_len: int) -> LogitsProxy:
-        if pad_len > 0:
-            hidden = hidden[: hidden.shape[0] - pad_len]
         nc = self.config.native
-        return LogitsProxy(self.model, hidden, nc.logprob_chunk, nc.keep_logits, self.grid.group("tp"))
+        return LogitsProxy(self.model, hidden, nc.logprob_chunk, nc.keep_logits, self.grid.group("tp"),
+                           sp=self.model.sp, pad_len=pad_len)
 
     @staticmethod
     def _unpadded(mb_padded: Dict[str, Any], pad_len: int, old_cu: torch.Tensor) -> Dict[str, Any]:
@@ -301,7 +383,7 @@ class NativeTrainEngine(TrainEngine):
             from ..parallel.pipeline import pipeline_train_batch
 
             return pipeline_train_batch(self, input_, loss_fn, loss_weight_fn)
-        self.model.flat.main_grad.zero_()
+        self.zero_main_grads()
         mb_list = self.prepare_mb_list(input_)
         weights = [loss_weight_fn(mb) for mb in mb_list.mbs]
         total_w = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=self.device) for w in weights]).sum()
@@ -318,14 +400,36 @@ class NativeTrainEngine(TrainEngine):
             if aux is not None:
                 loss = loss + aux
             (loss * scale).backward()
+        return self.optimizer_step()
+
+    def zero_main_grads(self):
+        self.model.flat.main_grad.zero_()
+        if self.model.flat_experts is not None:
+            self.model.flat_experts.main_grad.zero_()
+
+    def optimizer_step(self) -> Dict[str, float]:
+        """Reduce gradients, clip by the global norm (dense + expert parameters), AdamW, re-gather params."""
         lr = self.current_lr()
-        self.optimizer.step(lr=lr)
+        self._sync_replicated_kv_grads()
+        if self.expert_optimizer is None:
+            self.optimizer.step(lr=lr)
+        else:
+            d, e = self.optimizer.prepare(), self.expert_optimizer.prepare()
+            total = d + e
+            d.copy_(total)
+            e.copy_(total)
+            self.optimizer.apply(lr)
+            self.expert_optimizer.apply(lr)
         return dict(update_successful=float(self.optimizer.update_successful()), grad_norm=self.optimizer.grad_norm(),
                     lr=lr)
 
     @torch.no_grad()
     def eval_batch(self, input_: Dict[str, Any], loss_fn: Callable, loss_weight_fn: Callable) -> Optional[torch.Tensor]:
         self.train(False)
+        if self.grid.pp > 1:
+            from ..parallel.pipeline import pipeline_eval_batch
+
+            return pipeline_eval_batch(self, input_, loss_fn, loss_weight_fn)
         mb_list = self.prepare_mb_list(input_)
         weights = [loss_weight_fn(mb) for mb in mb_list.mbs]
         total_w = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=self.device) for w in weights]).sum()
@@ -374,25 +478,32 @@ class NativeTrainEngine(TrainEngine):
             raise NotImplementedError(f"weight format {meta.weight_format} (use 'hf')")
         g = self.grid
         # one writer per pipeline stage: dp rank 0, cp rank 0, tp rank 0 (tp shards are gathered)
-        writer = g.coord.dp == 0 and g.coord.cp == 0 and g.coord.tp == 0
+        # (with expert parallelism every ep rank of the first expert-data-parallel replica also writes
+        # its own experts)
+        participate = g.coord.dp < g.ep and g.coord.cp == 0
+        writer = participate and g.coord.tp == 0
         tag = f"-stage{g.coord.pp}" if g.pp > 1 else ""
-        participate = g.coord.dp == 0 and g.coord.cp == 0
+        if g.ep > 1:
+            tag += f"-ep{g.coord.dp}"
         wm = {}
         if participate:
-            wm = hf_io.save_hf_checkpoint(self.model, meta.path, stage_tag=tag, write=writer)
-        if dist.is_initialized() and g.pp > 1:
+            wm = hf_io.save_hf_checkpoint(self.model, meta.path, stage_tag=tag, write=writer,
+                                          experts_only=g.coord.dp > 0)
+        if dist.is_initialized() and (g.pp > 1 or g.ep > 1):
             maps = [None] * dist.get_world_size()
             dist.all_gather_object(maps, wm if writer else {})
         else:
             maps = [wm]
-        if self.rank == g.ranks[g.index_of(g.pp - 1, 0, 0, 0)] or (g.pp == 1 and writer):
+        if self.rank == g.ranks[g.index_of(g.pp - 1, 0, 0, 0)]:
             hf_io.finalize_hf_checkpoint(meta.path, self.model_config, maps, meta.tokenizer)
             if meta.processor is not None:
                 meta.processor.save_pretrained(meta.path)
         if meta.with_optim and self.optimizer is not None:
             os.makedirs(meta.path, exist_ok=True)
-            torch.save(dict(optim=self.optimizer.state_dict(), lr_step=self._lr_step),
-                       os.path.join(meta.path, f"optim_world_size_{self.world_size}_rank_{self.rank}.pt"))
+            sd = dict(optim=self.optimizer.state_dict(), lr_step=self._lr_step)
+            if self.expert_optimizer is not None:
+                sd["expert_optim"] = self.expert_optimizer.state_dict()
+            torch.save(sd, os.path.join(meta.path, f"optim_world_size_{self.world_size}_rank_{self.rank}.pt"))
         if dist.is_initialized():
             dist.barrier()
 
@@ -402,10 +513,14 @@ class NativeTrainEngine(TrainEngine):
         hf_io.load_hf_weights(self.model, meta.path)
         if self.optimizer is not None:
             self.optimizer.resync_master_from_params()
+            if self.expert_optimizer is not None:
+                self.expert_optimizer.resync_master_from_params()
             if meta.with_optim:
                 p = os.path.join(meta.path, f"optim_world_size_{self.world_size}_rank_{self.rank}.pt")
                 sd = torch.load(p, map_location="cpu", weights_only=True)
                 self.optimizer.load_state_dict(sd["optim"])
+                if self.expert_optimizer is not None:
+                    self.expert_optimizer.load_state_dict(sd["expert_optim"])
                 self._lr_step = int(sd["lr_step"])
         if dist.is_initialized():
             dist.barrier()

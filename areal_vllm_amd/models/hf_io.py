@@ -196,8 +196,14 @@ def _gather_tp(t: torch.Tensor, dim: int, group) -> torch.Tensor:
     return torch.cat(parts, dim)
 
 
-def native_to_hf_state(model, gather: bool = True) -> Iterable[Tuple[str, torch.Tensor]]:
-    """Yield (hf_name, full tensor) for everything this pipeline stage owns (tp shards gathered)."""
+def native_to_hf_state(model, gather: bool = True, experts_only: bool = False) -> Iterable[Tuple[str, torch.Tensor]]:
+    """Yield (hf_name, full tensor) for everything this pipeline stage owns (tp shards gathered).
+    `experts_only` restricts the stream to this rank's routed experts (expert-parallel ranks > 0)."""
+    if experts_only:
+        for name, t in native_to_hf_state(model, gather, False):
+            if ".experts." in name:
+                yield name, t
+        return
     cfg: ModelConfig = model.cfg
     g = model.tp_group if gather else None
     tp = model.tp_size
@@ -254,12 +260,13 @@ def native_to_hf_state(model, gather: bool = True) -> Iterable[Tuple[str, torch.
             yield names["mlp.down"][0], _gather_tp(params[pre + "mlp.down"].data, 1, g)
     if model.has_head:
         yield "model.norm.weight", params["norm"].data
-        if "head" in params:
+        tied_copy = cfg.tie_word_embeddings and not cfg.is_critic and not model.has_embed
+        if "head" in params and not tied_copy:  # a tied LM head on the last pipeline stage is not a checkpoint tensor
             yield ("score.weight" if cfg.is_critic else "lm_head.weight"), params["head"].data
 
 
 def save_hf_checkpoint(model, path: str, tokenizer=None, stage_tag: str = "", write: bool = True,
-                       max_shard_bytes: int = MAX_SHARD_BYTES) -> Dict[str, str]:
+                       max_shard_bytes: int = MAX_SHARD_BYTES, experts_only: bool = False) -> Dict[str, str]:
     """Write this stage's tensors as (possibly several) safetensors files and return its weight map.
     Every tp rank must call it (collective gather); only ranks with `write=True` touch the disk."""
     from safetensors.torch import save_file
@@ -269,7 +276,7 @@ def save_hf_checkpoint(model, path: str, tokenizer=None, stage_tag: str = "", wr
     cur: Dict[str, torch.Tensor] = {}
     cur_bytes = 0
     files: List[Dict[str, torch.Tensor]] = []
-    for name, t in native_to_hf_state(model):
+    for name, t in native_to_hf_state(model, experts_only=experts_only):
         t = t.detach().to("cpu").contiguous().clone() if write else None
         if not write:
             continue

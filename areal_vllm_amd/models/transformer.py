@@ -34,8 +34,8 @@ def _pad(n: int, a: int = ALIGN) -> int:
 class FlatParams:
     """Flat storage for a module's parameters (bf16 or fp32) plus an fp32 main-grad buffer."""
 
-    def __init__(self, module: nn.Module, dtype: torch.dtype, device, pad_to: int = 1):
-        params = [(n, p) for n, p in module.named_parameters()]
+    def __init__(self, module: nn.Module, dtype: torch.dtype, device, pad_to: int = 1, params=None):
+        params = [(n, p) for n, p in module.named_parameters()] if params is None else list(params)
         seen = set()
         self.specs: List[Tuple[str, int, torch.Size]] = []
         off = 0
@@ -283,6 +283,7 @@ class Transformer(nn.Module):
                 self.head = nn.Parameter(torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device))
         self._rope: Optional[ops.RotaryTable] = None
         self.flat: Optional[FlatParams] = None
+        self.flat_experts: Optional[FlatParams] = None
 
     # ---------------------------------------------------------------------------- set-up
     def init_weights(self, seed: int = 0, std: float = 0.02):
@@ -300,9 +301,19 @@ class Transformer(nn.Module):
             else:
                 p.data.fill_(0.0 if self.cfg.gemma_norm else 1.0)
 
-    def flatten(self, pad_to: int = 1) -> FlatParams:
+    def flatten(self, pad_to: int = 1, expert_pad_to: Optional[int] = None) -> FlatParams:
+        """Move parameters into flat storage. With `expert_pad_to` (expert parallelism) the routed-expert
+        weights get their own buffer `flat_experts`: they are replicated over a different group (expert
+        data parallel) than the dense weights, so their gradients are reduced separately."""
         dev = next(self.parameters()).device
-        self.flat = FlatParams(self, self.dtype, dev, pad_to)
+        if expert_pad_to is None or self.cfg.n_experts == 0:
+            self.flat = FlatParams(self, self.dtype, dev, pad_to)
+            self.flat_experts = None
+        else:
+            named = list(self.named_parameters())
+            is_exp = lambda n: n.endswith("mlp.gate_up") or n.endswith("mlp.down")  # noqa: E731
+            self.flat = FlatParams(self, self.dtype, dev, pad_to, [(n, q) for n, q in named if not is_exp(n)])
+            self.flat_experts = FlatParams(self, self.dtype, dev, expert_pad_to, [(n, q) for n, q in named if is_exp(n)])
         return self.flat
 
     def rope(self, device) -> ops.RotaryTable:

@@ -67,3 +67,34 @@ def all_reduce_max(t: torch.Tensor, group) -> torch.Tensor:
     if group_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t
+
+
+def all_gather_cat(x: torch.Tensor, group) -> torch.Tensor:
+    """Concatenate `x` from every rank along dim 0."""
+    n = group_size(group)
+    if n == 1:
+        return x
+    x = x.contiguous()
+    out = x.new_empty((n * x.shape[0],) + tuple(x.shape[1:]))
+    if _is_nccl(x):
+        dist.all_gather_into_tensor(out, x, group=group)
+    else:
+        dist.all_gather(list(out.chunk(n, 0)), x, group=group)
+    return out
+
+
+def reduce_scatter_rows(x: torch.Tensor, group) -> torch.Tensor:
+    """Sum `x` over ranks and return this rank's 1/n slice along dim 0."""
+    n = group_size(group)
+    if n == 1:
+        return x
+    x = x.contiguous()
+    c = x.shape[0] // n
+    if _is_nccl(x):
+        out = x.new_empty((c,) + tuple(x.shape[1:]))
+        dist.reduce_scatter_tensor(out, x, group=group)
+        return out
+    tmp = x.clone()
+    dist.all_reduce(tmp, group=group)
+    r = group_rank(group)
+    return tmp[r * c:(r + 1) * c].contiguous()

@@ -87,6 +87,10 @@ class ProcessGrid:
         self._new_group("dp_cp", [[R(p, d, c, t) for d in rng(self.dp) for c in rng(self.cp)]
                                   for p in rng(self.pp) for t in rng(self.tp)])
         self._new_group("world", [list(self.ranks)])
+        if self.pp > 1:
+            # first + last stage of every pipeline: owners of tied input / output embeddings
+            self._new_group("embed", [[R(0, d, c, t), R(self.pp - 1, d, c, t)]
+                                      for d in rng(self.dp) for c in rng(self.cp) for t in rng(self.tp)])
         if self.ep > 1:
             assert self.dp % self.ep == 0, "expert parallel size must divide the data parallel size"
             edp = self.dp // self.ep

@@ -5,8 +5,8 @@ kept replicated (ZeRO-1) and only the fp32 master weights and Adam moments are s
 data-parallel group. A step is then ONE reduce-scatter of the flat fp32 gradient buffer and ONE
 all-gather of the flat bf16 parameter buffer (large, bandwidth-efficient xGMI transfers) instead of the
 per-layer all-gather / reduce-scatter traffic of FSDP2 that the reference uses
-(``areal/utils/fsdp.py:253-285``; F3 in its collective inventory). Even a 32B model fits this way on 8
-GPUs (64 GB params + 128 GB fp32 grads... with bf16 grad accumulation 64 GB, + 48 GB sharded state).
+(``areal/utils/fsdp.py:253-285``). A 7B model costs 14 GB (bf16 params) + 28 GB (fp32 grads) replicated
+plus 84/dp GB of sharded optimizer state per GPU; larger models add tensor / pipeline parallelism.
 
 The whole step (norm -> clip coefficient -> non-finite check -> AdamW -> bf16 shadow) runs on device
 with no host synchronisation; the gradient norm is read back lazily for logging.
@@ -25,11 +25,12 @@ from . import comm
 
 class ShardedAdamW:
     def __init__(self, flat: FlatParams, cfg: OptimizerConfig, dp_group=None, mp_groups: Tuple = (),
-                 replicated_ranges: Optional[List[Tuple[int, int]]] = None):
+                 replicated_ranges: Optional[List[Tuple[int, int, int]]] = None):
         """`dp_group`: group over which parameters are replicated (gradients are summed over it).
         `mp_groups`: model-parallel groups (tp, pp) over which the squared gradient norm is summed.
-        `replicated_ranges`: flat ranges of parameters that are replicated over the tp group; their
-        norm contribution is counted once."""
+        `replicated_ranges`: (lo, hi, rep) flat ranges of parameters held by `rep` ranks of the tp group
+        (norm weights, embeddings, KV projections when tp exceeds the KV heads); their norm contribution
+        is counted once."""
         self.flat = flat
         self.cfg = cfg
         self.group = dp_group
@@ -47,8 +48,7 @@ class ShardedAdamW:
         self.state = torch.zeros(ops.optim.STATE_SIZE, dtype=torch.float32, device=dev)
         self.grad_shard = (torch.empty(self.shard_numel, dtype=torch.float32, device=dev)
                            if self.n > 1 else None)
-        self.replicated_ranges = replicated_ranges or []
-        self.tp_group = self.mp_groups[0] if self.mp_groups else None
+        self.replicated_ranges = sorted(replicated_ranges or [])
         self._norm_buf = torch.zeros(2, dtype=torch.float32, device=dev)
         self.lr = cfg.lr
 
@@ -61,45 +61,52 @@ class ShardedAdamW:
         return self.grad_shard
 
     def _sumsq(self, gshard: torch.Tensor):
-        """Squared norm of the full (all ranks, all model-parallel shards) gradient in state[0]."""
+        """Squared norm of the full (all ranks, all model-parallel shards) gradient in state[0].
+        A range replicated `rep` times over the tp group contributes 1/rep of its square sum on every
+        replica, so the plain sum over tp counts it exactly once."""
         buf = self._norm_buf
         buf.zero_()
         if not self.mp_groups or not self.replicated_ranges:
             ops.sumsq_(gshard, buf[0:1])
         else:
-            # split this rank's shard into tp-sharded and tp-replicated pieces
             cur = self.lo
-            for (a, b) in self.replicated_ranges:
+            for (a, b, rep) in self.replicated_ranges:
                 a2, b2 = max(a, self.lo), min(b, self.hi)
                 if a2 >= b2:
                     continue
                 if cur < a2:
                     ops.sumsq_(gshard[cur - self.lo:a2 - self.lo], buf[0:1])
+                buf[1:2].zero_()
                 ops.sumsq_(gshard[a2 - self.lo:b2 - self.lo], buf[1:2])
+                buf[0:1].add_(buf[1:2], alpha=1.0 / rep)
                 cur = b2
             if cur < self.hi:
                 ops.sumsq_(gshard[cur - self.lo:], buf[0:1])
-        comm.all_reduce_sum(buf, self.group)
-        if self.mp_groups:
-            # sharded part: sum over every model-parallel group; replicated part: only over pp
-            sharded = buf[0:1].clone()
-            repl = buf[1:2].clone()
-            for i, g in enumerate(self.mp_groups):
-                comm.all_reduce_sum(sharded, g)
-                if i > 0:
-                    comm.all_reduce_sum(repl, g)
-            self.state[0:1].copy_(sharded + repl)
-        else:
-            self.state[0:1].copy_(buf[0:1] + buf[1:2])
+        total = buf[0:1]
+        comm.all_reduce_sum(total, self.group)
+        for g in self.mp_groups:
+            comm.all_reduce_sum(total, g)
+        self.state[0:1].copy_(total)
 
     # -------------------------------------------------------------------------------- step
-    def step(self, lr: Optional[float] = None, grad_prescale: float = 1.0) -> None:
-        cfg = self.cfg
-        lr = self.lr if lr is None else lr
+    def prepare(self) -> torch.Tensor:
+        """Reduce gradients and leave the global squared gradient norm in ``state[0]``; returns it (a view)
+        so that several optimizers over disjoint parameter sets can sum their norms before `apply`."""
         gshard = self.reduce_gradients()
         if self.n == 1:
             gshard = gshard[self.lo:self.hi]
         self._sumsq(gshard)
+        self._gshard = gshard
+        return self.state[0:1]
+
+    def step(self, lr: Optional[float] = None, grad_prescale: float = 1.0) -> None:
+        self.prepare()
+        self.apply(lr, grad_prescale)
+
+    def apply(self, lr: Optional[float] = None, grad_prescale: float = 1.0) -> None:
+        cfg = self.cfg
+        lr = self.lr if lr is None else lr
+        gshard = self._gshard
         ops.adam_prepare_(self.state, float(cfg.gradient_clipping or 0.0), grad_prescale, cfg.beta1, cfg.beta2)
         shadow = self.flat.flat[self.lo:self.hi]
         ops.adamw_(self.master, self.m, self.v, gshard, shadow if shadow.dtype == torch.bfloat16 else None,
