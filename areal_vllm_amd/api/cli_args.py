@@ -436,6 +436,10 @@ class SFTConfig(BaseExperimentConfig):
 @dataclass
 class GRPOConfig(BaseExperimentConfig):
     async_training: bool = True
+    rollout_weight_update: str = field(default="nccl", metadata={"choices": ["nccl", "xgmi", "disk"],
+                                                                 "help": "transport to remote rollout servers"})
+    colocated_kv_cache_gb: Optional[float] = field(default=None, metadata={
+        "help": "KV-cache budget of the in-process rollout engine (colocated mode); default: mem_fraction_static"})
     gconfig: GenerationHyperparameters = field(default_factory=GenerationHyperparameters)
     rollout: InferenceEngineConfig = field(default_factory=InferenceEngineConfig)
     actor: PPOActorConfig = field(default_factory=PPOActorConfig)

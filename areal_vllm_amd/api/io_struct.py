@@ -109,7 +109,7 @@ class WeightUpdateMeta:
         from ..utils.network import find_free_ports, gethostip
 
         return cls(
-            type="nccl" if current_platform.communication_backend == "nccl" else "disk",
+            type="nccl",  # on CPU the same broadcast protocol runs over gloo
             alloc_mode=allocation_mode,
             nccl_master_address=gethostip(),
             nccl_master_port=find_free_ports(1)[0],

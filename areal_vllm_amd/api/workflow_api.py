@@ -34,6 +34,16 @@ if TYPE_CHECKING:
 ROLLOUT_POLL_WAIT_TIME = 0.05
 
 
+def _as_batch(traj):
+    """Episodes may return {completion_id: CompletionWithTokenLogpReward} (OpenAI-style agent
+    workflows): flatten them into one padded batch, one row per stored completion."""
+    if isinstance(traj, dict) and traj and all(hasattr(v, "to_tensor_dict") for v in traj.values()):
+        from ..utils.data import concat_padded_tensors
+
+        return concat_padded_tensors([v.to_tensor_dict() for v in traj.values()])
+    return traj
+
+
 class RolloutWorkflow:
     async def arun_episode(self, engine: "InferenceEngine", data: Dict[str, Any]) -> Optional[Dict[str, Any]]:
         """Run one episode; return a padded batch (dict of [n, S] tensors) or None to drop it."""
@@ -133,7 +143,7 @@ class WorkflowExecutor:
                     await asyncio.get_running_loop().run_in_executor(None, self._wake.wait, ROLLOUT_POLL_WAIT_TIME)
                 for task in done:
                     try:
-                        traj = await task
+                        traj = _as_batch(await task)
                     except Exception:
                         traceback.print_exc()
                         traj = None

@@ -85,12 +85,13 @@ class LocalLauncher:
             env.update(env_vars or {})
             if gpu > 0:
                 if not self._devices:
-                    raise RuntimeError("no GPU visible to the local launcher")
-                ids = []
-                for _ in range(gpu):
-                    ids.append(self._devices[self._gpu_counter % len(self._devices)])
-                    self._gpu_counter += 1
-                env.update(device_env(ids))
+                    logger.warning("no GPU visible to the local launcher: children run on the CPU platform")
+                else:
+                    ids = []
+                    for _ in range(gpu):
+                        ids.append(self._devices[self._gpu_counter % len(self._devices)])
+                        self._gpu_counter += 1
+                    env.update(device_env(ids))
             log = open(self.log_path_of(job_name), "ab", buffering=0)
             argv = cmds[i] if isinstance(cmds[i], list) else ["bash", "-c", cmds[i]]
             logger.info(f"Starting local process {job_name}/{offset + i}: {cmds[i]}")
@@ -101,7 +102,7 @@ class LocalLauncher:
             self._job_counter[job_name] += 1
 
     def submit(self, job_name: str, cmd, gpu: int = 0, env_vars: Optional[Dict[str, str]] = None):
-        self.submit_array(job_name, cmd, 1, gpu, env_vars)
+        self.submit_array(job_name, [cmd], 1, gpu, env_vars)
 
     def stop(self, job_name: str, signal=None):
         keys = [k for k in self._jobs if k.split("/")[0] == job_name]

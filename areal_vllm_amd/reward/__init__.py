@@ -6,6 +6,10 @@ VALID_REWARD_FN = ["clevr_count_70k", "geometry3k", "gsm8k"]
 
 def get_custom_reward_fn(path: str, **kwargs):
     """Select a reward function by dataset path (``areal/reward/__init__.py:1-17`` in the reference)."""
+    if path.startswith("synthetic:"):
+        from ..dataset.synthetic import get_synthetic_reward_fn
+
+        return get_synthetic_reward_fn(path)
     if "clevr_count_70k" in path:
         from .clevr_count_70k import clevr_count_70k_reward_fn
 
