@@ -1,0 +1,141 @@
+"""HTTP rollout server + remote client on the CPU platform: generation parity with the trainer's
+log-probs, interruptible generation across a weight update, disk weight update protocol and metrics.
+Mirrors ``areal/tests/test_sglang_engine.py`` (remote generate / rollout / disk update) without SGLang."""
+import asyncio
+import os
+import socket
+import sys
+import tempfile
+import threading
+import time
+
+import pytest
+import requests
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def server():
+    from aiohttp import web
+
+    from areal_vllm_amd.api.cli_args import InferenceServerConfig
+    from areal_vllm_amd.inference.engine import NativeInferenceEngine
+    from areal_vllm_amd.inference.server import InferenceServer
+
+    cfg = InferenceServerConfig(model_path="tiny", dtype="float32", context_length=256, max_running_requests=8,
+                                num_continuous_decode_steps=2)
+    eng = NativeInferenceEngine(cfg, device=torch.device("cpu"), num_pages=64).initialize(load_weights=False)
+    srv = InferenceServer(eng)
+    port = _free_port()
+    loop = asyncio.new_event_loop()
+    started = threading.Event()
+
+    def run():
+        asyncio.set_event_loop(loop)
+        runner = web.AppRunner(srv.app)
+        loop.run_until_complete(runner.setup())
+        loop.run_until_complete(web.TCPSite(runner, "127.0.0.1", port).start())
+        started.set()
+        loop.run_forever()
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    assert started.wait(30)
+    yield f"127.0.0.1:{port}", eng
+    loop.call_soon_threadsafe(loop.stop)
+    eng.destroy()
+
+
+def test_health_metrics_and_generate(server):
+    addr, eng = server
+    assert requests.get(f"http://{addr}/health", timeout=10).status_code == 200
+    r = requests.post(f"http://{addr}/generate", json={
+        "input_ids": [5, 6, 7, 8], "sampling_params": {"max_new_tokens": 6, "temperature": 1.0},
+        "return_logprob": True}, timeout=60).json()
+    meta = r["meta_info"]
+    assert meta["finish_reason"]["type"] in ("length", "stop")
+    assert len(meta["output_token_logprobs"]) == meta["completion_tokens"] == len(r["output_ids"])
+    assert all(lp <= 0 for lp, _, _ in meta["output_token_logprobs"])
+    assert meta["output_versions"] == [0] * meta["completion_tokens"]
+    text = requests.get(f"http://{addr}/metrics", timeout=10).text
+    assert "sglang:num_running_reqs" in text and "areal:gen_tokens_total" in text
+
+
+def test_remote_engine_rollout_and_disk_update(server, tmp_path):
+    addr, eng = server
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters, InferenceEngineConfig
+    from areal_vllm_amd.api.io_struct import WeightUpdateMeta
+    from areal_vllm_amd.engine.remote_engine import RemoteInferenceEngine
+    from areal_vllm_amd.models import hf_io
+    from areal_vllm_amd.utils import name_resolve, names
+    from areal_vllm_amd.workflow.rlvr import RLVRWorkflow
+
+    name_resolve.reconfigure("memory")
+    cfg = InferenceEngineConfig(experiment_name="srv", trial_name="t", max_concurrent_rollouts=4,
+                                consumer_batch_size=2, setup_timeout=30)
+    client = RemoteInferenceEngine(cfg).initialize(addr=addr, train_data_parallel_size=1)
+    wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: float(len(ci) % 2), GenerationHyperparameters(
+        n_samples=2, max_new_tokens=8, stop_token_ids=[1]), reward_in_process=True)
+    batch = client.rollout_batch([dict(input_ids=[3, 4, 5]), dict(input_ids=[9, 8, 7, 6, 5])], workflow=wf)
+    assert batch["input_ids"].shape[0] == 4
+    assert (batch["versions"][batch["loss_mask"].bool()] == 0).all()
+
+    # disk weight update: write the engine's own (perturbed) weights as a HF checkpoint
+    before = eng.model.flat.flat.clone()
+    eng.model.flat.flat.mul_(1.5)
+    path = str(tmp_path / "weight_update")
+    wm = hf_io.save_hf_checkpoint(eng.model, path)
+    hf_io.finalize_hf_checkpoint(path, eng.model_config, [wm])
+    eng.model.flat.flat.copy_(before)
+    name_resolve.add(names.update_weights_from_disk("srv", "t", 0), str(time.time_ns()), replace=True)
+    client.pause()
+    fut = client.update_weights(WeightUpdateMeta(type="disk", path=path))
+    assert fut.result(timeout=120)
+    client.set_version(1)
+    client.resume()
+    torch.testing.assert_close(eng.model.flat.flat, before * 1.5)
+    assert eng.get_version() == 1
+    batch = client.rollout_batch([dict(input_ids=[3, 4, 5])], workflow=wf)
+    assert (batch["versions"][batch["loss_mask"].bool()] == 1).all()
+    client.destroy()
+
+
+def test_interrupted_generation_spans_versions(server):
+    """A long generation that is aborted by a weight update is re-issued and finishes with tokens from
+    both versions (partial-rollout semantics)."""
+    addr, eng = server
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters, InferenceEngineConfig
+    from areal_vllm_amd.api.io_struct import ModelRequest
+    from areal_vllm_amd.engine.remote_engine import RemoteInferenceEngine
+
+    base = eng.get_version()
+    client = RemoteInferenceEngine(InferenceEngineConfig(setup_timeout=30)).initialize(addr=addr)
+    client.set_version(base)
+
+    async def go():
+        req = ModelRequest(input_ids=[4, 5, 6], gconfig=GenerationHyperparameters(max_new_tokens=120, min_new_tokens=120))
+        task = asyncio.create_task(client.agenerate(req))
+        await asyncio.sleep(0.3)
+        loop = asyncio.get_running_loop()
+        await loop.run_in_executor(None, lambda: requests.post(f"http://{addr}/pause_generation", timeout=30))
+        await loop.run_in_executor(None, lambda: requests.post(
+            f"http://{addr}/abort_request", json={}, timeout=30))
+        await loop.run_in_executor(None, lambda: requests.post(
+            f"http://{addr}/set_version", json={"version": base + 1}, timeout=30))
+        await loop.run_in_executor(None, lambda: requests.post(f"http://{addr}/continue_generation", timeout=30))
+        return await task
+
+    resp = asyncio.run(go())
+    assert resp.output_len == 120
+    vs = set(resp.output_versions)
+    assert vs <= {base, base + 1} and (base + 1) in vs
+    assert resp.output_versions == sorted(resp.output_versions)
+    client.destroy()
