@@ -548,7 +548,9 @@ class NativeTrainEngine(TrainEngine):
     def upload_weights(self, meta: WeightUpdateMeta):
         if meta.type == "inproc":
             assert self._local_rollout_engine is not None, "no in-process rollout engine connected"
-            self._local_rollout_engine.load_weights_from_trainer(self.model, version=None)
+            eng = self._local_rollout_engine
+            eng.load_weights_from_trainer(self.model, version=None,
+                                          abort_running=getattr(eng, "abort_on_weight_update", True))
         elif meta.type == "disk":
             self._upload_disk(meta)
         elif meta.type in ("nccl", "xgmi"):

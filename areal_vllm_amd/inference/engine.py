@@ -90,6 +90,7 @@ class NativeInferenceEngine:
         self.stats = dict(prefill_steps=0, decode_steps=0, prefill_time=0.0, decode_time=0.0, gen_tokens=0,
                           prompt_tokens=0, aborted=0)
         self._copy_stream = None
+        self._stream = None
 
     # ------------------------------------------------------------------------------ set-up
     def initialize(self, load_weights: bool = True):
@@ -153,6 +154,10 @@ class NativeInferenceEngine:
     def _loop(self):
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
+            # the engine owns a stream: decode graphs overlap with whatever the trainer thread runs on
+            # its stream (colocated asynchronous training)
+            self._stream = torch.cuda.Stream(device=self.device)
+            torch.cuda.set_stream(self._stream)
         try:
             while not self._stop.is_set():
                 self._drain_control()
@@ -334,6 +339,11 @@ class NativeInferenceEngine:
         """Colocated update: one device-to-device copy of the flat bf16 buffer on a side stream, applied
         between two engine steps; running requests are aborted first (their KV is stale)."""
         src = trainer_model.flat.flat
+        cuda = self.device.type == "cuda"
+        ready = done = None
+        if cuda:  # the optimizer step that produced `src` runs on the caller's stream
+            ready, done = torch.cuda.Event(), torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
 
         def f():
             if abort_running:
@@ -341,17 +351,21 @@ class NativeInferenceEngine:
                 self._deliver()
             dst = self.model.flat.flat
             assert dst.numel() == src.numel(), "trainer and rollout parameter layouts differ"
-            if self.device.type == "cuda":
+            if cuda:
                 if self._copy_stream is None:
                     self._copy_stream = torch.cuda.Stream(device=self.device)
                 self._copy_stream.wait_stream(torch.cuda.current_stream())
+                self._copy_stream.wait_event(ready)
                 with torch.cuda.stream(self._copy_stream):
                     dst.copy_(src, non_blocking=True)
+                    done.record(self._copy_stream)
                 torch.cuda.current_stream().wait_stream(self._copy_stream)
             else:
                 dst.copy_(src)
             self._after_weight_change(version)
         self._control(f)
+        if cuda:  # the caller must not overwrite `src` before the copy has read it
+            torch.cuda.current_stream().wait_event(done)
 
     def load_weights_from_disk(self, path: str, version: Optional[int] = None, abort_running: bool = True):
         def f():

@@ -10,6 +10,14 @@ Every rank owns one GPU and runs BOTH a rollout engine and a data-parallel train
 (colocated allocation); per-GPU work is fixed as N grows (weak scaling): 32 prompts x 4 samples per GPU
 per step, which at N = 8 is the reference config's 256 prompts x 4 samples per step.
 
+Training is asynchronous with bounded staleness like the reference config (``async_training: true``,
+``max_head_offpolicyness: 2``): the rollout engine keeps generating on its own HIP stream while the
+trainer consumes the oldest finished batch, weight updates interrupt running generations (their KV is
+recomputed with the new weights) and every token carries the version that produced it. ``--eta 0`` gives
+the synchronous schedule. Before the W warm-up steps the rollout pipeline is primed with eta+1 untimed
+steps so that the timed steps see the steady state (staggered batches), not the start-up transient in
+which eta+1 batches finish together.
+
 Launch: ``python bench.py`` (1 GPU) or
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W``.
 Rank 0 prints ONE JSON line. `value` = RL samples (trajectories) per second over the whole job.
@@ -42,6 +50,9 @@ def parse_args():
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--kv-cache-gb", type=float, default=24.0)
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--eta", type=int, default=2, help="max_head_offpolicyness; 0 = synchronous RL")
+    p.add_argument("--retain-kv", action="store_true",
+                   help="keep the KV cache of running generations across weight updates (no re-prefill)")
     p.add_argument("--profile-phases", action="store_true", help="print per-phase timings on rank 0 (stderr)")
     return p.parse_args()
 
@@ -97,15 +108,18 @@ def main():
     # ---- rollout engine on the same GPU
     srv = InferenceServerConfig(model_path=args.model, random_seed=1 + rank, dtype="bfloat16",
                                 context_length=args.prompt_len_max + args.max_new_tokens + 64,
-                                max_running_requests=n_seqs_per_gpu, max_prefill_tokens=32768,
+                                max_running_requests=n_seqs_per_gpu * (args.eta + 1), max_prefill_tokens=32768,
                                 num_continuous_decode_steps=args.decode_steps, disable_cuda_graph=args.no_graph,
                                 schedule_policy="fcfs")
     engine = NativeInferenceEngine(srv, model_config=actor.model_config, device=dev, kv_cache_gb=args.kv_cache_gb)
     engine.initialize(load_weights=False)
     actor.connect_local_engine(engine)
     rollout = LocalInferenceEngine(
-        InferenceEngineConfig(experiment_name="bench", trial_name="bench", max_concurrent_rollouts=args.prompts_per_gpu,
-                              consumer_batch_size=args.prompts_per_gpu * world, max_head_offpolicyness=0), engine)
+        InferenceEngineConfig(experiment_name="bench", trial_name="bench",
+                              max_concurrent_rollouts=args.prompts_per_gpu * world * (args.eta + 1),
+                              consumer_batch_size=args.prompts_per_gpu * world, max_head_offpolicyness=args.eta,
+                              queue_size=args.prompts_per_gpu * 64), engine)
+    engine.abort_on_weight_update = not args.retain_kv
     rollout.initialize(train_data_parallel_size=world)
     meta = WeightUpdateMeta.from_inproc()
     actor.upload_weights(meta)  # trainer weights -> engine (both start from the same values)
@@ -129,16 +143,25 @@ def main():
             out.append(dict(input_ids=torch.randint(1000, 100000, (n,), generator=g).tolist()))
         return out
 
+    class PromptLoader:
+        """Endless synthetic prompt stream in batches of one consumer batch per rank."""
+        batch_size = args.prompts_per_gpu
+
+        def __iter__(self):
+            while True:
+                yield make_prompts()
+
+    loader = PromptLoader()
     phase = {}
 
     def timed(name):
         class _T:
             def __enter__(s):
-                torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()
                 s.t = time.perf_counter()
 
             def __exit__(s, *a):
-                torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()
                 phase[name] = phase.get(name, 0.0) + time.perf_counter() - s.t
         return _T()
 
@@ -146,12 +169,17 @@ def main():
 
     def one_step(step, count):
         with timed("rollout"):
-            batch = rollout.rollout_batch(make_prompts(), workflow=workflow)
+            if args.eta > 0:
+                batch = rollout.prepare_batch(loader, workflow=workflow)
+            else:
+                batch = rollout.rollout_batch(make_prompts(), workflow=workflow)
             batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
         if count:
             tot["samples"] += batch["input_ids"].shape[0]
             tot["gen_tokens"] += int(batch["loss_mask"].sum())
             tot["all_tokens"] += int(batch["attention_mask"].sum())
+            lm = batch["loss_mask"].bool()
+            tot["stale_sum"] = tot.get("stale_sum", 0.0) + float((step - batch["versions"][lm]).float().mean())
         with timed("recompute_logp"):
             batch["prox_logp"] = actor.compute_logp(batch)
         with timed("advantages"):
@@ -173,13 +201,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
+    prime = args.eta + 1 if args.eta > 0 else 0
+    for s in range(prime + args.warmup):
         one_step(s, False)
     phase.clear()
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        stats = one_step(args.warmup + s, True)
+        stats = one_step(prime + args.warmup + s, True)
     barrier()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -205,12 +234,16 @@ def main():
             "mean_seq_len": round(mean_len, 1), "mean_gen_len": round(gen_tok / max(1.0, samples), 1),
             "phase_s_per_step_rank0": {k: round(v / args.steps, 4) for k, v in phase.items()},
             "grad_norm_last": stats[-1].get("grad_norm"),
+            "mean_token_staleness_rank0": round(tot.get("stale_sum", 0.0) / args.steps, 3),
+            "pipeline_prime_steps": prime,
             "baseline_note": "vs_baseline = end-to-end tokens/s over (20k tok/s x n_gpus/8), the reference's "
                              "published 1.5B single-node figure on 8xH800 (blog/AReaL_v0_2.md:54); it publishes no "
                              "samples/s number",
             "config": {"model": "Qwen2-1.5B (random init)", "global_batch": int(args.prompts_per_gpu * world),
                        "n_samples": args.n_samples, "seq_len": args.prompt_len_max + args.max_new_tokens,
                        "max_new_tokens": args.max_new_tokens, "parallelism": f"dp{world} colocated rollout+train",
+                       "async_training": args.eta > 0, "max_head_offpolicyness": args.eta,
+                       "interrupt_on_weight_update": "retain-kv" if args.retain_kv else "abort+recompute",
                        "algo": "GRPO, decoupled PPO loss, recompute_logprob, ppo_n_minibatches=1",
                        "max_tokens_per_mb": args.max_tokens_per_mb, "decode_steps_per_plan": args.decode_steps},
         }
