@@ -53,6 +53,8 @@ def parse_args():
     p.add_argument("--eta", type=int, default=2, help="max_head_offpolicyness; 0 = synchronous RL")
     p.add_argument("--retain-kv", action="store_true",
                    help="keep the KV cache of running generations across weight updates (no re-prefill)")
+    p.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                   help="cpu = gloo rehearsal of the multi-rank control flow with a tiny model (not a benchmark)")
     p.add_argument("--profile-phases", action="store_true", help="print per-phase timings on rank 0 (stderr)")
     return p.parse_args()
 
@@ -72,9 +74,19 @@ def main():
     os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("AREAL_LOG_LEVEL", "WARNING")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        os.environ["HIP_VISIBLE_DEVICES"] = os.environ["CUDA_VISIBLE_DEVICES"] = ""
+        os.environ["AREAL_PLATFORM"] = "cpu"
+        dev = torch.device("cpu")
+
+    def dev_sync(all_streams=False):
+        if on_gpu:
+            (torch.cuda.synchronize() if all_streams else torch.cuda.current_stream().synchronize())
 
     from areal_vllm_amd.api.alloc_mode import ParallelStrategy
     from areal_vllm_amd.api.cli_args import (AdvNormConfig, GenerationHyperparameters, InferenceEngineConfig,
@@ -91,7 +103,8 @@ def main():
 
     # ---- trainer (hyper-parameters of examples/math/gsm8k_grpo.yaml in the reference)
     actor_cfg = PPOActorConfig(
-        experiment_name="bench", trial_name="bench", path=args.model, init_from_scratch=True, dtype="bfloat16",
+        experiment_name="bench", trial_name="bench", path=args.model, init_from_scratch=True,
+        dtype="bfloat16" if on_gpu else "float32",
         gradient_checkpointing=False, mb_spec=MicroBatchSpec(max_tokens_per_mb=args.max_tokens_per_mb),
         optimizer=OptimizerConfig(type="adam", lr=1.7e-5, weight_decay=0.017, beta1=0.9, beta2=0.999, eps=1e-8,
                                   lr_scheduler_type="constant", gradient_clipping=1.0, warmup_steps_proportion=0.001),
@@ -106,12 +119,14 @@ def main():
                                         train_batch_size=args.prompts_per_gpu * world))
 
     # ---- rollout engine on the same GPU
-    srv = InferenceServerConfig(model_path=args.model, random_seed=1 + rank, dtype="bfloat16",
+    srv = InferenceServerConfig(model_path=args.model, random_seed=1 + rank, dtype="bfloat16" if on_gpu else "float32",
                                 context_length=args.prompt_len_max + args.max_new_tokens + 64,
                                 max_running_requests=n_seqs_per_gpu * (args.eta + 1), max_prefill_tokens=32768,
                                 num_continuous_decode_steps=args.decode_steps, disable_cuda_graph=args.no_graph,
                                 schedule_policy="fcfs")
-    engine = NativeInferenceEngine(srv, model_config=actor.model_config, device=dev, kv_cache_gb=args.kv_cache_gb)
+    engine = NativeInferenceEngine(srv, model_config=actor.model_config, device=dev,
+                                   kv_cache_gb=args.kv_cache_gb if on_gpu else None,
+                                   num_pages=None if on_gpu else 2048)
     engine.initialize(load_weights=False)
     actor.connect_local_engine(engine)
     rollout = LocalInferenceEngine(
@@ -140,7 +155,7 @@ def main():
         out = []
         for _ in range(args.prompts_per_gpu):
             n = int(torch.randint(args.prompt_len_min, args.prompt_len_max + 1, (1,), generator=g))
-            out.append(dict(input_ids=torch.randint(1000, 100000, (n,), generator=g).tolist()))
+            out.append(dict(input_ids=torch.randint(2, min(100000, mc.vocab_size), (n,), generator=g).tolist()))
         return out
 
     class PromptLoader:
@@ -157,11 +172,11 @@ def main():
     def timed(name):
         class _T:
             def __enter__(s):
-                torch.cuda.current_stream().synchronize()
+                dev_sync()
                 s.t = time.perf_counter()
 
             def __exit__(s, *a):
-                torch.cuda.current_stream().synchronize()
+                dev_sync()
                 phase[name] = phase.get(name, 0.0) + time.perf_counter() - s.t
         return _T()
 
@@ -199,7 +214,7 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync(all_streams=True)
 
     prime = args.eta + 1 if args.eta > 0 else 0
     for s in range(prime + args.warmup):
@@ -239,7 +254,7 @@ def main():
             "baseline_note": "vs_baseline = end-to-end tokens/s over (20k tok/s x n_gpus/8), the reference's "
                              "published 1.5B single-node figure on 8xH800 (blog/AReaL_v0_2.md:54); it publishes no "
                              "samples/s number",
-            "config": {"model": "Qwen2-1.5B (random init)", "global_batch": int(args.prompts_per_gpu * world),
+            "config": {"model": "Qwen2-1.5B (random init)" if args.model == "qwen2-1.5b" else f"{args.model} (random init)", "global_batch": int(args.prompts_per_gpu * world),
                        "n_samples": args.n_samples, "seq_len": args.prompt_len_max + args.max_new_tokens,
                        "max_new_tokens": args.max_new_tokens, "parallelism": f"dp{world} colocated rollout+train",
                        "async_training": args.eta > 0, "max_head_offpolicyness": args.eta,
