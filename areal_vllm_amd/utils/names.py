@@ -78,3 +78,11 @@ def distributed_master(experiment_name, trial_name, model_name):
 
 def used_ports(experiment_name, trial_name, host_name):
     return f"{USER_NAMESPACE}/{experiment_name}/{trial_name}/{host_name}/"
+
+
+def stream_pullers(experiment_name, trial_name):
+    return f"{trial_root(experiment_name, trial_name)}/stream_pullers"
+
+
+def metric_server(experiment_name, trial_name, group, name):
+    return f"{trial_root(experiment_name, trial_name)}/metrics/{group}/{name}"
