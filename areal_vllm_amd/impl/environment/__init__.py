@@ -1,0 +1,1 @@
+from . import math_code_single_step_env  # noqa: F401
