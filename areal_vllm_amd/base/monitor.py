@@ -58,6 +58,16 @@ def calculate_llama_gen_flops(batch_size: int, prompt_lens: List[int], gen_len: 
     return flops + gen_len * per_step_fixed + attn
 
 
+def transformer_forward_flops(n_tokens: int, avg_seqlen: float, num_layers: int, hidden_size: int,
+                              intermediate_size: int, vocab_size: int, n_q_heads: Optional[int] = None,
+                              n_kv_heads: Optional[int] = None, head_dim: Optional[int] = None, **_) -> float:
+    """Forward FLOPs from token counts alone (`n_tokens` tokens in sequences of about `avg_seqlen`)."""
+    n = max(1, int(round(n_tokens / max(1.0, avg_seqlen))))
+    lens = [int(avg_seqlen)] * n
+    return float(calculate_llama_forward_flops(n, lens, num_layers, hidden_size, intermediate_size, vocab_size,
+                                               n_q_heads, n_kv_heads, head_dim))
+
+
 caculuate_llama_forward_flops = calculate_llama_forward_flops  # spelling used by the reference's callers
 
 

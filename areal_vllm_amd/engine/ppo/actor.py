@@ -181,7 +181,9 @@ class PPOActor:
         old_logp = old_logp * loss_mask
         attn_mask = data["attention_mask"]
         seqlens = attn_mask.sum(-1).long()
-        seq_no_eos_mask = seqlens == attn_mask.shape[1]
+        # truncated sequences: flagged explicitly by the worker runtime, else "filled the whole row"
+        seq_no_eos_mask = (data["seq_no_eos_mask"].bool() if "seq_no_eos_mask" in data
+                           else seqlens == attn_mask.shape[1])
         rewards = -self.kl_ctl * (old_logp - ref_logp)
         kl_rewards = rewards.clone()
         rewards[idx, seqlens - 1] = 0

@@ -140,7 +140,10 @@ class NativeTrainEngine(TrainEngine):
         self._training = True
 
     # ------------------------------------------------------------------ process groups
-    def create_process_group(self, parallel_strategy: Optional[ParallelStrategy] = None):
+    def create_process_group(self, parallel_strategy: Optional[ParallelStrategy] = None,
+                             grid: Optional[ProcessGrid] = None):
+        """`grid`: a ready-made rank grid over a SUBSET of the world (worker runtime: several models share
+        one world of model workers, each with its own layout); otherwise the strategy must fill the world."""
         from ..platforms import current_platform
 
         if not dist.is_initialized():
@@ -148,6 +151,13 @@ class NativeTrainEngine(TrainEngine):
             self.own_global_group = True
         if current_platform.device_type == "cuda":
             self.device = torch.device("cuda", torch.cuda.current_device())
+        if grid is not None:
+            assert grid.member, "this process is not part of the model's rank grid"
+            self.parallel_strategy = grid.strategy
+            self.grid = grid
+            self.rank = grid.local_index
+            self.world_size = grid.world
+            return
         if parallel_strategy is None:
             parallel_strategy = ParallelStrategy(data_parallel_size=dist.get_world_size())
         self.parallel_strategy = parallel_strategy
@@ -490,11 +500,11 @@ class NativeTrainEngine(TrainEngine):
             wm = hf_io.save_hf_checkpoint(self.model, meta.path, stage_tag=tag, write=writer,
                                           experts_only=g.coord.dp > 0)
         if dist.is_initialized() and (g.pp > 1 or g.ep > 1):
-            maps = [None] * dist.get_world_size()
-            dist.all_gather_object(maps, wm if writer else {})
+            maps = [None] * g.world
+            dist.all_gather_object(maps, wm if writer else {}, group=g.group("world"))
         else:
             maps = [wm]
-        if self.rank == g.ranks[g.index_of(g.pp - 1, 0, 0, 0)]:
+        if g.global_rank == g.ranks[g.index_of(g.pp - 1, 0, 0, 0)]:
             hf_io.finalize_hf_checkpoint(meta.path, self.model_config, maps, meta.tokenizer)
             if meta.processor is not None:
                 meta.processor.save_pretrained(meta.path)
@@ -505,7 +515,7 @@ class NativeTrainEngine(TrainEngine):
                 sd["expert_optim"] = self.expert_optimizer.state_dict()
             torch.save(sd, os.path.join(meta.path, f"optim_world_size_{self.world_size}_rank_{self.rank}.pt"))
         if dist.is_initialized():
-            dist.barrier()
+            dist.barrier(group=self.grid.group("world"))
 
     def load(self, meta: SaveLoadMeta):
         if meta.weight_format != "hf":
@@ -523,7 +533,7 @@ class NativeTrainEngine(TrainEngine):
                     self.expert_optimizer.load_state_dict(sd["expert_optim"])
                 self._lr_step = int(sd["lr_step"])
         if dist.is_initialized():
-            dist.barrier()
+            dist.barrier(group=self.grid.group("world"))
 
     # ---------------------------------------------------------------------- weight upload
     def get_param_specs(self, weight_chunked_mem_mb: int = 1024) -> List[List[ParamSpec]]:
@@ -564,7 +574,7 @@ class NativeTrainEngine(TrainEngine):
             key = names.update_weights_from_disk(self.config.experiment_name, self.config.trial_name, self._version)
             name_resolve.add(key, str(time.time_ns()), keepalive_ttl=120, replace=True)
         if dist.is_initialized():
-            dist.barrier()
+            dist.barrier(group=self.grid.group("world"))
 
     def _init_weight_update_group(self, meta: WeightUpdateMeta):
         from ..utils.distributed import init_custom_process_group
@@ -587,7 +597,7 @@ class NativeTrainEngine(TrainEngine):
                     t = full[spec.name].contiguous()
                     dist.broadcast(t, src=0, group=self._weight_update_group)
             if dist.is_initialized():
-                dist.barrier()
+                dist.barrier(group=self.grid.group("world"))
         if self.device.type == "cuda":
             torch.cuda.synchronize()
 

@@ -1,1 +1,1 @@
-from . import math_code_single_step_env  # noqa: F401
+from . import math_code_single_step_env, toy_env  # noqa: F401

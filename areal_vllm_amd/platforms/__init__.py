@@ -3,12 +3,16 @@
 The reference only detects NVIDIA devices (``areal/platforms/__init__.py:13-33``); this framework targets
 gfx950 and keeps a CPU/gloo platform for unit tests and the plumbing configuration.
 """
+import os
+
 import torch
 
 from .platform import CpuPlatform, Platform, RocmPlatform
 
 
 def _detect() -> Platform:
+    if os.environ.get("AREAL_PLATFORM", "").lower() == "cpu":  # forced host run (tests, plumbing configuration)
+        return CpuPlatform()
     try:
         if torch.cuda.is_available() and torch.cuda.device_count() > 0:
             return RocmPlatform()

@@ -62,6 +62,7 @@ class GserverManager(Worker):
         self._gen_tokens = 0
         self._last_thpt_time = time.time()
         self._staleness_warned = set()
+        self._base_samples = None
         self.thread: Optional[threading.Thread] = None
         self.manager_addr: Optional[str] = None
         self._loop: Optional[asyncio.AbstractEventLoop] = None
@@ -105,7 +106,12 @@ class GserverManager(Worker):
             return 0
 
     def is_staled(self) -> bool:
-        n = self.get_training_sample_cnt() + self.rollout_stat.running
+        # finished rollouts count as soon as they are accepted, not only once the trainer has fetched
+        # them: samples waiting in the trainer's stream queue are just as committed as fetched ones
+        if self._base_samples is None:
+            self._base_samples = self.get_training_sample_cnt()
+        n = max(self.get_training_sample_cnt(), self._base_samples + self.rollout_stat.accepted) \
+            + self.rollout_stat.running
         expected_version = n // self.config.train_batch_size
         staled = expected_version > self.config.max_head_offpolicyness + self._version
         if staled and self._version not in self._staleness_warned:

@@ -317,7 +317,13 @@ class NameResolvingRequestClient:
             return self._replies.pop(request_id)
 
     def gather(self, request_ids: List[str], timeout: Optional[float] = None) -> List[Any]:
-        return [self.poll(r, block=True, timeout=timeout).data for r in request_ids]
+        out = []
+        for r in request_ids:
+            d = self.poll(r, block=True, timeout=timeout).data
+            if isinstance(d, dict) and d.get("__error__"):
+                raise RuntimeError(f"remote handler failed: {d['__error__']}")
+            out.append(d)
+        return out
 
     def call(self, handlers: List[Hashable], handle_type: str, datas: Optional[List[Any]] = None, **kw) -> List[Any]:
         return self.gather(self.request(handlers, handle_type, datas, **kw))

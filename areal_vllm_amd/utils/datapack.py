@@ -99,3 +99,26 @@ def reorder_to_balanced_batches(seqlens: Sequence[int], n_groups: int) -> Tuple[
 
 def flat2d(xs):
     return [y for x in xs for y in x]
+
+
+def balanced_partition(lens: Sequence[int], k: int, equal_size: bool = False) -> List[List[int]]:
+    """Assign item indices to `k` parts with near-equal token sums (longest first, to the lightest part).
+    With `equal_size` the item counts of the parts differ by at most one as well (training batches: every
+    data-parallel replica must see the same number of samples). Indices inside a part keep input order."""
+    n = len(lens)
+    assert n >= k, f"cannot split {n} items into {k} non-empty parts"
+    cap = (n + k - 1) // k if equal_size else n
+    order = sorted(range(n), key=lambda i: (-int(lens[i]), i))
+    parts: List[List[int]] = [[] for _ in range(k)]
+    sums = [0] * k
+    for pos, i in enumerate(order):
+        remaining = n - pos
+        empty = [j for j in range(k) if not parts[j]]
+        if len(empty) >= remaining:  # every remaining item is needed to keep the parts non-empty
+            j = empty[0]
+        else:
+            cands = [j for j in range(k) if len(parts[j]) < cap]
+            j = min(cands, key=lambda j: (sums[j], j))
+        parts[j].append(i)
+        sums[j] += int(lens[i])
+    return [sorted(p) for p in parts]

@@ -1,0 +1,77 @@
+"""Time the captured decode graph of the rollout engine at fixed batch / context sizes.
+
+    python tools/decode_probe.py --model qwen2-1.5b --batch 128,256,384 --ctx 640 --iters 20
+
+Builds the model with random weights, fabricates decode plans (sequential page tables, every sequence at
+`ctx` tokens) and replays the `decode_steps`-step graph. Prints ms per decode step and tokens/s. Run it
+under ``rocprofv3 --kernel-trace --stats`` for the per-kernel split (``--iters 3`` is enough then).
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from areal_vllm_amd.inference.model_runner import ModelRunner  # noqa: E402
+from areal_vllm_amd.models.config import preset  # noqa: E402
+from areal_vllm_amd.models.transformer import Transformer  # noqa: E402
+from areal_vllm_amd.ops.attention import PAGE_SIZE  # noqa: E402
+
+
+def make_plan(B, ctx, steps, max_pages, V, page_base=0):
+    pages_per_seq = (ctx + steps + PAGE_SIZE - 1) // PAGE_SIZE + 1
+    bt = np.zeros((B, pages_per_seq), dtype=np.int32)
+    for b in range(B):
+        bt[b] = page_base + b * pages_per_seq + np.arange(pages_per_seq)
+    pos = np.full(B, ctx - 1, dtype=np.int32)
+    slots = (bt[np.arange(B), pos // PAGE_SIZE].astype(np.int64) * PAGE_SIZE + pos % PAGE_SIZE)
+    return dict(req_ids=list(range(B)), n_steps=steps, input_ids=np.random.randint(2, V, B).astype(np.int32),
+                positions=pos, context_lens=np.full(B, ctx, dtype=np.int32), slot_mapping=slots, block_tables=bt,
+                max_pages=pages_per_seq, temperature=np.ones(B, dtype=np.float32), top_p=np.ones(B, dtype=np.float32),
+                top_k=np.full(B, 1 << 30, dtype=np.int64))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="qwen2-1.5b")
+    ap.add_argument("--batch", default="128,256,384")
+    ap.add_argument("--ctx", type=int, default=640)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    cfg = preset(args.model)
+    model = Transformer(cfg, dtype=torch.bfloat16, device=dev)
+    model.requires_grad_(False)
+    model.eval()
+    model.flatten()
+    model.init_weights(seed=1)
+    batches = [int(b) for b in args.batch.split(",")]
+    maxb = max(batches)
+    pages_per_seq = (args.ctx + args.steps + PAGE_SIZE - 1) // PAGE_SIZE + 1
+    runner = ModelRunner(model, maxb * pages_per_seq + 8, args.ctx + 64, maxb, decode_steps=args.steps,
+                         use_graph=not args.no_graph, buckets=batches)
+    for kc, vc in runner.kv:  # non-trivial cache contents (softmax over zeros is cheaper than real data)
+        kc.normal_(0, 0.5)
+        vc.normal_(0, 0.5)
+    for B in batches:
+        plan = make_plan(B, args.ctx, args.steps, runner.max_pages, cfg.vocab_size)
+        runner.decode(plan)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            runner.decode(plan)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / (args.iters * args.steps)
+        print(f"B={B:4d} ctx={args.ctx}: {dt * 1e3:7.3f} ms/step  {B / dt:9.0f} tok/s  "
+              f"({dt * 1e6 / cfg.n_layers:6.1f} us/layer incl. head+sampler)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
