@@ -1,0 +1,256 @@
+"""Parameter re-allocation between two parallel layouts of the same model.
+
+A model trained as (dp, tp, pp) can hand its weights to a copy laid out as (dp', tp', pp') - e.g. a
+tensor-parallel trainer feeding data-parallel generation replicas - without going through a full
+checkpoint: every destination shard pulls exactly the slices it needs from the source shards that own
+them. Capability of ``realhf/impl/model/comm/param_realloc.py:73-563`` +
+``realhf/impl/model/nn/real_llm_api.py:569-807`` (interval-based resharding with chunked broadcasts).
+
+How it works here:
+
+* Every shard's flat parameter buffer is described by *pieces* ``(local_offset, full_offset, length)``:
+  a contiguous run of the local buffer that is a contiguous run of the full (unsharded) parameter.
+  Row-partitioned weights (fused qkv, gate|up) contribute one piece per section, column-partitioned
+  weights (o, down) one piece per row, replicated weights a single piece. The layout of ANY shard can be
+  computed by any process from the model config alone (the module is built on the meta device).
+* Intersecting destination pieces with the (de-duplicated) source pieces of a parameter gives transfer
+  segments. Segments of one (source shard, destination shard) pair are packed with the interval-gather
+  kernel, moved with ONE point-to-point message and unpacked with the interval-scatter kernel
+  (``ops.slice_intervals`` / ``ops.set_intervals``, the HIP counterparts of ``csrc/interval_op``).
+* All pairs are posted as one batch of sends / receives: on an xGMI node every pair has its own link, so
+  destination replica d pulls from source replica ``d % dp_src`` and all links carry traffic at once
+  (the reference funnels through per-pair broadcast groups, one sender per node).
+"""
+import dataclasses
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..models.config import ModelConfig
+from ..models.transformer import Transformer
+from .pipeline import stage_layer_range
+
+
+@dataclasses.dataclass(frozen=True)
+class Layout:
+    dp: int = 1
+    tp: int = 1
+    pp: int = 1
+
+    @property
+    def world(self) -> int:
+        return self.dp * self.tp * self.pp
+
+    def index_of(self, pp: int, dp: int, tp: int) -> int:
+        """Position in the model's rank list (same order as `ProcessGrid` with cp = 1)."""
+        return (pp * self.dp + dp) * self.tp + tp
+
+
+def _meta_shard(cfg: ModelConfig, lay: Layout, tp_rank: int, pp_rank: int, dtype=torch.bfloat16) -> Transformer:
+    lr = stage_layer_range(cfg.n_layers, lay.pp, pp_rank)
+    m = Transformer(cfg, dtype=dtype, device="meta", tp_size=lay.tp, tp_rank=tp_rank, layer_range=lr,
+                    has_embed=pp_rank == 0, has_head=pp_rank == lay.pp - 1)
+    m.flatten()
+    return m
+
+
+def shard_pieces(model: Transformer) -> Dict[str, np.ndarray]:
+    """Global parameter name -> int64 array [n, 3] of (local_offset, full_offset, length) pieces."""
+    cfg = model.cfg
+    tp, tr = model.tp_size, model.tp_rank
+    D, H = cfg.head_dim, cfg.hidden_size
+    out: Dict[str, np.ndarray] = {}
+    lo_layer, _ = model.layer_range
+
+    def rows(off, row_lo, n_rows, width):  # a block of whole rows is contiguous in both spaces
+        return [(off, row_lo * width, n_rows * width)]
+
+    def cols(off, n_rows, local_w, full_w, col_lo):  # one piece per row
+        r = np.arange(n_rows, dtype=np.int64)
+        return np.stack([off + r * local_w, r * full_w + col_lo, np.full(n_rows, local_w, dtype=np.int64)], 1)
+
+    for n, (off, numel) in model.flat.offsets.items():
+        parts = n.split(".")
+        leaf = parts[-1]
+        if parts[0] == "layers":
+            li = int(parts[1])
+            blk = model.layers[li]
+            gname = ".".join(["layers", str(lo_layer + li)] + parts[2:])
+        else:
+            blk, gname = None, n
+        if leaf in ("qkv", "qkv_bias"):
+            hq, hkv = blk.attn.hq, blk.attn.hkv
+            w = H if leaf == "qkv" else 1
+            q_lo = tr * hq
+            kv_lo = tr * hkv if cfg.n_kv_heads >= tp else tr // (tp // cfg.n_kv_heads)
+            Q, KV = cfg.n_q_heads, cfg.n_kv_heads
+            p = rows(off, q_lo * D, hq * D, w)
+            p += rows(off + hq * D * w, Q * D + kv_lo * D, hkv * D, w)
+            p += rows(off + (hq + hkv) * D * w, (Q + KV) * D + kv_lo * D, hkv * D, w)
+            out[gname] = np.asarray(p, dtype=np.int64)
+        elif leaf == "o":
+            lw = blk.attn.hq * D
+            out[gname] = cols(off, H, lw, cfg.n_q_heads * D, tr * lw)
+        elif leaf == "gate_up" and cfg.n_experts == 0:
+            f, F_ = blk.mlp.gate_up.shape[0] // 2, cfg.intermediate_size
+            out[gname] = np.asarray(rows(off, tr * f, f, H) + rows(off + f * H, F_ + tr * f, f, H), dtype=np.int64)
+        elif leaf == "down" and cfg.n_experts == 0:
+            f = blk.mlp.down.shape[1]
+            out[gname] = cols(off, H, f, cfg.intermediate_size, tr * f)
+        elif leaf == "gate_up":  # routed experts [E_local, 2f, H]; experts are not split over pipeline / tp here
+            E, two_f, _ = blk.mlp.gate_up.shape
+            f, F_ = two_f // 2, cfg.moe_intermediate_size
+            e0 = blk.mlp.ep_rank * blk.mlp.n_local
+            p = []
+            for e in range(E):
+                base_l, base_f = off + e * two_f * H, (e0 + e) * 2 * F_ * H
+                p += [(base_l, base_f + tr * f * H, f * H), (base_l + f * H, base_f + (F_ + tr * f) * H, f * H)]
+            out[gname] = np.asarray(p, dtype=np.int64)
+        elif leaf == "down":
+            E, _, f = blk.mlp.down.shape
+            F_ = cfg.moe_intermediate_size
+            e0 = blk.mlp.ep_rank * blk.mlp.n_local
+            out[gname] = np.concatenate([cols(off + e * H * f, H, f, F_, tr * f) + np.array([0, (e0 + e) * H * F_, 0])
+                                         for e in range(E)])
+        else:  # replicated over tp: norms, embeddings, value / LM head, router
+            out[gname] = np.asarray([(off, 0, numel)], dtype=np.int64)
+    return out
+
+
+@dataclasses.dataclass
+class Transfer:
+    src: int  # index into the source model's rank list
+    dst: int  # index into the destination model's rank list
+    src_intervals: np.ndarray  # [n, 2] half-open ranges of the source shard's flat buffer
+    dst_intervals: np.ndarray  # [n, 2] matching ranges of the destination shard's flat buffer
+
+    @property
+    def numel(self) -> int:
+        return int((self.src_intervals[:, 1] - self.src_intervals[:, 0]).sum())
+
+
+def _intersect(src_pieces: np.ndarray, src_owner: np.ndarray, dst_pieces: np.ndarray):
+    """Overlaps of destination pieces with a sorted, non-overlapping list of source pieces.
+    -> (owner, src_local_off, dst_local_off, length) arrays."""
+    s_start, s_end = src_pieces[:, 1], src_pieces[:, 1] + src_pieces[:, 2]
+    d_start, d_end = dst_pieces[:, 1], dst_pieces[:, 1] + dst_pieces[:, 2]
+    lo = np.searchsorted(s_end, d_start, side="right")
+    hi = np.searchsorted(s_start, d_end, side="left")
+    cnt = np.maximum(hi - lo, 0)
+    di = np.repeat(np.arange(len(dst_pieces)), cnt)
+    si = np.concatenate([np.arange(a, b) for a, b in zip(lo, hi)]) if cnt.sum() else np.zeros(0, dtype=np.int64)
+    ov_s = np.maximum(s_start[si], d_start[di])
+    ov_e = np.minimum(s_end[si], d_end[di])
+    keep = ov_e > ov_s
+    si, di, ov_s, ov_e = si[keep], di[keep], ov_s[keep], ov_e[keep]
+    covered = np.zeros(len(dst_pieces), dtype=np.int64)
+    np.add.at(covered, di, ov_e - ov_s)
+    if not np.array_equal(covered, dst_pieces[:, 2]):
+        raise RuntimeError("source shards do not cover a destination parameter slice")
+    return (src_owner[si], src_pieces[si, 0] + (ov_s - s_start[si]), dst_pieces[di, 0] + (ov_s - d_start[di]),
+            ov_e - ov_s)
+
+
+def derive_realloc_plan(cfg: ModelConfig, src: Layout, dst: Layout, dtype=torch.bfloat16) -> List[Transfer]:
+    """All transfers that turn the source layout's weights into the destination layout's, in a fixed order
+    every process agrees on. Destination replica d pulls from source replica d % dp_src."""
+    assert cfg.n_experts == 0 or (src.pp == dst.pp == 1), "expert weights are re-allocated within one stage only"
+    src_shards = {(p, t): shard_pieces(_meta_shard(cfg, src, t, p, dtype)) for p in range(src.pp) for t in range(src.tp)}
+    tied = cfg.tie_word_embeddings and not cfg.is_critic
+    plan: List[Transfer] = []
+    for dpp in range(dst.pp):
+        for dtp in range(dst.tp):
+            need = shard_pieces(_meta_shard(cfg, dst, dtp, dpp, dtype))
+            # per source shard (pp, tp): segments for this destination shard
+            seg: Dict[Tuple[int, int], List[np.ndarray]] = {}
+            for gname, dpieces in need.items():
+                cands = [(p, t) for (p, t), d in src_shards.items() if gname in d]
+                lookup = gname
+                if not cands and gname == "head" and tied:  # tied LM head: the embedding is the source
+                    lookup = "embed"
+                    cands = [(p, t) for (p, t), d in src_shards.items() if lookup in d]
+                if not cands:
+                    raise RuntimeError(f"parameter {gname} does not exist in the source layout")
+                # replicated pieces: prefer the source tp rank aligned with this destination rank
+                start = (dtp * src.tp) // dst.tp
+                cands.sort(key=lambda pt: (pt[0], (pt[1] - start) % src.tp))
+                seen, rows_, owner = set(), [], []
+                for ci, (p, t) in enumerate(cands):
+                    for pc in src_shards[(p, t)][lookup]:
+                        key = (int(pc[1]), int(pc[2]))
+                        if key in seen:
+                            continue
+                        seen.add(key)
+                        rows_.append(pc)
+                        owner.append(ci)
+                sp = np.asarray(rows_, dtype=np.int64)
+                ow = np.asarray(owner, dtype=np.int64)
+                order = np.argsort(sp[:, 1], kind="stable")
+                sp, ow = sp[order], ow[order]
+                o, so, do, ln = _intersect(sp, ow, dpieces[np.argsort(dpieces[:, 1], kind="stable")])
+                for ci in np.unique(o):
+                    m = o == ci
+                    seg.setdefault(cands[int(ci)], []).append(np.stack([so[m], do[m], ln[m]], 1))
+            for (p, t), chunks in sorted(seg.items()):
+                a = np.concatenate(chunks)
+                a = a[np.argsort(a[:, 1], kind="stable")]
+                for ddp in range(dst.dp):
+                    sdp = ddp % src.dp
+                    plan.append(Transfer(src=src.index_of(p, sdp, t), dst=dst.index_of(dpp, ddp, dtp),
+                                         src_intervals=np.stack([a[:, 0], a[:, 0] + a[:, 2]], 1),
+                                         dst_intervals=np.stack([a[:, 1], a[:, 1] + a[:, 2]], 1)))
+    plan.sort(key=lambda x: (x.dst, x.src))
+    return plan
+
+
+def _merged(iv_src: np.ndarray, iv_dst: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Fuse neighbouring segments that are contiguous on both sides (fewer, longer copies)."""
+    if len(iv_src) <= 1:
+        return iv_src, iv_dst
+    brk = (iv_src[1:, 0] != iv_src[:-1, 1]) | (iv_dst[1:, 0] != iv_dst[:-1, 1])
+    starts = np.concatenate([[0], np.nonzero(brk)[0] + 1])
+    ends = np.concatenate([starts[1:], [len(iv_src)]]) - 1
+    return (np.stack([iv_src[starts, 0], iv_src[ends, 1]], 1), np.stack([iv_dst[starts, 0], iv_dst[ends, 1]], 1))
+
+
+@torch.no_grad()
+def realloc_parameters(plan: Sequence[Transfer], src_ranks: Sequence[int], dst_ranks: Sequence[int],
+                       src_flat: Optional[torch.Tensor], dst_flat: Optional[torch.Tensor], group=None,
+                       eta: float = 1.0) -> int:
+    """Execute this process's part of `plan`. `src_ranks` / `dst_ranks`: global ranks of the two models in
+    layout order; `src_flat` / `dst_flat`: this process's flat buffers of the source / destination model
+    (None when it hosts no shard of that model). ``eta < 1`` mixes instead of overwriting:
+    ``dst = eta * src + (1 - eta) * dst`` (exponential moving average targets). Returns elements received."""
+    me = dist.get_rank() if dist.is_initialized() else 0
+    p2p, recvs, keep = [], [], []
+    n_recv = 0
+    for tag, t in enumerate(plan):
+        s_rank, d_rank = src_ranks[t.src], dst_ranks[t.dst]
+        if me != s_rank and me != d_rank:
+            continue
+        siv, div = _merged(t.src_intervals, t.dst_intervals)
+        if me == s_rank and me == d_rank:
+            packed = ops.slice_intervals(src_flat, siv)
+            recvs.append((packed, div))
+        elif me == s_rank:
+            packed = ops.slice_intervals(src_flat, siv)
+            keep.append(packed)
+            p2p.append(dist.P2POp(dist.isend, packed, d_rank, group=group, tag=tag))
+        else:
+            buf = torch.empty(t.numel, dtype=dst_flat.dtype, device=dst_flat.device)
+            p2p.append(dist.P2POp(dist.irecv, buf, s_rank, group=group, tag=tag))
+            recvs.append((buf, div))
+    if p2p:
+        for w in dist.batch_isend_irecv(p2p):
+            w.wait()
+    for buf, div in recvs:
+        buf = buf.to(dst_flat.dtype)
+        if eta != 1.0:
+            cur = ops.slice_intervals(dst_flat, div)
+            buf = (eta * buf.float() + (1.0 - eta) * cur.float()).to(dst_flat.dtype)
+        ops.set_intervals(buf, dst_flat, div)
+        n_recv += buf.numel()
+    return n_recv
