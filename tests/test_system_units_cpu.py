@@ -1,0 +1,402 @@
+"""Unit tests of the worker runtime's building blocks: samples, data-flow graph, buffer, streams, worker
+control, the generation-server manager against mock servers (staleness, routing, weight roll-out), chunked
+generation and the agents. Patterns of the reference's ``realhf/tests/{data,system,agent}``."""
+import asyncio
+import dataclasses
+import json
+import os
+import threading
+import time
+
+import pytest
+import torch
+from aiohttp import web
+
+from areal_vllm_amd.api.cli_args import GenerationHyperparameters, MicroBatchSpec
+from areal_vllm_amd.utils import name_resolve, names
+
+
+@pytest.fixture(autouse=True)
+def _memory_name_resolve():
+    cfg = type("C", (), dict(type="memory"))()
+    name_resolve.reconfigure(cfg)
+    yield
+    name_resolve.reconfigure(type("C", (), dict(type="nfs", nfs_record_root="/tmp/areal/name_resolve"))())
+
+
+# ------------------------------------------------------------------------------- samples
+def _sample(ids, lens, group=1):
+    from areal_vllm_amd.system.data_api import SequenceSample
+
+    tot = sum(lens)
+    return SequenceSample.from_default(ids=ids, seqlens=lens, data=dict(
+        packed_input_ids=torch.arange(tot), packed_logprobs=torch.arange(tot - len(lens)).float(),
+        rewards=torch.arange(len(lens)).float()))
+
+
+def test_sequence_sample_gather_split_json():
+    from areal_vllm_amd.system.data_api import SequenceSample, SequenceSplitSpec
+
+    s = _sample(["a", "b", "c", "d"], [3, 5, 2, 4])
+    assert s.seqlens["packed_logprobs"] == [[2], [4], [1], [3]] and s.seqlens["rewards"] == [[1]] * 4
+    parts = s.split_with_spec(SequenceSplitSpec(sizes=[1, 3]))
+    assert parts[1].ids == ["b", "c", "d"] and parts[1].data["packed_input_ids"].tolist() == list(range(3, 14))
+    back = SequenceSample.gather(parts)
+    assert back.ids == s.ids and torch.equal(back.data["packed_logprobs"], s.data["packed_logprobs"])
+    mbs, fwd, bwd = s.split(MicroBatchSpec(max_tokens_per_mb=8))
+    assert all(sum(m._item_tokens("packed_input_ids")) <= 8 for m in mbs)
+    re = SequenceSample.gather(mbs).reorder(bwd)
+    assert re.ids == s.ids
+    js = json.loads(json.dumps(s.as_json_compatible()))
+    s2 = SequenceSample.from_json_compatible(js)
+    assert s2.ids == s.ids and torch.equal(s2.data["packed_input_ids"], s.data["packed_input_ids"])
+    assert s2.data["packed_input_ids"].dtype == torch.int64
+    s.remap_keys_({"rewards": "scores"})
+    assert "scores" in s.keys and "rewards" not in s.keys
+    meta = s.meta()
+    assert meta.data is None and meta.seqlens["scores"] == [[1]] * 4
+    with pytest.raises(AssertionError):
+        SequenceSample(keys={"x"}, ids=["a", "a"], seqlens=dict(x=[[1], [1]]))
+
+
+def test_dfg_edges_and_buffer_readiness():
+    from areal_vllm_amd.system.buffer import AsyncIOSequenceBuffer
+    from areal_vllm_amd.system.dfg import MFCDef, ModelInterfaceAbstraction, ModelInterfaceType, build_graph, \
+        topological_levels
+
+    itf = ModelInterfaceAbstraction("null")
+    gen = MFCDef("gen", 2, ModelInterfaceType.GENERATE, itf, "actor", input_keys=("packed_prompts",),
+                 output_keys=("packed_input_ids",))
+    rew = MFCDef("rew", 2, ModelInterfaceType.INFERENCE, itf, "reward", input_keys=("packed_input_ids",),
+                 output_keys=("rewards",))
+    ref = MFCDef("ref", 2, ModelInterfaceType.INFERENCE, itf, "ref", input_keys=("packed_input_ids",),
+                 output_keys=("ref_logp",))
+    trn = MFCDef("train", 2, ModelInterfaceType.TRAIN_STEP, itf, "actor",
+                 input_keys=("packed_input_ids", "rewards", "ref_logp"))
+    G = build_graph([gen, rew, ref, trn])
+    assert topological_levels(G) == [["gen"], ["ref", "rew"], ["train"]]
+    assert gen.is_src and trn.is_dst and not gen.is_dst_of_model_role("actor") and trn.is_dst_of_model_role("actor")
+    assert G.graph["dataset_keys"] == ["packed_prompts"]
+    with pytest.raises(AssertionError):
+        build_graph([gen, MFCDef("gen2", 2, ModelInterfaceType.GENERATE, itf, "actor", output_keys=("packed_input_ids",))])
+
+    async def run():
+        from areal_vllm_amd.system.data_api import SequenceSample
+
+        buf = AsyncIOSequenceBuffer([gen, rew, ref, trn], max_size=8)
+        items = [SequenceSample(keys={"packed_prompts"}, ids=[f"q{i}"], seqlens=dict(packed_prompts=[[3]]))
+                 for i in range(3)]
+        await buf.put_batch(items)
+        assert buf.n_ready("gen") == 3 and buf.n_ready("train") == 0
+        ids, s = await buf.get_batch_for_rpc(gen)
+        assert ids == ["q0", "q1"]  # oldest first
+        with pytest.raises(asyncio.TimeoutError):
+            await buf.get_batch_for_rpc(rew, timeout=0.05)
+        await buf.amend_batch(ids, [SequenceSample(keys={"packed_input_ids"}, ids=[i],
+                                                   seqlens=dict(packed_input_ids=[[7]])) for i in ids])
+        ids2, s2 = await buf.get_batch_for_rpc(rew)
+        assert ids2 == ids and s2.keys == {"packed_input_ids"}
+        await buf.get_batch_for_rpc(ref)
+        await buf.amend_batch(ids, [SequenceSample(keys={"rewards", "ref_logp"}, ids=[i],
+                                                   seqlens=dict(rewards=[[1]], ref_logp=[[6]])) for i in ids])
+        await buf.get_batch_for_rpc(trn)
+        assert buf.size == 1  # consumed by every call -> gone; q2 still waits for generation
+
+    asyncio.run(run())
+
+
+# ------------------------------------------------------------------------------- streams
+def test_push_pull_grouping_and_request_reply_handshake():
+    from areal_vllm_amd.system.streams import (NameResolvingPuller, NameResolvingPusher, NameResolvingReplyServer,
+                                               NameResolvingRequestClient, NoMessage, Payload, grouping)
+
+    assert grouping(5, 2) == {0: [0, 1, 2], 1: [3, 4]}
+    pullers = [NameResolvingPuller("e", "t", i) for i in range(2)]
+    pushers = [NameResolvingPusher("e", "t", i, 5) for i in range(5)]
+    for i, p in enumerate(pushers):
+        p.push(dict(who=i))
+    got0 = sorted(pullers[0].pull(2000)["who"] for _ in range(3))
+    got1 = sorted(pullers[1].pull(2000)["who"] for _ in range(2))
+    assert got0 == [0, 1, 2] and got1 == [3, 4]
+    [p.close() for p in pushers + pullers]
+
+    servers = [NameResolvingReplyServer("e", "t", "master", handler=i) for i in range(2)]
+    stop = threading.Event()
+
+    def serve(s):
+        while not stop.is_set():
+            try:
+                p = s.poll(block=True, timeout=0.05)
+            except NoMessage:
+                continue
+            s.post(Payload(handler="master", handle_name=p.handle_name, request_id=p.request_id,
+                           data=(s.handler, p.data, p.pre_hooks)))
+
+    ts = [threading.Thread(target=serve, args=(s,), daemon=True) for s in servers]
+    [t.start() for t in ts]
+    client = NameResolvingRequestClient("e", "t", "master", [0, 1])
+    assert client.call([0, 1], "echo", ["x", "y"]) == [(0, "x", []), (1, "y", [])]
+    ids = client.request([0, 1], "echo", [1, 2], no_syn=False, pre_hooks=["data_transfer"])  # syn/ack round
+    assert client.gather(ids) == [(0, 1, ["data_transfer"]), (1, 2, ["data_transfer"])]
+    stop.set()
+    [t.join(2) for t in ts]
+    client.close()
+    [s.close() for s in servers]
+
+
+def test_worker_control_lifecycle():
+    from areal_vllm_amd.system.worker_base import (PollResult, Worker, WorkerControlPanel, WorkerInformation,
+                                                   WorkerServer, WorkerServerStatus)
+
+    class Counter(Worker):
+        def _configure(self, config):
+            self.n = 0
+            self.step = config["step"]
+
+        def _poll(self):
+            self.n += self.step
+            if self.n >= 5 * self.step:
+                self.exit()
+            return PollResult(1, 1)
+
+    server = WorkerServer("e", "t", "toy/0")
+    w = Counter(server)
+    th = threading.Thread(target=w.run, daemon=True)
+    th.start()
+    panel = WorkerControlPanel("e", "t")
+    panel.connect(["toy/0"])
+    assert panel.request("toy/0", "ping") == "pong"
+    assert panel.get_worker_status("toy/0") == WorkerServerStatus.READY
+    panel.request("toy/0", "configure", worker_info=WorkerInformation("e", "t", "toy", 0, 1), config=dict(step=3))
+    panel.group_request("start")
+    th.join(10)
+    assert not th.is_alive() and w.n == 15
+    assert panel.get_worker_status("toy/0") == WorkerServerStatus.COMPLETED
+    from areal_vllm_amd.system.worker_base import WorkerException
+
+    with pytest.raises(WorkerException):
+        panel2 = WorkerControlPanel("e", "t")
+        server2 = WorkerServer("e", "t", "toy/1")
+        t2 = threading.Thread(target=Counter(server2).run, daemon=True)
+        t2.start()
+        panel2.connect(["toy/1"])
+        try:
+            panel2.request("toy/1", "no_such_command")
+        finally:
+            panel2.request("toy/1", "exit")
+            t2.join(5)
+    panel.close()
+    server.close()
+
+
+# ------------------------------------------------------- generation-server manager + mocks
+class MockServer:
+    """Speaks the rollout server's control verbs and a deterministic /generate."""
+
+    def __init__(self):
+        self.version = 0
+        self.n_generate = 0
+        self.events = []
+        self.used_tokens = 0.0
+        self.loop = asyncio.new_event_loop()
+        self.started = threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+        self.started.wait(10)
+
+    def _run(self):
+        asyncio.set_event_loop(self.loop)
+        app = web.Application()
+
+        async def ok(name):
+            self.events.append(name)
+            return web.json_response(dict(success=True))
+
+        async def upd(req):
+            body = await req.json()
+            self.version = int(body["version"])
+            self.events.append(("update", body["model_path"]))
+            return web.json_response(dict(success=True))
+
+        async def gen(req):
+            body = await req.json()
+            self.n_generate += 1
+            n = int(body["sampling_params"]["max_new_tokens"])
+            base = len(body["input_ids"])
+            toks = [100 + base + i for i in range(n)]
+            stop = base + n >= 14  # "EOS" once the sequence is 14 tokens long
+            return web.json_response(dict(output_ids=toks, meta_info=dict(
+                finish_reason=dict(type="stop" if stop else "length"),
+                output_token_logprobs=[(-0.5, t, None) for t in toks], weight_version=self.version)))
+
+        async def metrics(req):
+            return web.Response(text=f"# TYPE x gauge\nsglang:num_used_tokens{{model_name=\"m\"}} {self.used_tokens}\n")
+
+        app.router.add_post("/pause_generation", lambda r: ok("pause"))
+        app.router.add_post("/continue_generation", lambda r: ok("continue"))
+        app.router.add_post("/update_weights_from_disk", upd)
+        app.router.add_post("/generate", gen)
+        app.router.add_get("/metrics", metrics)
+        runner = web.AppRunner(app)
+        self.loop.run_until_complete(runner.setup())
+        from areal_vllm_amd.utils.network import find_free_ports
+
+        self.port = find_free_ports(1)[0]
+        self.loop.run_until_complete(web.TCPSite(runner, "127.0.0.1", self.port).start())
+        self.started.set()
+        self.loop.run_forever()
+
+    @property
+    def addr(self):
+        return f"127.0.0.1:{self.port}"
+
+    def close(self):
+        self.loop.call_soon_threadsafe(self.loop.stop)
+        self.thread.join(3)
+
+
+def _manager(tmp_path, n_servers=2, **kw):
+    from areal_vllm_amd.system.gserver_manager import GserverManager, GserverManagerConfig
+    from areal_vllm_amd.system.worker_base import ExpStatus, WorkerInformation
+
+    servers = [MockServer() for _ in range(n_servers)]
+    for s in servers:
+        name_resolve.add_subentry(names.gen_servers("e", "t"), s.addr)
+    name_resolve.add(names.experiment_status("e", "t"), ExpStatus.RUNNING.value, replace=True)
+    cfg = GserverManagerConfig(model_name="actor", n_servers=n_servers, realloc_root=str(tmp_path), poll_interval=0.0,
+                               **kw)
+    m = GserverManager()
+    m.configure(WorkerInformation("e", "t", "gserver_manager", 0, 1), cfg)
+    m._poll()
+    return m, servers
+
+
+def _post(addr, route, payload):
+    import requests
+
+    r = requests.post(f"http://{addr}{route}", json=payload, timeout=10)
+    r.raise_for_status()
+    return r.json()
+
+
+def test_gserver_manager_routing_staleness_and_weight_rollout(tmp_path):
+    bs, eta = 4, 1
+    m, servers = _manager(tmp_path, schedule_policy="round_robin", train_batch_size=bs, max_head_offpolicyness=eta,
+                          max_concurrent_rollouts=100)
+    try:
+        a = m.manager_addr
+        meta = dict(qid="q0", prompt_len=5, group_size=2, new_token_budget=8, previous_server_url="",
+                    previous_version=-1)
+        u0 = _post(a, "/schedule_request", meta)
+        u1 = _post(a, "/schedule_request", dict(meta, qid="q1"))
+        assert {u0["url"], u1["url"]} == {f"http://{s.addr}" for s in servers} and u0["version"] == 0
+        # sticky while the version is unchanged
+        again = _post(a, "/schedule_request", dict(meta, previous_server_url=u0["url"], previous_version=0))
+        assert again["url"] == u0["url"]
+        # staleness gate: with nothing trained, exactly (1 + eta) * bs rollouts may start
+        granted = [_post(a, "/allocate_rollout", dict(qid=f"r{i}"))["success"] for i in range(3 * bs)]
+        assert sum(granted) == (1 + eta) * bs and not granted[-1]
+        for i in range(sum(granted)):
+            _post(a, "/finish_rollout", dict(qid=f"r{i}", accepted=True, n_tokens=10))
+        assert not _post(a, "/allocate_rollout", dict(qid="x"))["success"]  # finished samples still count
+        # the trainer consumes a batch and publishes version 1: servers are paused, updated, resumed
+        name_resolve.add(names.training_samples("e", "t"), str(bs), replace=True)
+        name_resolve.add(names.model_version("e", "t", "actor"), "1", replace=True)
+        os.makedirs(os.path.join(str(tmp_path), "actor", "1"))
+        m._poll()
+        for s in servers:
+            assert s.version == 1 and s.events[:1] == ["pause"] and s.events[-1] == "continue"
+            assert s.events[1] == ("update", os.path.join(str(tmp_path), "actor", "1"))
+        assert _post(a, "/get_model_version", {})["version"] == 1
+        more = [_post(a, "/allocate_rollout", dict(qid=f"s{i}"))["success"] for i in range(2 * bs)]
+        assert sum(more) == bs  # one more batch per version
+        moved = _post(a, "/schedule_request", dict(meta, previous_server_url=u0["url"], previous_version=0))
+        assert moved["version"] == 1  # new weights: the sticky route is dropped
+        # capacity gate
+        m.config.max_concurrent_rollouts = m.rollout_stat.running
+        res = _post(a, "/allocate_rollout", dict(qid="cap"))
+        assert not res["success"] and "capacity" in res["reason"]
+    finally:
+        m._exit_hook(None)
+        [s.close() for s in servers]
+
+
+def test_gserver_manager_least_token_usage_and_gc(tmp_path):
+    m, servers = _manager(tmp_path, schedule_policy="least_token_usage", train_batch_size=100)
+    try:
+        servers[0].used_tokens, servers[1].used_tokens = 5000.0, 10.0
+        m._poll()
+        meta = dict(qid="q0", prompt_len=5, group_size=1, new_token_budget=8, previous_server_url="", previous_version=-1)
+        assert _post(m.manager_addr, "/schedule_request", meta)["url"] == f"http://{servers[1].addr}"
+        for v in (1, 2, 3):
+            os.makedirs(os.path.join(str(tmp_path), "actor", str(v)))
+            name_resolve.add(names.model_version("e", "t", "actor"), str(v), replace=True)
+            m._poll()
+        assert sorted(os.listdir(os.path.join(str(tmp_path), "actor"))) == ["2", "3"]  # current + previous kept
+    finally:
+        m._exit_hook(None)
+        [s.close() for s in servers]
+
+
+def test_partial_rollout_chunks_and_agents(tmp_path):
+    from areal_vllm_amd.impl.agent.math_single_step_agent import MathSingleStepAgent
+    from areal_vllm_amd.impl.environment.toy_env import TokenParityEnv
+    from areal_vllm_amd.system.data_api import SequenceSample
+    from areal_vllm_amd.system.partial_rollout import PartialRolloutManager
+
+    m, servers = _manager(tmp_path, n_servers=1, train_batch_size=100)
+
+    async def run():
+        req, rep = asyncio.Queue(), asyncio.Queue()
+        prm = PartialRolloutManager(0, req, rep, new_tokens_per_chunk=3, stop_token_ids=[1], timeout=30,
+                                    experiment_name="e", trial_name="t", gserver_manager_addr=m.manager_addr)
+        g = GenerationHyperparameters(n_samples=2, max_new_tokens=8)
+        agent = MathSingleStepAgent(g, answer_save_path=str(tmp_path / "ans"), reward_scaling=2.0)
+        prompt = SequenceSample(keys={"packed_prompts"}, ids=["q7"], seqlens=dict(packed_prompts=[[5]]),
+                                data=dict(packed_prompts=torch.tensor([11, 12, 13, 14, 15])))
+        act = asyncio.Queue()
+        task = asyncio.create_task(agent.collect_trajectory(prompt, TokenParityEnv(), req, act))
+        while not task.done():
+            await prm.run_step()
+            while not rep.empty():
+                act.put_nowait(rep.get_nowait())
+        await prm.close()
+        return task.result()
+
+    try:
+        (traj,) = asyncio.run(run())
+        # 8 new tokens in chunks of 3 -> 3 calls per answer, 2 answers
+        assert servers[0].n_generate == 6
+        assert traj.seqlens["packed_input_ids"] == [[13, 13]] and traj.seqlens["packed_logprobs"] == [[12, 12]]
+        assert traj.data["seq_no_eos_mask"].tolist() == [True, True]  # budget exhausted before the mock's EOS
+        assert traj.data["prompt_mask"].view(2, 13)[:, :5].all() and not traj.data["prompt_mask"].view(2, 13)[:, 5:].any()
+        lp = traj.data["packed_logprobs"].view(2, 12)
+        assert (lp[:, :4] == 0).all() and (lp[:, 4:] == -0.5).all()
+        assert set(traj.data["rewards"].tolist()) <= {-2.0, 2.0}
+        assert traj.data["version_start"].tolist() == [0, 0]
+        assert os.listdir(tmp_path / "ans" / "0") == ["q7.txt", "q7.jsonl"] or len(os.listdir(tmp_path / "ans" / "0")) == 2
+    finally:
+        m._exit_hook(None)
+        [s.close() for s in servers]
+
+
+def test_multi_task_reward_interface_and_function_call_client():
+    from areal_vllm_amd.impl.interface.math_rw_interface import MultiTaskRewardInterface
+    from areal_vllm_amd.system.dfg import ModelName
+    from areal_vllm_amd.system.model_api import Model
+
+    id2info = {"q1": dict(query_id="q1", task="math", solutions=["\\boxed{42}"])}
+
+    class Tok:
+        def decode(self, ids, **kw):
+            return "so the answer is \\boxed{42}" if 9 in ids else "no idea"
+
+    itf = MultiTaskRewardInterface(id2info=id2info, output_scaling=5.0)
+    from areal_vllm_amd.system.data_api import SequenceSample
+
+    x = SequenceSample(keys={"packed_input_ids", "prompt_mask"}, ids=["q1"],
+                       seqlens=dict(packed_input_ids=[[4, 3]], prompt_mask=[[4, 3]]),
+                       data=dict(packed_input_ids=torch.tensor([5, 5, 9, 9, 5, 7, 7]),
+                                 prompt_mask=torch.tensor([1, 1, 0, 0, 1, 0, 0]).bool()))
+    out = itf.inference(Model(name=ModelName("reward"), module=None, tokenizer=Tok()), x, None)
+    assert out.data["rewards"].tolist() == [5.0, -5.0] and out.seqlens["rewards"] == [[1, 1]]
