@@ -400,3 +400,60 @@ def test_multi_task_reward_interface_and_function_call_client():
                                  prompt_mask=torch.tensor([1, 1, 0, 0, 1, 0, 0]).bool()))
     out = itf.inference(Model(name=ModelName("reward"), module=None, tokenizer=Tok()), x, None)
     assert out.data["rewards"].tolist() == [5.0, -5.0] and out.seqlens["rewards"] == [[1, 1]]
+
+
+def test_quickstart_builds_experiment_from_overrides(tmp_path):
+    from areal_vllm_amd.apps.quickstart import build_experiment
+
+    y = tmp_path / "exp.yaml"
+    y.write_text("layout: d2t2\nactor:\n  path: qwen2-1.5b\nppo:\n  kl_ctl: 0.05\n  gen:\n    max_new_tokens: 512\n"
+                 "train_bs_n_seqs: 64\nmode: slurm\n")
+    exp, launcher = build_experiment("async-ppo-math", str(y), ["group_size=8", "max_head_offpolicyness=4",
+                                                                "recover_mode=auto"])
+    assert exp.layout == "d2t2" and exp.actor.path == "qwen2-1.5b" and exp.ppo.gen.max_new_tokens == 512
+    assert exp.group_size == 8 and exp.max_head_offpolicyness == 4
+    assert launcher == dict(mode="slurm", recover_mode="auto", recover_retries=1, platform="")
+    cfg = exp.initial_setup().lazy_init()
+    assert len(cfg.model_worker) == 4 and cfg.gserver_manager[0].max_head_offpolicyness == 4
+    assert cfg.gserver_manager[0].train_batch_size == 64
+    with pytest.raises(KeyError):
+        build_experiment("async-ppo-math", None, ["no_such_field=1"])
+    with pytest.raises(KeyError):
+        build_experiment("no-such-experiment")
+
+
+def test_automatic_evaluator_orders_and_resumes(tmp_path):
+    import sys
+
+    from areal_vllm_amd.evaluation import pass_at_k
+    from areal_vllm_amd.evaluation.evaluator import AutomaticEvaluator, AutomaticEvaluatorConfig, EvaluationStepStatus
+
+    assert pass_at_k(8, 0, 4) == 0.0 and pass_at_k(8, 8, 1) == 1.0 and abs(pass_at_k(8, 2, 4) - 11 / 14) < 1e-9
+    ck, ev = tmp_path / "ckpt", tmp_path / "eval"
+    for g in (2, 4):
+        (ck / f"epoch1epochstep{g}globalstep{g}").mkdir(parents=True)
+    (ck / "recover_checkpoint").mkdir()
+    logged = []
+
+    def cmd(step):  # stand-in for the evaluation job: slow for step 2 so that step 4 finishes first
+        delay = 0.6 if step.global_step == 2 else 0.0
+        code = (f"import json,time; time.sleep({delay}); "
+                f"json.dump(dict(metrics={{'mean@1': {step.global_step} / 10}}), open(r'{step.output_path}', 'w'))")
+        return [sys.executable, "-c", code]
+
+    e = AutomaticEvaluator(AutomaticEvaluatorConfig(max_concurrent_jobs=2), str(ck), str(ev),
+                           log_fn=lambda m, g: logged.append((g, m)), cmd_builder=cmd)
+    deadline = time.time() + 30
+    while (e.pending() or not e.steps) and time.time() < deadline:
+        e.step()
+        time.sleep(0.05)
+    assert logged == [(2, {"eval/mean@1": 0.2}), (4, {"eval/mean@1": 0.4})]  # step order, despite finish order
+    assert sorted(e.steps) == [2, 4]  # the recover checkpoint is not a numbered checkpoint
+    (ck / "epoch2epochstep2globalstep6").mkdir()
+    e2 = AutomaticEvaluator(AutomaticEvaluatorConfig(), str(ck), str(ev), cmd_builder=cmd)
+    assert e2.steps[2].status == EvaluationStepStatus.LOGGED and e2.steps[4].status == EvaluationStepStatus.LOGGED
+    while (e2.pending() or 6 not in e2.steps) and time.time() < deadline:
+        e2.step()
+        time.sleep(0.05)
+    rows = [json.loads(l) for l in open(ev / "eval_results.jsonl")]
+    assert [r["global_step"] for r in rows] == [2, 4, 6]
