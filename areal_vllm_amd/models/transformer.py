@@ -134,7 +134,7 @@ class Attention(nn.Module):
         """Fused q|k|v projection, returned 2-D [T, (hq + 2 hkv) * D] (not a view, RoPE runs in place)."""
         T = x.shape[0]
         D = self.cfg.head_dim
-        qkv = F.linear(x, self.qkv, self.qkv_bias)
+        qkv = ops.linear(x, self.qkv, self.qkv_bias)
         if self.cfg.qk_norm:
             q3 = qkv.view(T, self.hq + 2 * self.hkv, D)
             q, _ = ops.rmsnorm(q3[:, :self.hq], self.q_norm, self.cfg.rms_norm_eps)
@@ -152,7 +152,7 @@ class Attention(nn.Module):
             attn = sp.attention(qkv, self.hq, self.hkv, cu_seqlens, max_seqlen)
         else:
             attn = ops.flash_attn_varlen_qkv(qkv, cu_seqlens, max_seqlen, self.hq, self.hkv)
-        out = F.linear(attn.reshape(T, -1), self.o)
+        out = ops.linear(attn.reshape(T, -1), self.o)
         return _AllReduceFwd.apply(out, tp_group)
 
 
@@ -166,8 +166,8 @@ class MLP(nn.Module):
 
     def forward(self, x, tp_group):
         x = _AllReduceBwd.apply(x, tp_group)
-        h = ops.swiglu(F.linear(x, self.gate_up))
-        return _AllReduceFwd.apply(F.linear(h, self.down), tp_group)
+        h = ops.swiglu(ops.linear(x, self.gate_up))
+        return _AllReduceFwd.apply(ops.linear(h, self.down), tp_group)
 
 
 class MoE(nn.Module):

@@ -1,0 +1,48 @@
+"""Linear layer whose weight gradient is accumulated by the GEMM itself into the fp32 main-grad buffer.
+
+``y = x @ W^T (+ b)``. In the backward pass ``dW`` is not materialised in bf16 and added afterwards:
+when the weight carries a ``main_grad`` view (see ``models/transformer.py::FlatParams.alloc_main_grad``)
+the weight-gradient GEMM runs with bf16 operands, fp32 output and beta = 1 directly on that view
+(hipBLASLt through ``torch.addmm(..., out_dtype=float32, out=main_grad)``), so micro-batch gradients are
+summed in fp32 without a rounding step and without a separate add kernel. This is the role of apex's
+``fused_weight_gradient_mlp_cuda.wgrad_gemm_accum_fp32`` in the reference
+(``realhf/impl/model/parallelism/tensor_parallel/modules.py:242-402``).
+"""
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def _accumulate_wgrad(weight: torch.Tensor, dy2: torch.Tensor, x2: torch.Tensor) -> None:
+    mg = weight.main_grad
+    if dy2.is_cuda and mg.dtype == torch.float32 and dy2.dtype in (torch.bfloat16, torch.float16):
+        torch.addmm(mg, dy2.t(), x2, out_dtype=torch.float32, out=mg)
+    else:
+        mg.add_(torch.mm(dy2.t(), x2))
+
+
+class _LinearMainGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.mm(dy2, weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            _accumulate_wgrad(weight, dy2, x.reshape(-1, x.shape[-1]))
+        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, None, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if torch.is_grad_enabled() and weight.requires_grad and getattr(weight, "main_grad", None) is not None:
+        return _LinearMainGrad.apply(x, weight, bias)
+    return F.linear(x, weight, bias)

@@ -38,7 +38,7 @@ BASELINE_TOK_S_8GPU = 20000.0
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--steps", type=int, default=6)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--model", default="qwen2-1.5b")
     p.add_argument("--prompts-per-gpu", type=int, default=32)

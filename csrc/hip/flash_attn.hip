@@ -319,28 +319,51 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
   }
   const int lrow = tid >> 4, lch = tid & 15;  // 16 rows x 16 chunks per pass, 2 passes for 32 rows
 
-  for (int g = 0; g < G; ++g) {
-    const int head = kvh * G + g;
-    for (int qs0 = qs_first; qs0 < q_len; qs0 += 32) {
+  // Work list: (query head of the GQA group) x (32-row query slices that can see this key block),
+  // walked as one flat loop so that the loads of the next slice - also across a head boundary - are
+  // in flight while the current slice is computed (the MFMA chain of a slice is ~1.3k cycles, a
+  // global load ~2-4k: without the prefetch every slice exposes the full latency).
+  const int nslice = q_len > qs_first ? (q_len - qs_first + 31) / 32 : 0;
+  const int nwork = G * nslice;
+  bf16x8 qreg[2], doreg[2];
+  float lse_r = INFINITY, dl_r = 0.f;
+  auto prefetch = [&](int it) {
+    const int head = kvh * G + it / nslice;
+    const int qs0 = qs_first + 32 * (it % nslice);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int qi = qs0 + lrow + 16 * i;
+      qi = qi < q_len ? qi : q_len - 1;
+      qreg[i] = ld8(q + (size_t)(q_beg + qi) * q_stride + (size_t)head * D + lch * 8);
+      doreg[i] = ld8(d_o + (size_t)(q_beg + qi) * do_stride + (size_t)head * D + lch * 8);
+    }
+    if (tid < 32) {
+      int qi = qs0 + tid;
+      const bool ok = qi < q_len;
+      qi = ok ? qi : q_len - 1;
+      // rows past the end get lse = +inf so that p = exp2(-inf) = 0
+      lse_r = ok ? lse[(size_t)head * total_q + q_beg + qi] * 1.4426950408889634f : INFINITY;
+      dl_r = ok ? delta[(size_t)head * total_q + q_beg + qi] : 0.f;
+    }
+  };
+  if (nwork > 0) prefetch(0);
+
+  for (int it = 0; it < nwork; ++it) {
+    const int head = kvh * G + it / nslice;
+    const int qs0 = qs_first + 32 * (it % nslice);
+    {
       __syncthreads();  // previous slice fully consumed (Q/dO/dS tiles)
-      // ---- stage Q and dO slices + row constants
+      // ---- stage the prefetched Q and dO slices + row constants, then start the next loads
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        int qi = qs0 + lrow + 16 * i;
-        qi = qi < q_len ? qi : q_len - 1;
-        lds_row_write(qs, lrow + 16 * i, lch,
-                      ld8(q + (size_t)(q_beg + qi) * q_stride + (size_t)head * D + lch * 8));
-        lds_row_write(dos, lrow + 16 * i, lch,
-                      ld8(d_o + (size_t)(q_beg + qi) * do_stride + (size_t)head * D + lch * 8));
+        lds_row_write(qs, lrow + 16 * i, lch, qreg[i]);
+        lds_row_write(dos, lrow + 16 * i, lch, doreg[i]);
       }
       if (tid < 32) {
-        int qi = qs0 + tid;
-        const bool ok = qi < q_len;
-        qi = ok ? qi : q_len - 1;
-        // rows past the end get lse = +inf so that p = exp2(-inf) = 0
-        lse_s[tid] = ok ? lse[(size_t)head * total_q + q_beg + qi] * 1.4426950408889634f : INFINITY;
-        dl_s[tid] = ok ? delta[(size_t)head * total_q + q_beg + qi] : 0.f;
+        lse_s[tid] = lse_r;
+        dl_s[tid] = dl_r;
       }
+      if (it + 1 < nwork) prefetch(it + 1);
       __syncthreads();
       // ---- S = Q.K^T, dP = dO.V^T (rows = q in registers, col = key on the lane)
       f32x16 sacc, pacc;

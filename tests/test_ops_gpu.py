@@ -425,3 +425,31 @@ def test_embed_rowsumsq():
     torch.testing.assert_close(out[:37], table[ids])
     torch.testing.assert_close(rss_all[0, :37], table[ids].float().pow(2).sum(-1), rtol=1e-4, atol=1e-3)
     assert rss_all[1:].abs().max().item() == 0
+
+
+@pytest.mark.gpu
+def test_linear_accumulates_wgrad_into_fp32_main_grad():
+    """ops.linear: dW is summed by the GEMM into the fp32 main-grad view over two micro-batches."""
+    from areal_vllm_amd import ops
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    w = torch.nn.Parameter((torch.randn(384, 256, device=dev) * 0.05).bfloat16())
+    b = torch.nn.Parameter(torch.zeros(384, device=dev, dtype=torch.bfloat16))
+    w.main_grad = torch.zeros(384, 256, device=dev, dtype=torch.float32)
+    ref_w = torch.zeros(384, 256, device=dev, dtype=torch.float32)
+    ref_b = torch.zeros(384, device=dev, dtype=torch.float32)
+    for _ in range(2):
+        x = torch.randn(512, 256, device=dev).bfloat16().requires_grad_(True)
+        dy = torch.randn(512, 384, device=dev).bfloat16()
+        y = ops.linear(x, w, b)
+        y.backward(dy)
+        assert w.grad is None  # nothing materialised in bf16
+        ref_w += dy.float().t() @ x.detach().float()
+        ref_b += dy.float().sum(0)
+        ref_dx = dy.float() @ w.detach().float()
+        assert torch.allclose(x.grad.float(), ref_dx, atol=0.15, rtol=2e-2)
+        assert torch.allclose(y.float(), torch.nn.functional.linear(x.detach().float(), w.detach().float()), atol=0.1,
+                              rtol=2e-2)
+    assert torch.allclose(w.main_grad, ref_w, atol=2e-2, rtol=1e-3), (w.main_grad - ref_w).abs().max()
+    assert torch.allclose(b.grad.float(), ref_b, atol=0.5, rtol=2e-2)

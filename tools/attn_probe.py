@@ -1,0 +1,27 @@
+"""Time the varlen flash-attention forward / backward kernels on a trainer-shaped packed batch."""
+import sys, time, torch
+sys.path.insert(0, ".")
+from areal_vllm_amd import ops
+dev = torch.device("cuda")
+torch.manual_seed(0)
+Hq, Hkv, D = 12, 2, 128
+lens = torch.randint(1050, 1216, (25,)).tolist()
+T = sum(lens)
+cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
+qkv = torch.randn(T, Hq + 2 * Hkv, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
+def fwd():
+    return ops.flash_attn_varlen_qkv(qkv, cu, max(lens), Hq, Hkv)
+out = fwd(); g = torch.randn_like(out)
+def fb():
+    qkv.grad = None
+    fwd().backward(g)
+def bench(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n
+with torch.no_grad():
+    tf = bench(fwd)
+tfb = bench(fb)
+fl = sum(4 * l * l / 2 * Hq * D for l in lens)
+print(f"T={T} fwd {tf*1e6:.0f}us ({fl/tf/1e12:.0f} TF/s)  fwd+bwd {tfb*1e6:.0f}us  bwd~{(tfb-tf)*1e6:.0f}us ({2.5*fl/(tfb-tf)/1e12:.0f} TF/s)")
