@@ -42,6 +42,7 @@ class ProcessGrid:
         self.coord = self.coord_of(self.local_index) if self.member else None
         self.backend = backend
         self.groups: Dict[str, Optional[dist.ProcessGroup]] = {}
+        self._group_cache: Dict[tuple, dist.ProcessGroup] = {}
         self.group_ranks: Dict[str, List[int]] = {}
         if dist.is_initialized():
             self._build_groups()
@@ -61,9 +62,17 @@ class ProcessGrid:
         return ((pp * self.dp + dp) * self.cp + cp) * self.tp + tp
 
     def _new_group(self, name: str, rank_lists: List[List[int]]):
+        """Groups are created collectively (every process walks every rank list) and shared between
+        dimensions with identical members: with tp = cp = pp = 1 the dp, dp_cp and world groups are one
+        communicator and the four kinds of single-rank groups are one object per rank, which keeps
+        start-up at a handful of communicator creations instead of dozens."""
         mine, mine_ranks = None, None
         for rl in rank_lists:
-            g = dist.new_group(ranks=rl, timeout=DIST_TIMEOUT, backend=self.backend)
+            key = tuple(rl)
+            g = self._group_cache.get(key)
+            if g is None:
+                g = dist.new_group(ranks=rl, timeout=DIST_TIMEOUT, backend=self.backend)
+                self._group_cache[key] = g
             if self.global_rank in rl:
                 mine, mine_ranks = g, rl
         self.groups[name] = mine
