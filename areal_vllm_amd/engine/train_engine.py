@@ -483,9 +483,66 @@ class NativeTrainEngine(TrainEngine):
         return out
 
     # ----------------------------------------------------------------------- save / load
+    def _save_sharded(self, meta: SaveLoadMeta):
+        """Distributed checkpoint: every (pp, tp) shard writes its own slice of the flat buffer - no
+        gather, no conversion - plus a manifest with the parameter offsets; dp replica 0 writes. The
+        optimizer state is per rank as in the HF format. Role of the reference's ``dcp`` /
+        ``naive_distributed`` formats (``areal/experimental/utils/megatron_checkpointer.py``,
+        ``areal/experimental/autotp_engine.py:97``)."""
+        import json
+
+        from safetensors.torch import save_file
+
+        g = self.grid
+        os.makedirs(meta.path, exist_ok=True)
+        tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
+        if g.coord.dp == 0 and g.coord.cp == 0:
+            tensors = {"flat": self.model.flat.flat.detach().cpu()}
+            if self.model.flat_experts is not None:
+                tensors["flat_experts"] = self.model.flat_experts.flat.detach().cpu()
+            save_file(tensors, os.path.join(meta.path, f"shard-{tag}.safetensors"))
+            manifest = dict(format="areal-sharded-v1", layout=dict(dp=g.dp, tp=g.tp, pp=g.pp, cp=g.cp, ep=g.ep),
+                            dtype=str(self.model.dtype).replace("torch.", ""),
+                            offsets={n: [int(o), int(k)] for n, (o, k) in self.model.flat.offsets.items()},
+                            layer_range=list(self.model.layer_range))
+            with open(os.path.join(meta.path, f"manifest-{tag}.json"), "w") as f:
+                json.dump(manifest, f)
+            if g.coord.pp == 0 and g.coord.tp == 0:
+                with open(os.path.join(meta.path, "config.json"), "w") as f:
+                    json.dump(self.model_config.to_hf_dict(), f, indent=2)
+        if meta.with_optim and self.optimizer is not None:
+            sd = dict(optim=self.optimizer.state_dict(), lr_step=self._lr_step)
+            if self.expert_optimizer is not None:
+                sd["expert_optim"] = self.expert_optimizer.state_dict()
+            torch.save(sd, os.path.join(meta.path, f"optim_world_size_{self.world_size}_rank_{self.rank}.pt"))
+        if dist.is_initialized():
+            dist.barrier(group=self.grid.group("world"))
+
+    def _load_sharded(self, meta: SaveLoadMeta):
+        import json
+
+        from safetensors.torch import load_file
+
+        g = self.grid
+        tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
+        with open(os.path.join(meta.path, f"manifest-{tag}.json")) as f:
+            man = json.load(f)
+        lay = man["layout"]
+        if (lay["tp"], lay["pp"]) != (g.tp, g.pp):
+            raise ValueError(f"sharded checkpoint was written as tp{lay['tp']} pp{lay['pp']}, this engine is "
+                             f"tp{g.tp} pp{g.pp}; convert through the hf format or parallel/param_realloc.py")
+        mine = {n: [int(o), int(k)] for n, (o, k) in self.model.flat.offsets.items()}
+        assert man["offsets"] == mine, "parameter layout of the checkpoint differs from this model"
+        t = load_file(os.path.join(meta.path, f"shard-{tag}.safetensors"))
+        self.model.flat.flat.copy_(t["flat"].to(self.model.flat.flat.dtype))
+        if self.model.flat_experts is not None:
+            self.model.flat_experts.flat.copy_(t["flat_experts"])
+
     def save(self, meta: SaveLoadMeta):
+        if meta.weight_format in ("dcp", "naive_distributed"):
+            return self._save_sharded(meta)
         if meta.weight_format != "hf":
-            raise NotImplementedError(f"weight format {meta.weight_format} (use 'hf')")
+            raise NotImplementedError(f"weight format {meta.weight_format} (use 'hf', 'dcp' or 'naive_distributed')")
         g = self.grid
         # one writer per pipeline stage: dp rank 0, cp rank 0, tp rank 0 (tp shards are gathered)
         # (with expert parallelism every ep rank of the first expert-data-parallel replica also writes
@@ -518,9 +575,12 @@ class NativeTrainEngine(TrainEngine):
             dist.barrier(group=self.grid.group("world"))
 
     def load(self, meta: SaveLoadMeta):
-        if meta.weight_format != "hf":
-            raise NotImplementedError(f"weight format {meta.weight_format} (use 'hf')")
-        hf_io.load_hf_weights(self.model, meta.path)
+        if meta.weight_format in ("dcp", "naive_distributed"):
+            self._load_sharded(meta)
+        elif meta.weight_format == "hf":
+            hf_io.load_hf_weights(self.model, meta.path)
+        else:
+            raise NotImplementedError(f"weight format {meta.weight_format} (use 'hf', 'dcp' or 'naive_distributed')")
         if self.optimizer is not None:
             self.optimizer.resync_master_from_params()
             if self.expert_optimizer is not None:
@@ -605,3 +665,4 @@ class NativeTrainEngine(TrainEngine):
 # Names used by scripts written against the reference API.
 FSDPEngine = NativeTrainEngine
 MegatronEngine = NativeTrainEngine
+AutoTPEngine = NativeTrainEngine  # tensor parallelism comes from the strategy's `t` dimension; no DeepSpeed

@@ -213,14 +213,16 @@ class ModelWorker(Worker):
         if rpc.input_key_remap:
             x.remap_keys_(rpc.input_key_remap)
         tik = time.perf_counter()
-        if handle_name == "train_step":
-            res = itf.train_step(model, x, rpc.mb_spec)
-        elif handle_name == "inference":
-            res = itf.inference(model, x, rpc.mb_spec)
-        elif handle_name == "generate":
-            res = itf.generate(model, x, rpc.mb_spec)
-        else:
-            raise NotImplementedError(handle_name)
+        with self._maybe_profile_rpc(rpc):
+            if handle_name == "train_step":
+                res = itf.train_step(model, x, rpc.mb_spec)
+            elif handle_name == "inference":
+                res = itf.inference(model, x, rpc.mb_spec)
+            elif handle_name == "generate":
+                res = itf.generate(model, x, rpc.mb_spec)
+            else:
+                raise NotImplementedError(handle_name)
+        self._log_gpu_stats(rpc.name)
         stats_tracker.export()  # interfaces report through their return value; drop stray local stats
         if isinstance(res, SequenceSample):
             if rpc.output_key_remap:
@@ -235,6 +237,54 @@ class ModelWorker(Worker):
         if isinstance(res, dict):
             res = dict(res, mfc_time=time.perf_counter() - tik)
         return res
+
+    # ------------------------------------------------------------------ tracing / monitoring
+    def _maybe_profile_rpc(self, rpc: MFCDef):
+        """``AREAL_DUMP_TRACE=1``: wrap the call in the PyTorch profiler and write a chrome trace per
+        (rpc, worker) under ``{fileroot}/logs/.../trace``; ``AREAL_DUMP_MEMORY=1`` adds an allocator
+        snapshot. Off by default (per-call profiler of ``realhf/system/model_worker.py:79-95,829-909``)."""
+        import contextlib
+
+        if os.environ.get("AREAL_DUMP_TRACE", "0") != "1":
+            return contextlib.nullcontext()
+        worker = self
+
+        class _Ctx:
+            def __enter__(self_):
+                acts = [torch.profiler.ProfilerActivity.CPU]
+                if worker.device.type == "cuda":
+                    acts.append(torch.profiler.ProfilerActivity.CUDA)
+                    if os.environ.get("AREAL_DUMP_MEMORY", "0") == "1":
+                        torch.cuda.memory._record_memory_history()
+                self_.prof = torch.profiler.profile(activities=acts, record_shapes=True, with_stack=False)
+                self_.prof.__enter__()
+
+            def __exit__(self_, *exc):
+                self_.prof.__exit__(*exc)
+                d = os.path.join(worker.config.fileroot, "logs", worker.experiment_name, worker.trial_name, "trace")
+                os.makedirs(d, exist_ok=True)
+                worker._trace_count = getattr(worker, "_trace_count", 0) + 1
+                base = os.path.join(d, f"{rpc.name}_r{worker.worker_index}_{worker._trace_count}")
+                self_.prof.export_chrome_trace(base + ".json")
+                if worker.device.type == "cuda" and os.environ.get("AREAL_DUMP_MEMORY", "0") == "1":
+                    torch.cuda.memory._dump_snapshot(base + "_mem.pkl")
+                return False
+
+        return _Ctx()
+
+    def _log_gpu_stats(self, tag: str):
+        """Memory high-water mark after a call; the worker takes itself down when the device is nearly
+        full (``AREAL_GPU_MEMORY_KILL_THRESHOLD``, a fraction) so that the launcher's recover loop restarts
+        the trial instead of the job dying later inside a collective."""
+        if self.device.type != "cuda":
+            return
+        free, total = torch.cuda.mem_get_info(self.device)
+        used = 1.0 - free / total
+        peak = torch.cuda.max_memory_allocated(self.device) / 2 ** 30
+        logger.debug(f"after {tag}: device memory {used * 100:.1f}% used, peak allocated {peak:.1f} GiB")
+        thr = float(os.environ.get("AREAL_GPU_MEMORY_KILL_THRESHOLD", "1.0"))
+        if used > thr:
+            raise RuntimeError(f"device memory {used:.3f} above the kill threshold {thr}: exiting for a clean restart")
 
     def _hook_data_transfer(self, hd: Dict):
         self.data_manager.redistribute(hd["meta"], hd["plan"])

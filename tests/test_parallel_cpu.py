@@ -82,6 +82,15 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
     if rank == 0:
         torch.save(dict(grad_norm=[s["grad_norm"] for s in stats], eval=float(ev)), os.path.join(ckpt_out, "stats.pt"))
     torch.save(fw, os.path.join(ckpt_out, f"fwd_dp{dpr}_r{rank}.pt"))
+    # sharded ("dcp") checkpoint round trip in the same layout: weights and optimizer state come back exactly
+    shard_dir = os.path.join(ckpt_out, "sharded")
+    eng.save(SaveLoadMeta(path=shard_dir, weight_format="dcp", with_optim=True))
+    want_w, want_m = eng.model.flat.flat.clone(), eng.optimizer.m.clone()
+    eng.model.flat.flat.add_(1.0)
+    eng.optimizer.m.zero_()
+    eng.load(SaveLoadMeta(path=shard_dir, weight_format="dcp", with_optim=True))
+    assert torch.equal(eng.model.flat.flat, want_w) and torch.equal(eng.optimizer.m, want_m)
+    assert torch.equal(eng.optimizer.master, want_w[eng.optimizer.lo:eng.optimizer.hi].float())
     eng.destroy()
 
 
