@@ -189,17 +189,11 @@ class MoE(nn.Module):
         self.aux_loss = None
 
     def _experts(self, xs, counts):
-        outs = []
-        s = 0
-        for e, n in enumerate(counts):
-            if n == 0:
-                continue
-            h = ops.swiglu(F.linear(xs[s:s + n], self.gate_up[e]))
-            outs.append(F.linear(h, self.down[e]))
-            s += n
-        if not outs:
+        """All local experts on their expert-sorted token slabs: two grouped GEMMs around SwiGLU."""
+        if xs.shape[0] == 0:
             return xs.new_zeros(0, self.cfg.hidden_size)
-        return torch.cat(outs, 0)
+        h = ops.swiglu(ops.grouped_gemm(xs, self.gate_up, counts))
+        return ops.grouped_gemm(h, self.down, counts)
 
     def forward(self, x, tp_group, ep_group=None):
         cfg = self.cfg

@@ -453,3 +453,26 @@ def test_linear_accumulates_wgrad_into_fp32_main_grad():
                               rtol=2e-2)
     assert torch.allclose(w.main_grad, ref_w, atol=2e-2, rtol=1e-3), (w.main_grad - ref_w).abs().max()
     assert torch.allclose(b.grad.float(), ref_b, atol=0.5, rtol=2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("counts", [[64, 0, 130, 1, 61], [5, 300, 7, 0, 0, 200, 33, 64]])
+def test_grouped_gemm_matches_reference_fwd_bwd(counts):
+    from areal_vllm_amd import ops
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    E, N, K = len(counts), 192, 256
+    T = sum(counts)
+    x = (torch.randn(T, K, device=dev)).bfloat16().requires_grad_(True)
+    w = (torch.randn(E, N, K, device=dev) * 0.05).bfloat16().requires_grad_(True)
+    dy = torch.randn(T, N, device=dev).bfloat16()
+    out = ops.grouped_gemm(x, w, counts)
+    xf, wf = x.detach().float().requires_grad_(True), w.detach().float().requires_grad_(True)
+    ref = ops.grouped_gemm_ref(xf, wf, counts)
+    assert out.shape == ref.shape
+    assert torch.allclose(out.float(), ref, atol=3e-2, rtol=2e-2), (out.float() - ref).abs().max()
+    out.backward(dy)
+    ref.backward(dy.float())
+    assert torch.allclose(x.grad.float(), xf.grad, atol=3e-2, rtol=2e-2), (x.grad.float() - xf.grad).abs().max()
+    assert torch.allclose(w.grad.float(), wf.grad, atol=0.25, rtol=3e-2), (w.grad.float() - wf.grad).abs().max()
