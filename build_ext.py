@@ -86,6 +86,20 @@ def build_runtime(verbose=True) -> Path:
     return out
 
 
+def build_stress(sanitize: str = "address,undefined", verbose=True) -> Path:
+    """Stand-alone stress test of the scheduler / block manager, built with host sanitizers
+    (``address,undefined`` by default; the runtime is driven by one thread, so no thread sanitizer)."""
+    BUILD_DIR.mkdir(exist_ok=True)
+    src = RT_DIR / "tests" / "stress_test.cpp"
+    out = BUILD_DIR / f"sched_stress_{sanitize.replace(',', '_') or 'plain'}"
+    if _newer(src, out, list(RT_DIR.glob("*.hpp"))):
+        flags = [f"-fsanitize={sanitize}", "-fno-omit-frame-pointer"] if sanitize else []
+        if verbose:
+            print(f"[build_ext] compiling scheduler stress test ({sanitize or 'no sanitizer'})")
+        _run([os.environ.get("CXX", "g++"), "-std=c++17", "-O1", "-g", *flags, f"-I{RT_DIR}", str(src), "-o", str(out)])
+    return out
+
+
 def build_all(verbose=True):
     return build_hip(verbose), build_runtime(verbose)
 
