@@ -188,11 +188,20 @@ class RolloutWorker(AsyncWorker):
         done, _ = await asyncio.wait(tasks, timeout=ROLLOUT_POLL_WAIT_TIME, return_when=asyncio.FIRST_COMPLETED)
         return list(done)
 
+    def _act_queue_of(self, qid) -> asyncio.Queue:
+        """Multi-turn agents tag their generation requests ``{qid}-{turn}``: route by the episode's qid."""
+        q = self.act_queues.get(qid)
+        if q is None and isinstance(qid, str) and "-" in qid:
+            q = self.act_queues.get(qid.rsplit("-", 1)[0])
+        if q is None:
+            raise KeyError(f"generation result for unknown episode {qid}")
+        return q
+
     async def poll_queue_dispatch_task(self):
         for _ in range(20):
             try:
                 resp = self.rollout_response_queue.get_nowait()
-                self.act_queues[resp.qid].put_nowait(resp)
+                self._act_queue_of(resp.qid).put_nowait(resp)
             except asyncio.QueueEmpty:
                 await asyncio.sleep(0.005)
 

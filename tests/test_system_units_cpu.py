@@ -457,3 +457,48 @@ def test_automatic_evaluator_orders_and_resumes(tmp_path):
         time.sleep(0.05)
     rows = [json.loads(l) for l in open(ev / "eval_results.jsonl")]
     assert [r["global_step"] for r in rows] == [2, 4, 6]
+
+
+def test_multi_turn_agent_discounts_rewards_and_masks_feedback():
+    from areal_vllm_amd.impl.agent.math_multi_turn_agent import MathMultiTurnAgent
+    from areal_vllm_amd.system.agent_api import EnvironmentService
+    from areal_vllm_amd.system.data_api import SequenceSample
+    from areal_vllm_amd.system.model_api import BundledGenerationOutputs
+
+    class Env(EnvironmentService):
+        def __init__(self):
+            self.calls = 0
+
+        async def step(self, action):
+            self.calls += 1
+            return None, [self.calls == 3], True, False, {}  # right on the third attempt
+
+    async def run():
+        agent = MathMultiTurnAgent(GenerationHyperparameters(max_new_tokens=4), num_turns=3, turn_level_discount=0.5)
+        obs, act = asyncio.Queue(), asyncio.Queue()
+        prompt = SequenceSample(keys={"packed_prompts"}, ids=["q1"], seqlens=dict(packed_prompts=[[3]]),
+                                data=dict(packed_prompts=torch.tensor([10, 11, 12])))
+        task = asyncio.create_task(agent.collect_trajectory(prompt, Env(), obs, act))
+        seen = []
+        for turn in range(3):
+            qid, ids, g = await obs.get()
+            seen.append((qid, list(ids)))
+            out = [50 + turn, 60 + turn]
+            act.put_nowait(BundledGenerationOutputs(qid=qid, prompt_ids=list(ids), output_ids=[out], seqs=[list(ids) + out],
+                                                    logprobs=[[0.0] * (len(ids) - 1) + [-0.1, -0.2]], no_eos=[False],
+                                                    version_start=[turn], version_end=[turn]))
+        return seen, await task
+
+    seen, (traj,) = asyncio.run(run())
+    assert [q for q, _ in seen] == ["q1-0", "q1-1", "q1-2"] and g_ok(seen)
+    # rewards -1, -1, +1 discounted backwards with 0.5: r1 = -1 + 0.5 * 1 = -0.5, r0 = -1 + 0.5 * r1 = -1.25
+    assert traj.data["rewards"].tolist() == [-1.25, -0.5, 1.0]
+    assert traj.seqlens["packed_input_ids"] == [[5, 9, 13]]
+    pm = traj.data["prompt_mask"].tolist()
+    assert pm[:5] == [1, 1, 1, 0, 0] and pm[5:14] == [1] * 7 + [0, 0]  # earlier turns + feedback are context
+    assert traj.data["version_start"].tolist() == [0, 1, 2]
+
+
+def g_ok(seen):
+    # every turn's context = previous sequence + the (tokenizer-free) "wrong answer" feedback ids [5, 6]
+    return seen[1][1] == seen[0][1] + [50, 60, 5, 6] and seen[2][1] == seen[1][1] + [51, 61, 5, 6]
