@@ -91,6 +91,26 @@ class NativeInferenceEngine:
                           prompt_tokens=0, aborted=0)
         self._copy_stream = None
         self._stream = None
+        self.update_group = None
+        # tensor-parallel serving: rank 0 of the TP group owns the scheduler and tells the other ranks
+        # what to run (see inference/tp_worker.py)
+        self.is_leader = tp_rank == 0
+        self._tp_src = 0
+        self._last_bcast = time.monotonic()
+        if tp_size > 1:
+            import torch.distributed as dist
+
+            assert tp_group is not None or dist.is_initialized(), "tensor-parallel serving needs a process group"
+            self._tp_src = dist.get_global_rank(tp_group, 0) if tp_group is not None else 0
+
+    # ---------------------------------------------------------------------- TP command fan-out
+    def _tp_bcast(self, cmd: str, payload: Any = None):
+        """Leader only: send one command to the follower ranks (host objects, gloo / RCCL bootstrap)."""
+        if self.tp_size > 1 and self.is_leader:
+            import torch.distributed as dist
+
+            dist.broadcast_object_list([(cmd, payload)], src=self._tp_src, group=self.tp_group)
+            self._last_bcast = time.monotonic()
 
     # ------------------------------------------------------------------------------ set-up
     def initialize(self, load_weights: bool = True):
@@ -104,8 +124,15 @@ class NativeInferenceEngine:
 
         if load_weights and cfg.model_path and os.path.isdir(cfg.model_path):
             hf_io.load_hf_weights(self.model, cfg.model_path)
+        elif self.tp_size > 1:
+            # random weights must agree across the TP group: build the unsharded model from one seed on
+            # the host and keep this rank's slices
+            full = Transformer(mc, dtype=torch.float32, device="cpu")
+            full.init_weights(seed=1)
+            assign_hf_named_tensors(self.model, dict(hf_io.native_to_hf_state(full, gather=False)))
+            del full
         else:
-            self.model.init_weights(seed=1 + 1000 * self.tp_rank)
+            self.model.init_weights(seed=1)
         ctx = int(cfg.context_length or mc.max_position_embeddings)
         hkv = self.model.layers[0].attn.hkv
         per_page = _kv_bytes_per_page(mc, len(self.model.layers), hkv, 2)
@@ -125,6 +152,9 @@ class NativeInferenceEngine:
         self.runner = ModelRunner(self.model, num_pages, ctx, max_running, decode_steps=self.decode_steps,
                                   use_graph=not cfg.disable_cuda_graph, seed=int(cfg.random_seed),
                                   buckets=cfg.cuda_graph_bs)
+        self.num_pages = num_pages
+        if not self.is_leader:
+            return self  # followers execute the leader's plans in `run_follower`
         sc = _runtime.SchedulerConfig()
         sc.num_pages = num_pages
         sc.max_running_requests = max_running
@@ -164,6 +194,8 @@ class NativeInferenceEngine:
                 self._drain_requests()
                 if self._paused or not self.sched.has_work():
                     self._deliver()
+                    if self.tp_size > 1 and time.monotonic() - self._last_bcast > 30.0:
+                        self._tp_bcast("noop")  # keeps the followers' blocking receive inside its timeout
                     self._wake.wait(timeout=0.01)
                     self._wake.clear()
                     continue
@@ -175,6 +207,8 @@ class NativeInferenceEngine:
                     self._wake.clear()
                     continue
                 t0 = time.perf_counter()
+                if self.tp_size > 1:
+                    self._tp_bcast("prefill" if kind == 1 else "decode", plan)
                 if kind == 1:
                     toks, lps = self.runner.prefill(plan)
                     self.sched.process_prefill(toks, lps)
@@ -189,6 +223,40 @@ class NativeInferenceEngine:
         except Exception:
             traceback.print_exc()
             self._fail_all("engine loop crashed")
+        finally:
+            if self.tp_size > 1:
+                try:
+                    self._tp_bcast("shutdown")
+                except Exception:  # the group may already be gone at interpreter exit
+                    pass
+
+    def run_follower(self):
+        """Loop of TP ranks > 0: receive the leader's commands and run them on this rank's shard. Sampling
+        is keyed by (seed, step counter) and the LM head is replicated, so every rank draws the same
+        tokens; the runner additionally broadcasts the leader's tokens so that ranks can never diverge."""
+        import torch.distributed as dist
+
+        assert not self.is_leader
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        while True:
+            box = [None]
+            dist.broadcast_object_list(box, src=self._tp_src, group=self.tp_group)
+            cmd, payload = box[0]
+            if cmd == "prefill":
+                self.runner.prefill(payload)
+            elif cmd == "decode":
+                self.runner.decode(payload)
+            elif cmd == "load_disk":
+                hf_io.load_hf_weights(self.model, payload)
+            elif cmd == "init_update_group":
+                self._join_update_group(payload)
+            elif cmd == "recv_weights":
+                self._recv_weights(*payload)
+            elif cmd == "shutdown":
+                return
+            elif cmd != "noop":
+                raise RuntimeError(f"unknown TP command {cmd!r}")
 
     def _drain_requests(self):
         while True:
@@ -338,6 +406,7 @@ class NativeInferenceEngine:
                                   abort_running: bool = True):
         """Colocated update: one device-to-device copy of the flat bf16 buffer on a side stream, applied
         between two engine steps; running requests are aborted first (their KV is stale)."""
+        assert self.tp_size == 1, "the flat-buffer copy needs identical layouts; TP engines load by name"
         src = trainer_model.flat.flat
         cuda = self.device.type == "cuda"
         ready = done = None
@@ -372,6 +441,7 @@ class NativeInferenceEngine:
             if abort_running:
                 self.sched.abort_all()
                 self._deliver()
+            self._tp_bcast("load_disk", path)
             hf_io.load_hf_weights(self.model, path)
             self._after_weight_change(version)
         self._control(f)
@@ -386,6 +456,45 @@ class NativeInferenceEngine:
             assign_hf_named_tensors(self.model, tensors)
             if finalize:
                 self._after_weight_change(version)
+        self._control(f)
+
+    # ------------------------------------------------------- weight updates over a collective
+    def _join_update_group(self, body: Dict[str, Any]):
+        from ..utils.distributed import init_custom_process_group
+
+        rank = int(body["rank_offset"]) + self.tp_rank
+        self.update_group = init_custom_process_group(
+            backend=body.get("backend", "nccl"), world_size=int(body["world_size"]), rank=rank,
+            init_method=f"tcp://{body['master_address']}:{body['master_port']}", group_name=body["group_name"])
+
+    def init_weight_update_group(self, body: Dict[str, Any]):
+        """Join the trainer's weight-update group: trainer rank 0 is rank 0, TP rank r of this server is
+        rank ``rank_offset + r`` (``areal/engine/sglang_remote.py:452-480`` in the reference)."""
+        def f():
+            self._tp_bcast("init_update_group", body)
+            self._join_update_group(body)
+        self._control(f)
+
+    def _recv_weights(self, names, dtypes, shapes):
+        import torch.distributed as dist
+
+        tensors = {}
+        for n, dt, sh in zip(names, dtypes, shapes):
+            t = torch.empty(sh, dtype=getattr(torch, str(dt).replace("torch.", "")), device=self.device)
+            dist.broadcast(t, src=0, group=self.update_group)
+            tensors[n] = t
+        assign_hf_named_tensors(self.model, tensors)
+
+    def update_weights_from_distributed(self, names, dtypes, shapes, version: Optional[int] = None,
+                                        abort_running: bool = True):
+        """Receive HF-named full tensors broadcast by trainer rank 0; every TP rank keeps its slices."""
+        def f():
+            if abort_running:
+                self.sched.abort_all()
+                self._deliver()
+            self._tp_bcast("recv_weights", (names, dtypes, shapes))
+            self._recv_weights(names, dtypes, shapes)
+            self._after_weight_change(version)
         self._control(f)
 
     # ----------------------------------------------------------------------------- metrics

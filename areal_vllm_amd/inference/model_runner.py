@@ -78,6 +78,17 @@ class ModelRunner:
             torch.distributed.all_reduce(h, group=self.model.tp_group)
         return h, residual
 
+    def _sync_tokens(self, tok: torch.Tensor, lp: torch.Tensor):
+        """Tensor-parallel ranks sample from identical logits with identical Philox keys; broadcasting the
+        leader's draw (a few hundred bytes per step) makes agreement unconditional, so a rounding
+        difference between ranks can never fork the KV caches."""
+        if self.model.tp_size > 1:
+            import torch.distributed as dist
+
+            src = dist.get_global_rank(self.model.tp_group, 0) if self.model.tp_group is not None else 0
+            dist.broadcast(tok, src=src, group=self.model.tp_group)
+            dist.broadcast(lp, src=src, group=self.model.tp_group)
+
     def _final_logits(self, h, residual) -> torch.Tensor:
         cfg = self.cfg
         x, _ = ops.rmsnorm(h, self.model.norm, cfg.rms_norm_eps, residual, cfg.gemma_norm)
@@ -125,6 +136,7 @@ class ModelRunner:
         filt = bool((plan["top_k"] < self.V).any() or (plan["top_p"] < 1.0).any())
         tok, lp = ops.sample(logits, temp, top_k if filt else None, top_p if filt else None, self.seed,
                              self.step_counter)
+        self._sync_tokens(tok, lp)
         return tok.cpu().numpy(), lp.cpu().numpy()
 
     # ------------------------------------------------------------------------------ decode
@@ -183,6 +195,7 @@ class ModelRunner:
             ops.sample(logits, st["temperature"], st["top_k"] if filtered else None, st["top_p"] if filtered else None,
                        self.seed, self.step_counter, bump_step=True, out_tokens=st["out_tokens"][s],
                        out_logprobs=st["out_logprobs"][s])
+            self._sync_tokens(st["out_tokens"][s], st["out_logprobs"][s])
             ops.advance_step_(st["out_tokens"][s], st["input_ids"], st["positions"], st["context_lens"], st["slots"],
                               st["block_tables"])
 

@@ -151,41 +151,18 @@ class InferenceServer:
 
     async def init_update_group(self, req):
         body = await req.json()
-
-        def f():
-            from ..utils.distributed import init_custom_process_group
-
-            rank = int(body["rank_offset"]) + self.engine.tp_rank
-            self.update_group = init_custom_process_group(
-                backend=body.get("backend", "nccl"), world_size=int(body["world_size"]), rank=rank,
-                init_method=f"tcp://{body['master_address']}:{body['master_port']}", group_name=body["group_name"])
-            return True
-
         try:
-            await self._offload(f)
+            await self._offload(self.engine.init_weight_update_group, body)
         except Exception as e:
             return web.json_response({"success": False, "message": repr(e)})
         return web.json_response({"success": True, "message": "Succeeded to initialize custom process group."})
 
     async def update_from_distributed(self, req):
         body = await req.json()
-        names, dtypes, shapes = body["names"], body["dtypes"], body["shapes"]
         abort = bool(body.get("abort_all_requests", True))
-
-        def f():
-            import torch.distributed as dist
-
-            dev = self.engine.device
-            tensors = {}
-            for n, dt, sh in zip(names, dtypes, shapes):
-                t = torch.empty(sh, dtype=getattr(torch, dt.replace("torch.", "")), device=dev)
-                dist.broadcast(t, src=0, group=self.update_group)
-                tensors[n] = t
-            self.engine.load_named_tensors(tensors, version=body.get("version"), abort_running=abort)
-            return True
-
         try:
-            await self._offload(f)
+            await self._offload(self.engine.update_weights_from_distributed, body["names"], body["dtypes"],
+                                body["shapes"], body.get("version"), abort)
         except Exception as e:
             return web.json_response({"success": False, "message": repr(e)})
         return web.json_response({"success": True, "message": "Succeeded to update parameter online."})
@@ -235,7 +212,7 @@ def build_engine(args, cfg: InferenceServerConfig) -> NativeInferenceEngine:
     else:
         dev = torch.device("cpu")
     if args.tp_size > 1:
-        raise NotImplementedError("multi-GPU tensor-parallel serving is launched through inference.tp_worker")
+        raise RuntimeError("tensor-parallel serving is started by main() through inference.tp_worker")
     eng = NativeInferenceEngine(cfg, device=dev, num_pages=args.num_pages, kv_cache_gb=args.kv_cache_gb)
     eng.initialize(load_weights=True)
     return eng
@@ -243,7 +220,14 @@ def build_engine(args, cfg: InferenceServerConfig) -> NativeInferenceEngine:
 
 def main(argv: Optional[List[str]] = None):
     args, cfg = parse_server_args(argv)
-    engine = build_engine(args, cfg)
+    if args.tp_size > 1:
+        from . import tp_worker
+
+        engine = tp_worker.launch(args, cfg, sys.argv[1:] if argv is None else list(argv))
+        if engine is None:  # follower rank: served its leader until shutdown
+            return
+    else:
+        engine = build_engine(args, cfg)
     server = InferenceServer(engine)
     logger.info(f"serving on {args.host}:{args.port}")
     web.run_app(server.app, host=args.host, port=args.port, print=None, access_log=None)

@@ -169,8 +169,9 @@ def init_distributed(backend: Optional[str] = None, timeout=DIST_TIMEOUT):
     if backend == "nccl":
         local_rank = int(os.environ.get("LOCAL_RANK", str(rank % max(1, torch.cuda.device_count()))))
         torch.cuda.set_device(local_rank)
-        # gloo is registered next to RCCL so host-side object collectives never touch the GPU
-        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world, timeout=timeout,
-                                device_id=torch.device("cuda", local_rank))
+        # gloo is registered next to RCCL so host-side object collectives never touch the GPU. No
+        # `device_id`: communicators are then created by plain ncclCommInitRank on first use of each
+        # group instead of eagerly by splitting the world communicator.
+        dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world, timeout=timeout)
     else:
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
