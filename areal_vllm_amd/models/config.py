@@ -168,6 +168,9 @@ PRESETS: Dict[str, Dict[str, Any]] = {
     "tiny": dict(family="qwen2", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
                  head_dim=128, intermediate_size=512, tie_word_embeddings=True, qkv_bias=True, rope_theta=1e4,
                  max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
+    "small": dict(family="qwen2", vocab_size=4096, hidden_size=512, n_layers=4, n_q_heads=4, n_kv_heads=2,
+                  head_dim=128, intermediate_size=1536, tie_word_embeddings=True, qkv_bias=True, rope_theta=1e4,
+                  max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
     "tiny-moe": dict(family="qwen3_moe", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
                      head_dim=128, intermediate_size=512, tie_word_embeddings=False, qkv_bias=False, qk_norm=True,
                      rope_theta=1e4, max_position_embeddings=4096, n_experts=4, n_experts_per_tok=2,

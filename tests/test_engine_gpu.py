@@ -1,0 +1,306 @@
+"""Engine-level tests on an MI355X: the native train engine against a plain PyTorch fp32 re-implementation
+of the same architecture (forward log-probs, a few optimizer steps, HF round trip, packed vs padded),
+the rollout engine's log-probs against the trainer's recomputation, interruption by a weight update, and
+the driver's smoke entry. Mirrors ``areal/tests/test_train_engine.py``,
+``test_packed_vs_padded_consistency.py`` and ``test_sglang_engine.py`` of the reference."""
+import math
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    import areal_vllm_amd.ops as ops
+
+    assert ops.hip_available(), "libareal_hip.so must be loaded on a GPU box (python build_ext.py)"
+
+
+def _batch(vocab, lens, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    S = max(lens)
+    ids = torch.zeros(len(lens), S, dtype=torch.long)
+    am = torch.zeros(len(lens), S, dtype=torch.bool)
+    lm = torch.zeros(len(lens), S, dtype=torch.bool)
+    for i, n in enumerate(lens):
+        ids[i, :n] = torch.randint(2, vocab, (n,), generator=g)
+        am[i, :n] = True
+        lm[i, n // 4:n - 1] = True
+    return dict(input_ids=ids, attention_mask=am, loss_mask=lm)
+
+
+def _ref_logits(cfg, W, ids):
+    """Plain PyTorch fp32 Qwen2-style decoder on one sequence `ids` [S] from HF-named weights."""
+    f = lambda n: W[n].float()  # noqa: E731
+    S, D, Hq, Hkv = ids.numel(), cfg.head_dim, cfg.n_q_heads, cfg.n_kv_heads
+    dev = ids.device
+
+    def rms(x, w):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + cfg.rms_norm_eps) * w
+
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, device=dev).float() / D))
+    ang = torch.arange(S, device=dev).float()[:, None] * inv[None]
+    cos, sin = torch.cat([ang.cos(), ang.cos()], -1)[:, None], torch.cat([ang.sin(), ang.sin()], -1)[:, None]
+
+    def rope(t):
+        return t * cos + torch.cat([-t[..., D // 2:], t[..., :D // 2]], -1) * sin
+
+    x = f("model.embed_tokens.weight")[ids]
+    mask = torch.full((S, S), float("-inf"), device=dev).triu(1)
+    for i in range(cfg.n_layers):
+        p = f"model.layers.{i}."
+        h = rms(x, f(p + "input_layernorm.weight"))
+        q = (h @ f(p + "self_attn.q_proj.weight").T + f(p + "self_attn.q_proj.bias")).view(S, Hq, D)
+        k = (h @ f(p + "self_attn.k_proj.weight").T + f(p + "self_attn.k_proj.bias")).view(S, Hkv, D)
+        v = (h @ f(p + "self_attn.v_proj.weight").T + f(p + "self_attn.v_proj.bias")).view(S, Hkv, D)
+        q, k = rope(q), rope(k)
+        k, v = k.repeat_interleave(Hq // Hkv, 1), v.repeat_interleave(Hq // Hkv, 1)
+        att = torch.softmax(torch.einsum("shd,thd->hst", q, k) / math.sqrt(D) + mask, -1)
+        o = torch.einsum("hst,thd->shd", att, v).reshape(S, Hq * D)
+        x = x + o @ f(p + "self_attn.o_proj.weight").T
+        h = rms(x, f(p + "post_attention_layernorm.weight"))
+        x = x + (F.silu(h @ f(p + "mlp.gate_proj.weight").T) * (h @ f(p + "mlp.up_proj.weight").T)) @ f(
+            p + "mlp.down_proj.weight").T
+    x = rms(x, f("model.norm.weight"))
+    head = W.get("lm_head.weight", W["model.embed_tokens.weight"]).float()
+    return x @ head.T
+
+
+def _sft_loss(proxy, mb):
+    labels = torch.roll(mb["input_ids"], -1, 0)
+    lp = proxy.logprobs(labels)
+    m = mb["loss_mask"].float()
+    return -(lp * m).sum() / m.sum().clamp(min=1)
+
+
+def _weight(mb):
+    return mb["loss_mask"].float().sum()
+
+
+def _logp_hook(proxy, mb):
+    return proxy.logprobs(torch.roll(mb["input_ids"], -1, 0))
+
+
+@pytest.fixture(scope="module")
+def engine():
+    _env()
+    from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
+    from areal_vllm_amd.api.io_struct import FinetuneSpec
+    from areal_vllm_amd.engine.train_engine import NativeTrainEngine
+
+    cfg = TrainEngineConfig(experiment_name="t", trial_name="t", path="small", init_from_scratch=True,
+                            dtype="bfloat16", gradient_checkpointing=False,
+                            optimizer=OptimizerConfig(lr=2e-3, weight_decay=0.0, gradient_clipping=1.0,
+                                                      warmup_steps_proportion=0.0, lr_scheduler_type="constant"),
+                            mb_spec=MicroBatchSpec(max_tokens_per_mb=1024))
+    eng = NativeTrainEngine(cfg)
+    eng.create_process_group()
+    eng.initialize(None, FinetuneSpec(1, 64, 8))
+    yield eng
+    eng.destroy()
+
+
+def test_forward_matches_fp32_reference(engine):
+    from areal_vllm_amd.models import hf_io
+
+    cfg = engine.model_config
+    batch = _batch(cfg.vocab_size, [257, 64, 300, 129, 33, 512], seed=1)
+    got = engine.forward(batch, post_hook=_logp_hook).float().cpu()
+    W = dict(hf_io.native_to_hf_state(engine.model, gather=False))
+    dev = engine.device
+    worst = 0.0
+    for b in range(batch["input_ids"].shape[0]):
+        n = int(batch["attention_mask"][b].sum())
+        ids = batch["input_ids"][b, :n].to(dev)
+        lp = torch.log_softmax(_ref_logits(cfg, W, ids), -1)
+        ref = lp[torch.arange(n - 1, device=dev), ids[1:]].cpu()
+        err = (got[b, :n - 1] - ref).abs()
+        worst = max(worst, float(err.max()))
+        assert float(err.mean()) < 0.02, (b, float(err.mean()))
+    assert worst < 0.15, worst  # bf16 activations vs an fp32 model
+
+
+def test_packed_micro_batches_equal_single_batch(engine):
+    """Token-budget micro-batching (several packed micro-batches, padded to the page size) must not change
+    per-token results."""
+    from areal_vllm_amd.api.cli_args import MicroBatchSpec
+
+    cfg = engine.model_config
+    batch = _batch(cfg.vocab_size, [200, 180, 90, 310, 45, 400, 60, 128], seed=2)
+    old = engine.config.mb_spec
+    try:
+        engine.config.mb_spec = MicroBatchSpec(max_tokens_per_mb=8192)
+        one = engine.forward(batch, post_hook=_logp_hook).float()
+        engine.config.mb_spec = MicroBatchSpec(max_tokens_per_mb=512)
+        many = engine.forward(batch, post_hook=_logp_hook).float()
+    finally:
+        engine.config.mb_spec = old
+    # the last position of a sequence is scored against whatever follows it in the pack: never used
+    m = torch.roll(batch["attention_mask"], -1, 1)
+    m[:, -1] = False
+    m = (m & batch["attention_mask"]).to(one.device)
+    assert float(((one - many).abs() * m).max()) < 2e-2
+
+
+def test_train_steps_reduce_loss_and_hf_round_trip(engine, tmp_path):
+    from areal_vllm_amd.api.cli_args import TrainEngineConfig
+    from areal_vllm_amd.api.io_struct import SaveLoadMeta
+    from areal_vllm_amd.engine.train_engine import NativeTrainEngine
+
+    cfg = engine.model_config
+    batch = _batch(cfg.vocab_size, [128, 96, 200, 64], seed=3)
+    l0 = float(engine.eval_batch(batch, _sft_loss, _weight))
+    for _ in range(8):
+        st = engine.train_batch(batch, _sft_loss, _weight)
+        assert st["update_successful"] == 1.0 and math.isfinite(st["grad_norm"])
+    l1 = float(engine.eval_batch(batch, _sft_loss, _weight))
+    assert l1 < l0 - 0.5, (l0, l1)
+    path = str(tmp_path / "hf")
+    engine.save(SaveLoadMeta(path=path, weight_format="hf", with_optim=True))
+    assert os.path.exists(os.path.join(path, "config.json"))
+    before = engine.forward(batch, post_hook=_logp_hook)
+    c2 = TrainEngineConfig(experiment_name="t", trial_name="t2", path=path, dtype="bfloat16",
+                           gradient_checkpointing=False, optimizer=engine.config.optimizer, mb_spec=engine.config.mb_spec)
+    e2 = NativeTrainEngine(c2)
+    e2.create_process_group()
+    e2.initialize(None, None)
+    e2.load(SaveLoadMeta(path=path, weight_format="hf", with_optim=True))
+    after = e2.forward(batch, post_hook=_logp_hook)
+    assert torch.equal(before, after)
+    s1 = engine.train_batch(batch, _sft_loss, _weight)
+    s2 = e2.train_batch(batch, _sft_loss, _weight)
+    assert s1["grad_norm"] == pytest.approx(s2["grad_norm"], rel=1e-3)  # optimizer state came along
+    assert torch.allclose(engine.model.flat.flat.float(), e2.model.flat.flat.float(), atol=1e-3)
+
+
+def _rollout_pair(model="small", decode_steps=4, pages=512):
+    _env()
+    from areal_vllm_amd.api.cli_args import (AdvNormConfig, InferenceEngineConfig, InferenceServerConfig,
+                                             MicroBatchSpec, OptimizerConfig, PPOActorConfig)
+    from areal_vllm_amd.api.io_struct import FinetuneSpec, WeightUpdateMeta
+    from areal_vllm_amd.engine.local_engine import LocalInferenceEngine
+    from areal_vllm_amd.engine.ppo.actor import NativePPOActor
+    from areal_vllm_amd.inference.engine import NativeInferenceEngine
+
+    cfg = PPOActorConfig(experiment_name="g", trial_name="g", path=model, init_from_scratch=True, dtype="bfloat16",
+                         optimizer=OptimizerConfig(lr=5e-3, gradient_clipping=1.0), group_size=2,
+                         mb_spec=MicroBatchSpec(max_tokens_per_mb=4096), ppo_n_minibatches=1,
+                         use_decoupled_loss=True, recompute_logprob=True, kl_ctl=0.0,
+                         adv_norm=AdvNormConfig("group", "group", 2), gradient_checkpointing=False)
+    actor = NativePPOActor(cfg)
+    actor.create_process_group()
+    actor.initialize(None, FinetuneSpec(1, 100, 4))
+    dev = torch.device("cuda", 0)
+    srv = InferenceServerConfig(model_path=model, dtype="bfloat16", context_length=1024, max_running_requests=32,
+                                num_continuous_decode_steps=decode_steps, random_seed=3)
+    eng = NativeInferenceEngine(srv, model_config=actor.model_config, device=dev, num_pages=pages)
+    eng.initialize(load_weights=False)
+    actor.connect_local_engine(eng)
+    ro = LocalInferenceEngine(InferenceEngineConfig(max_concurrent_rollouts=16, consumer_batch_size=8,
+                                                    max_head_offpolicyness=4), eng)
+    ro.initialize(train_data_parallel_size=1)
+    meta = WeightUpdateMeta.from_inproc()
+    actor.upload_weights(meta)
+    eng.set_version(0)
+    return actor, eng, ro, meta, dev
+
+
+def test_rollout_logprobs_match_trainer_recompute():
+    """Prefill + paged decode under hipGraph replay must score its own samples like the trainer does:
+    behaviour log-probs from the engine vs recomputed log-probs from the train engine (same weights)."""
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters
+    from areal_vllm_amd.workflow.rlvr import RLVRWorkflow
+
+    actor, eng, ro, meta, dev = _rollout_pair()
+    try:
+        g = GenerationHyperparameters(n_samples=2, max_new_tokens=96, temperature=1.0, stop_token_ids=[1])
+        wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: float(sum(ci) % 2), g, reward_in_process=True)
+        gen = torch.Generator().manual_seed(5)
+        prompts = [dict(input_ids=torch.randint(2, 4000, (n,), generator=gen).tolist())
+                   for n in (7, 40, 33, 90, 130, 17, 64, 255)]
+        batch = ro.rollout_batch(prompts, workflow=wf)
+        batch = {k: v.to(dev) if torch.is_tensor(v) else v for k, v in batch.items()}
+        assert batch["input_ids"].shape[0] == 16
+        lm = batch["loss_mask"].bool()
+        assert int(lm.sum()) > 16 * 40
+        assert torch.all(batch["versions"][lm] == 0)
+        prox = actor.compute_logp(batch)  # position t scores token t+1
+        behav = torch.roll(batch["logprobs"], -1, 1)
+        m = torch.roll(lm, -1, 1)
+        m[:, -1] = False
+        diff = (prox.float() - behav.float()).abs()[m]
+        assert float(diff.mean()) < 0.02, float(diff.mean())
+        assert float(diff.max()) < 0.25, float(diff.max())
+        # a full GRPO step on that batch and a weight push must change what the engine samples from
+        batch["prox_logp"] = prox
+        actor.compute_advantages(batch)
+        st = actor.ppo_update(batch)
+        assert math.isfinite(st[0]["grad_norm"]) and st[0]["grad_norm"] > 0
+        actor.upload_weights(meta)
+        ro.set_version(1)
+        assert torch.equal(eng.model.flat.flat, actor.model.flat.flat)
+        b2 = ro.rollout_batch(prompts[:2], workflow=wf)
+        assert torch.all(b2["versions"][b2["loss_mask"].bool()] == 1)
+    finally:
+        ro.destroy()
+        eng.destroy()
+        actor.destroy()
+
+
+def test_weight_update_interrupts_running_generation():
+    """Requests in flight when new weights arrive are aborted, re-issued by the client with their partial
+    output, and finish with tokens tagged by both weight versions."""
+    import asyncio
+    import threading
+    import time
+
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters
+    from areal_vllm_amd.api.io_struct import ModelRequest
+
+    actor, eng, ro, meta, dev = _rollout_pair(decode_steps=2)
+    try:
+        g = GenerationHyperparameters(n_samples=1, max_new_tokens=600, temperature=1.0, stop_token_ids=[])
+        reqs = [ModelRequest(rid=f"r{i}", input_ids=list(range(5 + i, 40 + i)), gconfig=g) for i in range(6)]
+        out = {}
+
+        def run():
+            async def go():
+                return await asyncio.gather(*[ro.agenerate(r) for r in reqs])
+            out["res"] = asyncio.run(go())
+
+        th = threading.Thread(target=run)
+        th.start()
+        deadline = time.time() + 60
+        while eng.metrics()["gen_tokens_total"] < 6 * 40 and time.time() < deadline:
+            time.sleep(0.005)
+        ro.pause()
+        actor.upload_weights(meta)
+        ro.set_version(1)
+        ro.resume()
+        th.join(timeout=120)
+        assert not th.is_alive()
+        for r in out["res"]:
+            assert len(r.output_tokens) == 600 == len(r.output_logprobs) == len(r.output_versions)
+            assert r.output_versions == sorted(r.output_versions)
+            assert set(r.output_versions) == {0, 1}, set(r.output_versions)
+        assert eng.metrics()["aborted"] >= 6
+    finally:
+        ro.destroy()
+        eng.destroy()
+        actor.destroy()
+
+
+def test_driver_smoke_entry():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+
+    entry.smoke()
