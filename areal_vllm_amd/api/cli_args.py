@@ -121,14 +121,15 @@ class DeepSpeedAutoTPEngineConfig:
 class NativeEngineConfig:
     """Knobs of the native ZeRO/TP/PP trainer (no counterpart in the reference)."""
 
-    zero_stage: int = field(default=1, metadata={"help": "1: shard optimizer state over DP (params/grads "
-                                                 "replicated; fits <=32B at 288 GB); 3: also shard params"})
-    grad_bucket_mb: int = field(default=512, metadata={"help": "reduce-scatter bucket size"})
     keep_logits: bool = field(default=True, metadata={"help": "keep bf16 logits for backward instead of "
                                                       "recomputing the LM head"})
     logprob_chunk: int = 8192
     sequence_parallel: bool = False
-    virtual_pipeline_parallel_size: Optional[int] = None
+    context_parallel_mode: str = field(default="ulysses", metadata={
+        "help": "what the `c` dimension of the allocation mode does: 'ulysses' (all-to-all between token and "
+                "head partitions, the reference's FSDP engine) or 'zigzag' (load-balanced token placement with "
+                "all-gathered K/V, the role of Megatron's context parallelism)",
+        "choices": ["ulysses", "zigzag"]})
 
 
 @dataclass

@@ -216,9 +216,14 @@ class NativeTrainEngine(TrainEngine):
             gradient_checkpointing=cfg.gradient_checkpointing,
         )
         if g.cp > 1:
-            from ..parallel.ulysses import UlyssesContext
+            if cfg.native.context_parallel_mode == "zigzag":
+                from ..parallel.context_parallel import ZigZagContext
 
-            self.model.sp = UlyssesContext(g.group("cp"), g.cp, g.coord.cp)
+                self.model.sp = ZigZagContext(g.group("cp"), g.cp, g.coord.cp)
+            else:
+                from ..parallel.ulysses import UlyssesContext
+
+                self.model.sp = UlyssesContext(g.group("cp"), g.cp, g.coord.cp)
         edp = max(1, (g.dp // g.ep) * g.cp)
         flat = self.model.flatten(pad_to=g.dp * g.cp, expert_pad_to=edp if g.ep > 1 else None)
         if cfg.init_from_scratch or not (cfg.path and os.path.isdir(cfg.path)):
@@ -345,7 +350,7 @@ class NativeTrainEngine(TrainEngine):
         mb_list = split_padded_tensor_dict_into_mb_list(input_, self.config.mb_spec, group=self.grid.group("dp"))
         align = 1
         if self.grid.cp > 1:
-            align = self.grid.cp
+            align = getattr(self.model.sp, "align", self.grid.cp)
         if self.grid.tp > 1 and self.config.native.sequence_parallel:
             align = math.lcm(align, self.grid.tp)
         mb_list = pad_mb_list(mb_list, pad_value=0.0, pad_to_maximum=self.config.pad_to_maximum, align_to=align)

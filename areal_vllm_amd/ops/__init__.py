@@ -8,6 +8,7 @@ from .attention import (  # noqa: F401
     decode_num_splits,
     flash_attn_varlen,
     flash_attn_varlen_qkv,
+    flash_attn_varlen_sep,
     paged_attention_decode,
     rope_and_cache_write_,
 )

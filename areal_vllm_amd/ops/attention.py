@@ -145,6 +145,51 @@ def _flash_bwd_hip(q, k, v, out, dout, lse, dq, dk, dv, cu_q, cu_k, max_k, scale
     )
 
 
+class _FlashVarlenSepFn(torch.autograd.Function):
+    """Attention with separate q [Tq, Hq, D] and k / v [Tk, Hkv, D] (views with contiguous heads), each
+    batch entry attending q rows cu_q[b]:cu_q[b+1] to keys cu_k[b]:cu_k[b+1]; the causal mask is aligned
+    to the bottom-right corner, i.e. the q rows are the LAST rows of their key range."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu_q, cu_k, max_q, max_k, scale, causal):
+        if L.use_hip(q):
+            out, lse = _flash_fwd_hip(q, k, v, cu_q, cu_k, max_q, scale, causal)
+        else:
+            out, lse = attention_varlen_ref(q, k, v, cu_q, cu_k, scale, causal)
+        ctx.save_for_backward(q, k, v, out, lse, cu_q, cu_k)
+        ctx.meta = (max_k, scale, causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, cu_q, cu_k = ctx.saved_tensors
+        max_k, scale, causal = ctx.meta
+        dout = dout.contiguous()
+        if L.use_hip(q):
+            dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+            dk = torch.zeros(k.shape, dtype=k.dtype, device=k.device)  # keys outside every range get 0
+            dv = torch.zeros(v.shape, dtype=v.dtype, device=v.device)
+            _flash_bwd_hip(q, k, v, out, dout, lse, dq, dk, dv, cu_q, cu_k, max_k, scale, causal)
+        else:
+            with torch.enable_grad():
+                q_ = q.detach().float().requires_grad_(True)
+                k_ = k.detach().float().requires_grad_(True)
+                v_ = v.detach().float().requires_grad_(True)
+                o_, _ = attention_varlen_ref(q_, k_, v_, cu_q, cu_k, scale, causal)
+                dq, dk, dv = torch.autograd.grad(o_, (q_, k_, v_), dout.float())
+            dq, dk, dv = dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+def flash_attn_varlen_sep(q, k, v, cu_q, cu_k, max_q: int, max_k: int, scale: Optional[float] = None,
+                          causal: bool = True) -> torch.Tensor:
+    """Differentiable varlen attention with separate q and k / v streams (context parallelism: a chunk
+    of queries against the keys of its sequences up to the chunk's end)."""
+    if scale is None:
+        scale = 1.0 / math.sqrt(q.shape[-1])
+    return _FlashVarlenSepFn.apply(q, k, v, cu_q, cu_k, int(max_q), int(max_k), float(scale), causal)
+
+
 def flash_attn_varlen(q, k, v, cu_q, cu_k, max_q, scale=None, causal=True):
     """Forward-only varlen attention with separate q / k / v (prefill with a cached prefix:
     k/v longer than q, causal mask aligned bottom-right). Returns (out, lse)."""

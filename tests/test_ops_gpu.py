@@ -142,6 +142,31 @@ def test_flash_attn_prefix_extend():
     _close(lse.cpu(), lse_ref, 2e-2, 1e-2, "lse")
 
 
+def test_flash_attn_separate_streams_fwd_bwd():
+    """q chunk vs longer key ranges out of a shared K/V stream (context parallelism): strided views,
+    bottom-right causal mask, gradients for q and for the used slice of k / v."""
+    torch.manual_seed(14)
+    D, Hq, Hkv = 128, 12, 2
+    lq, lk = [130, 257, 64], [300, 257, 200]
+    cu_q = torch.tensor([0] + np.cumsum(lq).tolist(), dtype=torch.int32, device=DEV)
+    cu_k = torch.tensor([0] + np.cumsum(lk).tolist(), dtype=torch.int32, device=DEV)
+    qkv = (0.5 * torch.randn(sum(lq), Hq + 2 * Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
+    kv = (0.5 * torch.randn(sum(lk) + 40, 2 * Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
+    q, k, v = qkv[:, :Hq], kv[8:8 + sum(lk), :Hkv], kv[8:8 + sum(lk), Hkv:]
+    out = ops.flash_attn_varlen_sep(q, k, v, cu_q, cu_k, max(lq), max(lk))
+    g = torch.randn_like(out)
+    out.backward(g)
+    qf = qkv.detach().float().cpu().requires_grad_(True)
+    kvf = kv.detach().float().cpu().requires_grad_(True)
+    ref, _ = A.attention_varlen_ref(qf[:, :Hq], kvf[8:8 + sum(lk), :Hkv], kvf[8:8 + sum(lk), Hkv:], cu_q.cpu(),
+                                    cu_k.cpu(), 1.0 / math.sqrt(D), True)
+    ref.backward(g.float().cpu())
+    _close(out.cpu(), ref, 2e-2, 2e-2, "sep out")
+    _close(qkv.grad[:, :Hq].cpu(), qf.grad[:, :Hq], 3e-2, 5e-2, "sep dq")
+    _close(kv.grad.cpu(), kvf.grad, 3e-2, 5e-2, "sep dkv")
+    assert float(qkv.grad[:, Hq:].abs().max()) == 0.0 and float(kv.grad[:8].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("Hq,Hkv,D", [(12, 2, 128), (28, 4, 128), (8, 8, 128), (16, 2, 64)])
 @pytest.mark.parametrize("nsplit", [1, 4])
 def test_paged_decode_and_cache_write(Hq, Hkv, D, nsplit):

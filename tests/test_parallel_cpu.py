@@ -59,6 +59,8 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
                             optimizer=OptimizerConfig(lr=1e-2, weight_decay=0.01, gradient_clipping=1.0,
                                                       warmup_steps_proportion=0.0, lr_scheduler_type="constant"),
                             mb_spec=MicroBatchSpec(n_mbs=n_mbs, max_tokens_per_mb=4096))
+    strategy_kwargs = dict(strategy_kwargs)
+    cfg.native.context_parallel_mode = strategy_kwargs.pop("_cp_mode", "ulysses")
     eng = NativeTrainEngine(cfg)
     st = ParallelStrategy(**strategy_kwargs)
     eng.create_process_group(st)
@@ -145,6 +147,9 @@ def _compare(ref, out, atol=2e-5):
     ("dp2pp2", 4, dict(data_parallel_size=2, pipeline_parallel_size=2), 2),
     ("dp2tp2", 4, dict(data_parallel_size=2, tensor_parallel_size=2), 1),
     ("cp2pp2", 4, dict(context_parallel_size=2, pipeline_parallel_size=2), 2),
+    ("zigzag2", 2, dict(context_parallel_size=2, _cp_mode="zigzag"), 2),
+    ("zigzag4", 4, dict(context_parallel_size=4, _cp_mode="zigzag"), 1),
+    ("zigzag2tp2", 4, dict(context_parallel_size=2, tensor_parallel_size=2, _cp_mode="zigzag"), 2),
 ])
 def test_layout_matches_single_process(dense_reference, name, world, kw, n_mbs):
     d, init, ref = dense_reference
