@@ -6,7 +6,14 @@ Local ``.jsonl`` / ``.json`` / ``.parquet`` files and directories work without n
 """
 from typing import Optional
 
-VALID_DATASETS = ["gsm8k", "clevr_count_70k", "geometry3k"]
+VALID_DATASETS = ["gsm8k", "clevr_count_70k", "geometry3k", "countdown"]
+_CUSTOM = {}
+
+
+def register_dataset(key: str, fn) -> None:
+    """Serve every path containing `key` with `fn(path=, split=, type=, rank=, world_size=, tokenizer=,
+    processor=, max_length=, **kw)` - how example scripts plug their own data in."""
+    _CUSTOM[key] = fn
 
 
 def load_raw_dataset(path: str, split: Optional[str] = None, name: Optional[str] = None):
@@ -37,6 +44,15 @@ def get_custom_dataset(path: str, rank: int, world_size: int, type: str = "sft",
         from .synthetic import get_synthetic_dataset
 
         return get_synthetic_dataset(path, rank, world_size, type=type, split=split, **kwargs)
+    for key, fn in _CUSTOM.items():
+        if key in path:
+            return fn(path=path, split=split, type=type, rank=rank, world_size=world_size, tokenizer=tokenizer,
+                      processor=processor, max_length=max_length, **kwargs)
+    if "countdown" in path and type == "rl":
+        from .countdown import get_countdown_rl_dataset
+
+        return get_countdown_rl_dataset(path=path, split=split, tokenizer=tokenizer, rank=rank, world_size=world_size,
+                                        max_length=max_length, **kwargs)
     if "gsm8k" in path:
         from . import gsm8k as m
 

@@ -245,7 +245,8 @@ class PPOActor:
             for k2 in list(global_stats.keys()):
                 if k2.endswith(k):
                     global_stats.pop(k2)
-        for key in ["rewards", "tot_rewards", "kl_rewards", "versions", "returns"]:
+        for key in ["rewards", "tot_rewards", "kl_rewards", "versions", "returns", "begin_of_trajectory",
+                    *(cfg.log_agent_stats_keys if cfg.log_agent_stats else [])]:
             data.pop(key, None)
         self.engine.train()
         mb_inputs = split_padded_tensor_dict_into_mb_list(data, MicroBatchSpec(n_mbs=cfg.ppo_n_minibatches))

@@ -390,3 +390,92 @@ def test_wrapper_and_printing():
     wrap(d2, Src(), transform=lambda *a, **k: ("via", wrap_get_method(k)(*a, **wrap_remove_meta(dict(k)))))
     assert d2.f(1) == ("via", 2)
     assert "a" in tabulate_stats({"a": 1.0, "b": 2.0})
+
+
+# ------------------------------------------------------------------- tool-agent workflow
+class _CharTok:
+    """Byte-level tokenizer: ids are byte values shifted by 3 (0 pad, 1 eos)."""
+    eos_token_id, pad_token_id = 1, 0
+
+    def encode(self, text):
+        return [b + 3 for b in text.encode()]
+
+    def decode(self, ids, **kw):
+        return bytes(i - 3 for i in ids if i >= 3).decode(errors="ignore")
+
+    def apply_chat_template(self, messages, tools=None, tokenize=True, add_generation_prompt=True, **kw):
+        text = "".join(f"<{m['role']}>{m['content']}" for m in messages) + "<assistant>"
+        return self.encode(text) if tokenize else text
+
+
+class _ScriptedEngine:
+    """First turn of an episode calls the search tool, the second one answers from the observation."""
+
+    def __init__(self):
+        self.version = 0
+        self.seen_rids = []
+
+    def get_version(self):
+        return self.version
+
+    async def agenerate(self, req):
+        from areal_vllm_amd.api.io_struct import ModelResponse
+
+        tok = _CharTok()
+        self.seen_rids.append(req.rid)
+        ctx = tok.decode(req.input_ids)
+        if "<tool_response>" not in ctx:
+            text = 'let me look <tool_call>\n{"name": "search", "arguments": {"query": "capital France"}}\n</tool_call>'
+        else:
+            text = "<answer>Paris</answer>" if "Paris" in ctx else "<answer>unknown</answer>"
+        ids = tok.encode(text)[: req.gconfig.max_new_tokens]
+        self.version += 1
+        return ModelResponse(input_tokens=list(req.input_ids), output_tokens=ids, output_logprobs=[-0.1] * len(ids),
+                             output_versions=[self.version] * len(ids), stop_reason="stop")
+
+
+def test_tool_agent_workflow_masks_observations_and_scores_answer():
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters
+    from areal_vllm_amd.impl.environment.local_search_env import BM25Index, LocalSearchEnv, f1_answer_reward
+    from areal_vllm_amd.workflow.tool_agent import ToolAgentWorkflow
+
+    index = BM25Index([{"url": "doc://fr", "title": "France", "text": "Paris is the capital of France."},
+                       {"url": "doc://de", "title": "Germany", "text": "Berlin is the capital of Germany."}])
+    assert index.search("capital of France")[0] == 0
+    eng = _ScriptedEngine()
+    keys = ["num_llm_gens", "num_tool_calls", "num_success_search_queries", "score"]
+    wf = ToolAgentWorkflow(f1_answer_reward, GenerationHyperparameters(n_samples=2, max_new_tokens=256), _CharTok(),
+                           env_factory=lambda: LocalSearchEnv(index), max_turns=4, agent_stats_keys=keys)
+    data = dict(messages=[{"role": "user", "content": "What is the capital of France?"}], answer=["Paris"])
+    batch = asyncio.run(wf.arun_episode(eng, data))
+    assert batch["input_ids"].shape[0] == 2 and torch.all(batch["rewards"] == 1.0)
+    tok = _CharTok()
+    for b in range(2):
+        n = int(batch["attention_mask"][b].sum())
+        ids, lm, ver = batch["input_ids"][b, :n].tolist(), batch["loss_mask"][b, :n].bool(), batch["versions"][b, :n]
+        trained = tok.decode([t for t, m in zip(ids, lm.tolist()) if m])
+        untrained = tok.decode([t for t, m in zip(ids, lm.tolist()) if not m])
+        assert "<tool_call>" in trained and "<answer>Paris</answer>" in trained
+        assert "<tool_response>" in untrained and "Paris is the capital" in untrained and "tool_call" not in untrained
+        assert torch.all(ver[~lm] == -1) and len(set(ver[lm].tolist())) == 2  # two turns, two weight versions
+        assert float(batch["num_llm_gens"][b]) == 2 and float(batch["num_tool_calls"][b]) == 1
+        assert float(batch["num_success_search_queries"][b]) == 1
+    # both turns of an episode share one request id (prefix-cache affinity)
+    assert len(set(eng.seen_rids)) == 2 and len(eng.seen_rids) == 4
+
+
+def test_countdown_dataset_and_reward():
+    from areal_vllm_amd.dataset import get_custom_dataset
+    from areal_vllm_amd.dataset.countdown import generate
+    from areal_vllm_amd.reward import get_custom_reward_fn
+
+    rows = generate(40, seed=3)
+    fn = get_custom_reward_fn("data/countdown/train.jsonl")
+    for r in rows:
+        good = f"<think>..</think><answer> {r['solution']} </answer>"
+        assert fn("", good, [], [], numbers=r["numbers"], target=r["target"]) == 1.0
+        assert fn("", "<answer> 1 + 1 </answer>", [], [], numbers=r["numbers"], target=r["target"]) == 0.1
+        assert fn("", "__import__('os')", [], [], numbers=r["numbers"], target=r["target"]) == 0.0
+    d0 = get_custom_dataset("countdown", 0, 2, type="rl", split="train", n_rows=64)
+    d1 = get_custom_dataset("countdown", 1, 2, type="rl", split="train", n_rows=64)
+    assert len(d0) == len(d1) == 32 and d0[0]["query_id"] != d1[0]["query_id"]
