@@ -73,7 +73,7 @@ class ModelRunner:
         if cfg.n_experts > 0:
             h = blk.mlp(x, None, self.model.ep_group)
         else:
-            h = F.linear(ops.swiglu(F.linear(x, blk.mlp.gate_up)), blk.mlp.down)
+            h = F.linear(ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act), blk.mlp.down)
         if self.model.tp_size > 1:
             torch.distributed.all_reduce(h, group=self.model.tp_group)
         return h, residual

@@ -28,6 +28,7 @@ class ModelConfig:
     qkv_bias: bool = True
     qk_norm: bool = False  # per-head RMSNorm on q and k (Qwen3)
     gemma_norm: bool = False  # (1 + w) RMSNorm weights and sqrt(H) embedding scale (Gemma)
+    hidden_act: str = "silu"  # gate activation of the MLP: "silu" (SwiGLU) or "gelu_tanh" (GeGLU, Gemma)
     is_critic: bool = False  # value head [1, H] instead of the LM head
     # mixture of experts (0 = dense)
     n_experts: int = 0
@@ -78,8 +79,11 @@ class ModelConfig:
         nkv = d.get("num_key_value_heads", nq)
         hd = d.get("head_dim") or H // nq
         fam_bias = {"qwen2": True, "qwen2_moe": True}
-        rs = d.get("rope_scaling") or {}
+        # transformers >= 5 nests the rotary settings in `rope_parameters`
+        rp = d.get("rope_parameters") or {}
+        rs = d.get("rope_scaling") or rp
         scaling = float(rs.get("factor", 1.0)) if rs.get("type", rs.get("rope_type")) == "linear" else 1.0
+        act = d.get("hidden_activation") or d.get("hidden_act") or "silu"
         cfg = cls(
             family=mt,
             vocab_size=d["vocab_size"],
@@ -90,13 +94,14 @@ class ModelConfig:
             head_dim=hd,
             intermediate_size=d.get("intermediate_size", 4 * H),
             rms_norm_eps=d.get("rms_norm_eps", 1e-6),
-            rope_theta=float(d.get("rope_theta", 10000.0)),
+            rope_theta=float(d.get("rope_theta") or rp.get("rope_theta") or 10000.0),
             rope_scaling=scaling,
             max_position_embeddings=d.get("max_position_embeddings", 32768),
             tie_word_embeddings=bool(d.get("tie_word_embeddings", False)),
             qkv_bias=bool(d.get("attention_bias", fam_bias.get(mt, False))),
             qk_norm=mt in ("qwen3", "qwen3_moe"),
             gemma_norm=mt in ("gemma", "gemma2"),
+            hidden_act="gelu_tanh" if act in ("gelu_pytorch_tanh", "gelu_tanh", "gelu") else "silu",
             is_critic=is_critic,
             n_experts=d.get("num_local_experts", d.get("num_experts", 0)) or 0,
             n_experts_per_tok=d.get("num_experts_per_tok", 0) or 0,
@@ -133,15 +138,18 @@ class ModelConfig:
             "intermediate_size": self.intermediate_size,
             "rms_norm_eps": self.rms_norm_eps,
             "rope_theta": self.rope_theta,
+            "rope_parameters": {"rope_type": "default", "rope_theta": self.rope_theta},
             "max_position_embeddings": self.max_position_embeddings,
             "tie_word_embeddings": self.tie_word_embeddings,
             "attention_bias": self.qkv_bias,
-            "hidden_act": "silu",
+            "hidden_act": "gelu_pytorch_tanh" if self.hidden_act == "gelu_tanh" else "silu",
             "torch_dtype": "bfloat16",
             "bos_token_id": self.bos_token_id,
             "eos_token_id": self.eos_token_id,
             "pad_token_id": self.pad_token_id,
         }
+        if self.hidden_act == "gelu_tanh":
+            d["hidden_activation"] = "gelu_pytorch_tanh"
         if self.n_experts:
             d["num_local_experts" if self.family == "mixtral" else "num_experts"] = self.n_experts
             d["num_experts_per_tok"] = self.n_experts_per_tok

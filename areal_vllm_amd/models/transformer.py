@@ -157,16 +157,17 @@ class Attention(nn.Module):
 
 
 class MLP(nn.Module):
-    def __init__(self, hidden, inter, tp_size, dtype, device):
+    def __init__(self, hidden, inter, tp_size, dtype, device, act: str = "silu"):
         super().__init__()
         assert inter % tp_size == 0
+        self.act = act
         f = inter // tp_size
         self.gate_up = nn.Parameter(torch.empty(2 * f, hidden, dtype=dtype, device=device))
         self.down = nn.Parameter(torch.empty(hidden, f, dtype=dtype, device=device))
 
     def forward(self, x, tp_group):
         x = _AllReduceBwd.apply(x, tp_group)
-        h = ops.swiglu(ops.linear(x, self.gate_up))
+        h = ops.swiglu(ops.linear(x, self.gate_up), self.act)
         return _AllReduceFwd.apply(ops.linear(h, self.down), tp_group)
 
 
@@ -234,7 +235,7 @@ class Block(nn.Module):
         if cfg.n_experts > 0:
             self.mlp = MoE(cfg, tp_size, dtype, device, ep_size, ep_rank)
         else:
-            self.mlp = MLP(cfg.hidden_size, cfg.intermediate_size, tp_size, dtype, device)
+            self.mlp = MLP(cfg.hidden_size, cfg.intermediate_size, tp_size, dtype, device, cfg.hidden_act)
 
     def forward(self, h, residual, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None, ep_group=None):
         cfg = self.cfg

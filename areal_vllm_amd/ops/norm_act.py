@@ -102,15 +102,22 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, residual: 
 
 
 # -------------------------------------------------------------------------------- SwiGLU
-def _swiglu_ref(gu):
+GLU_ACTS = {"silu": 0, "gelu_tanh": 1, "gelu_pytorch_tanh": 1}
+
+
+def _act_ref(g, act: int):
+    return torch.nn.functional.silu(g) if act == 0 else torch.nn.functional.gelu(g, approximate="tanh")
+
+
+def _swiglu_ref(gu, act: int = 0):
     F = gu.shape[-1] // 2
     g, u = gu[..., :F].float(), gu[..., F:].float()
-    return (torch.nn.functional.silu(g) * u).to(gu.dtype)
+    return (_act_ref(g, act) * u).to(gu.dtype)
 
 
 class _SwiGLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, gu):
+    def forward(ctx, gu, act):
         F = gu.shape[-1] // 2
         gu2 = gu.reshape(-1, 2 * F)
         if not gu2.is_contiguous():
@@ -118,12 +125,12 @@ class _SwiGLUFn(torch.autograd.Function):
         if L.use_hip(gu2):
             assert gu2.dtype == torch.bfloat16
             out = torch.empty(gu2.shape[0], F, dtype=gu.dtype, device=gu.device)
-            L.check(L.lib().areal_swiglu_fwd(L.ptr(gu2), L.ptr(out), L.c_int64(gu2.shape[0]), L.c_int(F),
-                                             L.stream_ptr()), "swiglu_fwd")
+            L.check(L.lib().areal_glu_fwd(L.ptr(gu2), L.ptr(out), L.c_int64(gu2.shape[0]), L.c_int(F), L.c_int(act),
+                                          L.stream_ptr()), "glu_fwd")
         else:
-            out = _swiglu_ref(gu2)
+            out = _swiglu_ref(gu2, act)
         ctx.save_for_backward(gu2)
-        ctx.shape = gu.shape
+        ctx.shape, ctx.act = gu.shape, act
         return out.view(*gu.shape[:-1], F)
 
     @staticmethod
@@ -133,21 +140,22 @@ class _SwiGLUFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, F).contiguous()
         if L.use_hip(gu2):
             dgu = torch.empty_like(gu2)
-            L.check(L.lib().areal_swiglu_bwd(L.ptr(dy2), L.ptr(gu2), L.ptr(dgu), L.c_int64(gu2.shape[0]),
-                                             L.c_int(F), L.stream_ptr()), "swiglu_bwd")
+            L.check(L.lib().areal_glu_bwd(L.ptr(dy2), L.ptr(gu2), L.ptr(dgu), L.c_int64(gu2.shape[0]),
+                                          L.c_int(F), L.c_int(ctx.act), L.stream_ptr()), "glu_bwd")
         else:
-            g, u = gu2[:, :F].float(), gu2[:, F:].float()
-            sig = torch.sigmoid(g)
-            d = dy2.float()
-            dg = d * u * (sig * (1 + g * (1 - sig)))
-            du = d * g * sig
-            dgu = torch.cat([dg, du], -1).to(gu2.dtype)
-        return dgu.view(ctx.shape)
+            with torch.enable_grad():
+                g = gu2[:, :F].float().detach().requires_grad_(True)
+                a = _act_ref(g, ctx.act)
+                (da,) = torch.autograd.grad(a.sum(), g)
+            u, d = gu2[:, F:].float(), dy2.float()
+            dgu = torch.cat([d * u * da, d * a.detach()], -1).to(gu2.dtype)
+        return dgu.view(ctx.shape), None
 
 
-def swiglu(gate_up: torch.Tensor) -> torch.Tensor:
-    """out = silu(gate_up[..., :F]) * gate_up[..., F:] for the fused gate|up projection."""
-    return _SwiGLUFn.apply(gate_up)
+def swiglu(gate_up: torch.Tensor, act: str = "silu") -> torch.Tensor:
+    """out = act(gate_up[..., :F]) * gate_up[..., F:] for the fused gate|up projection; `act` is "silu"
+    (SwiGLU) or "gelu_tanh" (GeGLU, Gemma)."""
+    return _SwiGLUFn.apply(gate_up, GLU_ACTS[act])
 
 
 # ---------------------------------------------------------------------------------- RoPE

@@ -208,8 +208,26 @@ extern "C" int areal_rmsnorm_bwd(const void* dy, const void* x, const void* w, c
 }
 
 // ----------------------------------------------------------------------------------
-// SwiGLU on a fused [T, 2F] gate|up projection: out[t, f] = silu(gu[t, f]) * gu[t, F + f]
+// Gated linear unit on a fused [T, 2F] gate|up projection: out[t, f] = act(gu[t, f]) * gu[t, F + f]
+// ACT 0: SiLU (SwiGLU - Llama / Qwen / Mistral); ACT 1: tanh-approximated GELU (GeGLU - Gemma).
 // ----------------------------------------------------------------------------------
+template <int ACT>
+DEVINL void glu_act(float g, float& a, float& da) {
+  if (ACT == 0) {
+    const float sig = 1.f / (1.f + __expf(-g));
+    a = g * sig;
+    da = sig * (1.f + g * (1.f - sig));
+  } else {
+    const float k = 0.7978845608028654f, c = 0.044715f;
+    const float inner = k * (g + c * g * g * g);
+    const float e = __expf(-2.f * fabsf(inner));       // tanh via exp, stable for large |inner|
+    const float th = copysignf((1.f - e) / (1.f + e), inner);
+    a = 0.5f * g * (1.f + th);
+    da = 0.5f * (1.f + th) + 0.5f * g * (1.f - th * th) * k * (1.f + 3.f * c * g * g);
+  }
+}
+
+template <int ACT>
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu,
                                                          bf16_t* __restrict__ out, int64_t T, int F) {
   const int nvec_row = F >> 3;
@@ -221,14 +239,15 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float gf = bf2f(g[j]);
-      const float s = gf / (1.f + __expf(-gf));
-      o[j] = f2bf(s * bf2f(u[j]));
+      float a, da;
+      glu_act<ACT>(bf2f(g[j]), a, da);
+      o[j] = f2bf(a * bf2f(u[j]));
     }
     st8(out + t * F + c * 8, o);
   }
 }
 
+template <int ACT>
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dy,
                                                          const bf16_t* __restrict__ gu,
                                                          bf16_t* __restrict__ dgu, int64_t T, int F) {
@@ -242,11 +261,11 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
     bf16x8 dg, du;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float gf = bf2f(g[j]), uf = bf2f(u[j]), df = bf2f(d[j]);
-      const float sig = 1.f / (1.f + __expf(-gf));
-      const float silu = gf * sig;
-      dg[j] = f2bf(df * uf * (sig * (1.f + gf * (1.f - sig))));
-      du[j] = f2bf(df * silu);
+      const float uf = bf2f(u[j]), df = bf2f(d[j]);
+      float a, da;
+      glu_act<ACT>(bf2f(g[j]), a, da);
+      dg[j] = f2bf(df * uf * da);
+      du[j] = f2bf(df * a);
     }
     st8(dgu + t * 2 * F + c * 8, dg);
     st8(dgu + t * 2 * F + F + c * 8, du);
@@ -260,23 +279,37 @@ static inline int ew_grid(int64_t total, int block) {
   return (int)g;
 }
 
-extern "C" int areal_swiglu_fwd(const void* gu, void* out, int64_t T, int F, hipStream_t st) {
+extern "C" int areal_glu_fwd(const void* gu, void* out, int64_t T, int F, int act, hipStream_t st) {
   if (F % 8 != 0) return -1;
+  if (act != 0 && act != 1) return -2;
   if (T == 0) return 0;
-  const int gx = (F / 8 + 255) / 256;
-  const int gy = (int)(T < 8192 ? T : 8192);
-  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)gu, (bf16_t*)out, T, F);
+  const dim3 grid((F / 8 + 255) / 256, (int)(T < 8192 ? T : 8192));
+  if (act == 0)
+    hipLaunchKernelGGL(swiglu_fwd_kernel<0>, grid, dim3(256), 0, st, (const bf16_t*)gu, (bf16_t*)out, T, F);
+  else
+    hipLaunchKernelGGL(swiglu_fwd_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)gu, (bf16_t*)out, T, F);
   return (int)hipGetLastError();
+}
+extern "C" int areal_glu_bwd(const void* dy, const void* gu, void* dgu, int64_t T, int F, int act,
+                             hipStream_t st) {
+  if (F % 8 != 0) return -1;
+  if (act != 0 && act != 1) return -2;
+  if (T == 0) return 0;
+  const dim3 grid((F / 8 + 255) / 256, (int)(T < 8192 ? T : 8192));
+  if (act == 0)
+    hipLaunchKernelGGL(swiglu_bwd_kernel<0>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)gu,
+                       (bf16_t*)dgu, T, F);
+  else
+    hipLaunchKernelGGL(swiglu_bwd_kernel<1>, grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)gu,
+                       (bf16_t*)dgu, T, F);
+  return (int)hipGetLastError();
+}
+extern "C" int areal_swiglu_fwd(const void* gu, void* out, int64_t T, int F, hipStream_t st) {
+  return areal_glu_fwd(gu, out, T, F, 0, st);
 }
 extern "C" int areal_swiglu_bwd(const void* dy, const void* gu, void* dgu, int64_t T, int F,
                                 hipStream_t st) {
-  if (F % 8 != 0) return -1;
-  if (T == 0) return 0;
-  const int gx = (F / 8 + 255) / 256;
-  const int gy = (int)(T < 8192 ? T : 8192);
-  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(gx, gy), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)gu,
-                     (bf16_t*)dgu, T, F);
-  return (int)hipGetLastError();
+  return areal_glu_bwd(dy, gu, dgu, T, F, 0, st);
 }
 
 // ----------------------------------------------------------------------------------

@@ -67,14 +67,16 @@ def test_rmsnorm_fwd_bwd(T, H, with_res):
 
 
 @pytest.mark.parametrize("T,F", [(5, 8960), (1000, 8960), (77, 256)])
-def test_swiglu(T, F):
+@pytest.mark.parametrize("act", ["silu", "gelu_tanh"])
+def test_swiglu(T, F, act):
     torch.manual_seed(1)
-    gu = torch.randn(T, 2 * F, device=DEV).bfloat16().requires_grad_(True)
-    out = ops.swiglu(gu)
+    gu = (3.0 * torch.randn(T, 2 * F, device=DEV)).bfloat16().requires_grad_(True)
+    out = ops.swiglu(gu, act)
     g = torch.randn_like(out)
     out.backward(g)
     guf = gu.detach().float().requires_grad_(True)
-    ref = torch.nn.functional.silu(guf[:, :F]) * guf[:, F:]
+    fn = torch.nn.functional.silu if act == "silu" else (lambda x: torch.nn.functional.gelu(x, approximate="tanh"))
+    ref = fn(guf[:, :F]) * guf[:, F:]
     ref.backward(g.float())
     _close(out, ref, 1e-2, 1e-2, "swiglu")
     _close(gu.grad, guf.grad, 2e-2, 2e-2, "dswiglu")
