@@ -23,6 +23,9 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 DEVINL f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// v_exp_f32 directly: exp2f() expands to a denormal-safe sequence (scale, v_exp, ldexp, compare) that the
+// compiler then guards with per-element branches; softmax probabilities do not need denormal results.
+DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 DEVINL int swz_off(int row, int ch) {  // byte offset of 16-byte chunk `ch` of `row`
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
@@ -49,25 +52,29 @@ DEVINL void lds_row_write(char* tile, int row, int ch, bf16x8 v) {
 }
 
 // =====================================================================================
-// Forward. grid: (q tiles of 128 rows, Hq, B). block: 256 threads = 4 waves x 32 q rows.
+// Forward. 1-D grid over (q-tile rank, sequence, head). block: 256 threads = 4 waves x 32 q rows.
 // KV tile = 64 keys. D = 128.
 // =====================================================================================
 __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     bf16_t* __restrict__ o, float* __restrict__ lse, const int* __restrict__ cu_q,
     const int* __restrict__ cu_k, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-    int64_t o_stride, int Hq, int Hkv, int total_q, float scale_log2, int causal) {
+    int64_t o_stride, int Hq, int Hkv, int nbatch, int total_q, float scale_log2, int causal) {
   constexpr int D = 128;
   __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 256];
   char* ks = smem;
   char* vs = smem + 64 * 256;
 
-  const int b = blockIdx.z, head = blockIdx.y;
+  // 1-D grid, query-tile rank first: rank 0 is the LAST (heaviest under causal masking) tile of every
+  // (sequence, head), so heavy workgroups of all sequences start first and light ones fill the tail.
+  const int n_bh = Hq * nbatch;
+  const int rank = blockIdx.x / n_bh, bh = blockIdx.x - rank * n_bh;
+  const int b = bh / Hq, head = bh - b * Hq;
   const int q_beg = cu_q[b], q_len = cu_q[b + 1] - q_beg;
   const int k_beg = cu_k[b], k_len = cu_k[b + 1] - k_beg;
   const int ntile_q = (q_len + 127) / 128;
-  if ((int)blockIdx.x >= ntile_q) return;
-  const int qt = ntile_q - 1 - blockIdx.x;  // heaviest (latest) tiles first
+  if (rank >= ntile_q) return;
+  const int qt = ntile_q - 1 - rank;
   const int kvh = head / (Hq / Hkv);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hf = lane >> 5, gl = lane & 15, grp = lane >> 4;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
-    const float alpha = (mn == -INFINITY) ? 1.f : exp2f(m - mn);  // m=-inf -> 0
+    const float alpha = (mn == -INFINITY) ? 1.f : fast_exp2(m - mn);  // m=-inf -> 0
     m = mn;
     float ls = 0.f;
     bf16x8 pf[4];
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const float pr = (m == -INFINITY) ? 0.f : exp2f(sacc[kb][j] - m);
+        const float pr = (m == -INFINITY) ? 0.f : fast_exp2(sacc[kb][j] - m);
         ls += pr;
         pf[2 * kb + (j >> 3)][j & 7] = f2bf(pr);
       }
@@ -220,17 +227,17 @@ extern "C" int areal_flash_fwd(const void* q, const void* k, const void* v, void
   if (Hq % Hkv != 0) return -2;
   if ((q_stride | k_stride | v_stride | o_stride) % 8 != 0) return -3;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 != 0) return -4;
-  dim3 grid((max_q + 127) / 128, Hq, B), block(256);
+  dim3 grid((unsigned)(((max_q + 127) / 128) * Hq * B)), block(256);
   hipLaunchKernelGGL(flash_fwd_kernel, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
                      (const bf16_t*)v, (bf16_t*)o, lse, cu_q, cu_k, q_stride, k_stride, v_stride,
-                     o_stride, Hq, Hkv, total_q, softmax_scale * 1.4426950408889634f, causal);
+                     o_stride, Hq, Hkv, B, total_q, softmax_scale * 1.4426950408889634f, causal);
   return (int)hipGetLastError();
 }
 
 // =====================================================================================
 // Backward.
 //  pre : delta[h, t] = sum_d dO[t, h, d] * O[t, h, d]
-//  main: grid (key blocks of 128, Hkv, B); block 256 threads = 4 waves x 32 keys. Each wave
+//  main: 1-D grid over (key block of 128, sequence, kv head); block 256 threads = 4 waves x 32 keys. Each wave
 //        keeps its K / V fragments and the dK^T / dV^T accumulators in registers and sweeps
 //        the query heads of the GQA group x 32-row query slices. dQ goes out through fp32
 //        atomics into dq_acc [Tq, Hq, D].
@@ -261,22 +268,32 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
     float* __restrict__ dq_acc, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, int64_t q_stride, int64_t k_stride,
     int64_t v_stride, int64_t do_stride, int64_t dk_stride, int64_t dv_stride, int Hq, int Hkv,
-    int total_q, float softmax_scale, int causal) {
+    int nbatch, int total_q, float softmax_scale, int causal) {
   constexpr int D = 128;
   // LDS: Q tile [32][256B] | dO tile [32][256B] | K tile [128][256B] | dS^T [128 keys][32 q] bf16
-  //      | lse[32] f32 | delta[32] f32
+  //      | lse[32] f32 | delta[32] f32. dS^T rows are padded from 64 to 72 bytes: with a 64-byte stride
+  //      the 8-byte writes of lanes r and r+4 land in the same banks (8-way conflict), 72 spreads the
+  //      32 rows of a wave over all 64 banks.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* qs = smem;
   char* dos = qs + 32 * 256;
   char* kts = dos + 32 * 256;
-  char* dss = kts + 128 * 256;           // [128][64 B]
-  float* lse_s = reinterpret_cast<float*>(dss + 128 * 64);
+  constexpr int DSS = 72;                // dS^T row stride in bytes
+  char* dss = kts + 128 * 256;           // [128][DSS]
+  float* lse_s = reinterpret_cast<float*>(dss + 128 * DSS);
   float* dl_s = lse_s + 32;
 
-  const int b = blockIdx.z, kvh = blockIdx.y;
+  // 1-D grid ordered by key block first: under causal masking the work of a workgroup falls with its
+  // key-block index (later keys are seen by fewer queries), so the heaviest workgroups of ALL sequences
+  // are dispatched first and the light ones fill the tail (longest-processing-time-first scheduling;
+  // a (block, head, sequence) grid leaves CUs idle behind each sequence's heavy blocks).
+  const int n_bh = Hkv * nbatch;
+  const int bid = blockIdx.x;
+  const int kblk = bid / n_bh, bh = bid - kblk * n_bh;
+  const int b = bh / Hkv, kvh = bh - b * Hkv;
   const int q_beg = cu_q[b], q_len = cu_q[b + 1] - q_beg;
   const int k_beg = cu_k[b], k_len = cu_k[b + 1] - k_beg;
-  const int kb0 = blockIdx.x * 128;
+  const int kb0 = kblk * 128;
   if (kb0 >= k_len) return;
   const int G = Hq / Hkv;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -376,7 +393,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
         sacc = mfma32(qa, kf[s], sacc);
         pacc = mfma32(da, vf[s], pacc);
       }
-      // ---- P = exp2(S*c - lse), dS = P * (dP - delta)
+      // ---- P = exp2(S*c - lse), dS = P * (dP - delta). Only slices that touch the end of the key range or
+      //      the causal diagonal need per-element masking (wave-uniform test).
+      const bool need_mask = (kb0 + 128 > k_len) || (causal && (kb0 + 127 > qs0 + shift));
       bf16x8 pfr[2], dsfr[2];
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -387,15 +406,16 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
         for (int j = 0; j < 4; ++j) {
           const int reg = 4 * g4 + j;
           const int qrow = qs0 + 8 * g4 + 4 * hf + j;
-          float p = exp2f(sacc[reg] * scale_log2 - l4[j]);
-          if (my_key >= k_len || (causal && my_key > qrow + shift)) p = 0.f;
+          float sv = sacc[reg] * scale_log2 - l4[j];  // lse = +inf on rows past the end -> p = 0
+          if (need_mask && (my_key >= k_len || (causal && my_key > qrow + shift))) sv = -INFINITY;
+          const float p = fast_exp2(sv);
           const float ds = p * (pacc[reg] - d4[j]);
           pfr[reg >> 3][reg & 7] = f2bf(p);
           dsfr[reg >> 3][reg & 7] = f2bf(ds);
           dsw[j] = f2bf(ds);
         }
         // dS^T[key][q]: this lane's key row, 4 consecutive q -> 8 bytes
-        *reinterpret_cast<bf16x4*>(dss + (32 * wid + r) * 64 + (8 * g4 + 4 * hf) * 2) = dsw;
+        *reinterpret_cast<bf16x4*>(dss + (32 * wid + r) * DSS + (8 * g4 + 4 * hf) * 2) = dsw;
       }
       // ---- dV^T += dO^T.P ; dK^T += Q^T.dS   (A operand from transposed reads)
 #pragma unroll
@@ -420,9 +440,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
       for (int s = 0; s < 8; ++s) {
         // A = dS: lane (q = r, hf) needs keys 16s + 8hf + j  -> transposed reads of dS^T
         //   group rows = keys, cols = q block 16(grp&1)
-        const char* a0p = dss + (16 * s + 8 * hf + (gl >> 2)) * 64 + (16 * (grp & 1) + 4 * (gl & 3)) * 2;
+        const char* a0p = dss + (16 * s + 8 * hf + (gl >> 2)) * DSS + (16 * (grp & 1) + 4 * (gl & 3)) * 2;
         bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0p));
-        bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0p + 4 * 64));
+        bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0p + 4 * DSS));
         // B = K: lane (d = r, hf) needs K[key 16s + 8hf + j][32 wid + r]
         const int col0 = 32 * wid + 16 * (grp & 1);
         bf16x8 kb = cat4(tr_read(kts, 16 * s + 8 * hf, col0, gl),
@@ -430,12 +450,17 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
         dqacc = mfma32(cat4(a0, a1), kb, dqacc);
       }
       // atomics: lane (d col = r, hf), reg -> q row
+      float* dq_row = dq_acc + ((size_t)(q_beg + qs0 + 4 * hf) * Hq + head) * D + 32 * wid + r;
+      if (qs0 + 32 <= q_len) {  // whole slice inside the sequence (wave-uniform): no per-row guards
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int qrow = qs0 + (reg & 3) + 8 * (reg >> 2) + 4 * hf;
-        if (qrow < q_len)
-          atomicAdd(dq_acc + ((size_t)(q_beg + qrow) * Hq + head) * D + 32 * wid + r,
-                    dqacc[reg] * softmax_scale);
+        for (int reg = 0; reg < 16; ++reg)
+          atomicAdd(dq_row + (size_t)((reg & 3) + 8 * (reg >> 2)) * Hq * D, dqacc[reg] * softmax_scale);
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int dr = (reg & 3) + 8 * (reg >> 2);
+          if (qs0 + 4 * hf + dr < q_len) atomicAdd(dq_row + (size_t)dr * Hq * D, dqacc[reg] * softmax_scale);
+        }
       }
     }
   }
@@ -500,18 +525,18 @@ extern "C" int areal_flash_bwd(const void* q, const void* k, const void* v, cons
     hipLaunchKernelGGL(flash_bwd_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                        (const bf16_t*)o, (const bf16_t*)d_o, delta, o_stride, do_stride, Hq, total_q);
   }
-  const size_t lds = 32 * 256 * 2 + 128 * 256 + 128 * 64 + 64 * sizeof(float);
+  const size_t lds = 32 * 256 * 2 + 128 * 256 + 128 * 72 + 64 * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     HIP_RET(hipFuncSetAttribute((const void*)flash_bwd_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((max_k + 127) / 128, Hkv, B), block(256);
+  dim3 grid((unsigned)(((max_k + 127) / 128) * Hkv * B)), block(256);
   hipLaunchKernelGGL(flash_bwd_kernel, grid, block, lds, st, (const bf16_t*)q, (const bf16_t*)k,
                      (const bf16_t*)v, (const bf16_t*)d_o, lse, delta, dq_acc, (bf16_t*)dk,
                      (bf16_t*)dv, cu_q, cu_k, q_stride, k_stride, v_stride, do_stride, dk_stride,
-                     dv_stride, Hq, Hkv, total_q, softmax_scale, causal);
+                     dv_stride, Hq, Hkv, B, total_q, softmax_scale, causal);
   {
     const int64_t nvec = (int64_t)total_q * Hq * (D / 8);
     int64_t g = (nvec + 255) / 256;

@@ -1,6 +1,7 @@
 """Time the varlen flash-attention forward / backward kernels on a trainer-shaped packed batch."""
 import sys, time, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from areal_vllm_amd import ops
 dev = torch.device("cuda")
 torch.manual_seed(0)
