@@ -16,7 +16,7 @@ def register_dataset(name: str, cls):
 
 
 def make_dataset(cfg, seed: int, dp_rank: int, world_size: int, tokenizer_or_path=None):
-    from . import math_code_dataset, prompt_answer_dataset, prompt_dataset  # noqa: F401
+    from . import math_code_dataset, prompt_answer_dataset, prompt_dataset, rw_paired_dataset  # noqa: F401
 
     tok = tokenizer_or_path
     if isinstance(tok, str):

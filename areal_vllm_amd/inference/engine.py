@@ -16,6 +16,7 @@ Each generated token carries the weight version that sampled it.
 """
 import asyncio
 import dataclasses
+import os
 import queue
 import threading
 import time
@@ -186,7 +187,11 @@ class NativeInferenceEngine:
             torch.cuda.set_device(self.device)
             # the engine owns a stream: decode graphs overlap with whatever the trainer thread runs on
             # its stream (colocated asynchronous training)
-            self._stream = torch.cuda.Stream(device=self.device)
+            # high priority: decode kernels are small (a few hundred workgroups) and latency-bound; when the
+            # trainer's large GEMMs share the GPU they would otherwise queue behind full-chip grids, while with
+            # priority they take the CUs they need and the trainer's grids fill the rest
+            prio = int(os.environ.get("AREAL_ROLLOUT_STREAM_PRIORITY", "-1"))
+            self._stream = torch.cuda.Stream(device=self.device, priority=prio)
             torch.cuda.set_stream(self._stream)
         try:
             while not self._stop.is_set():

@@ -250,8 +250,13 @@ class NullInterface(ModelInterface):
                               data=dict(rewards=torch.zeros(n)))
 
     def train_step(self, model, data, mb_spec):
+        key = next((k for k in ("packed_input_ids", "packed_prompts") if k in data.keys), None)
+        n_tokens = float(sum(sum(x) for x in data.seqlens[key])) if key else 0.0
         model.inc_version()
-        return dict(loss=0.0)
+        return dict(loss=0.0, n_seqs=float(data.bs), n_tokens=n_tokens)
+
+    def generate(self, model, data, mb_spec):
+        return data
 
     def save(self, model, save_dir):
         pass

@@ -250,3 +250,26 @@ def test_async_ppo_experiment_staleness_and_weight_publication(tmp_path):
     assert "updated weights" in txt and "(version 3)" in txt
     # chunked generation: 8 new tokens in chunks of 4 means every answer crossed the router at least twice
     assert os.listdir(os.path.join(root, "answers"))
+
+
+def test_null_sft_experiment_runs_the_runtime_without_models(tmp_path):
+    """`null-sft`: master + 2 model workers + dataset + data-flow graph with the null interface."""
+    from areal_vllm_amd.apps.main import main_start
+    from areal_vllm_amd.system.system_api import DatasetAbstraction, ExperimentSaveEvalControl, make_experiment
+
+    root = str(tmp_path)
+    rows = [dict(id=str(i), prompt_ids=[3 + i, 4, 5], answer_ids=[7, 8]) for i in range(16)]
+    p = os.path.join(root, "data.jsonl")
+    with open(p, "w") as f:
+        f.write("\n".join(json.dumps(r) for r in rows))
+    exp = make_experiment("null-sft")
+    exp.experiment_name, exp.trial_name, exp.layout, exp.fileroot = "t-null", "t0", "d2", root
+    exp.dataset = DatasetAbstraction("prompt_answer", args=dict(dataset_path=p, eos_token_id=1))
+    exp.train_bs_n_seqs = 8
+    exp.exp_ctrl = ExperimentSaveEvalControl(total_train_epochs=2)
+    main_start(exp, "t-null", "t0", fileroot=root, platform="cpu", timeout=300)
+    st = _stats(root, "t-null", "t0")
+    assert [s["global_step"] for s in st] == [1, 2, 3, 4]
+    # every data-parallel head reports its half of the batch (prompt 3 + answer 2 + eos tokens per row)
+    assert all(s["trainDefault/n_seqs"] in (4, 8) and s["trainDefault/n_tokens"] == 6 * s["trainDefault/n_seqs"]
+               for s in st), st

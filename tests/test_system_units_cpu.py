@@ -502,3 +502,66 @@ def test_multi_turn_agent_discounts_rewards_and_masks_feedback():
 def g_ok(seen):
     # every turn's context = previous sequence + the (tokenizer-free) "wrong answer" feedback ids [5, 6]
     return seen[1][1] == seen[0][1] + [50, 60, 5, 6] and seen[2][1] == seen[1][1] + [51, 61, 5, 6]
+
+
+def test_paired_dataset_feeds_dpo_loss(tmp_path):
+    import json
+
+    from areal_vllm_amd.impl.dataset import make_dataset
+    from areal_vllm_amd.impl.utils.dpo_functional import dpo_loss
+    from areal_vllm_amd.system.system_api import DatasetAbstraction
+
+    rows = [dict(id=str(i), prompt_ids=[5, 6, 7], pos_answer_ids=[[10 + i], [11, 12]], neg_answer_ids=[[20], [21, 22, 23]])
+            for i in range(6)]
+    p = tmp_path / "pairs.jsonl"
+    p.write_text("\n".join(json.dumps(r) for r in rows))
+    ds = make_dataset(DatasetAbstraction("rw_pair", args=dict(dataset_path=str(p), max_pairs_per_prompt=2,
+                                                              eos_token_id=1)), seed=1, dp_rank=0, world_size=2)
+    assert len(ds) == 3
+    item = ds[0]
+    lens = item.seqlens["packed_input_ids"][0]
+    assert len(lens) == 4 and int(item.data["prompt_lens"][0]) == 3
+    flat = item.data["packed_input_ids"].tolist()
+    off = 0
+    for j, n in enumerate(lens):  # chosen / rejected alternate and share the prompt
+        seq = flat[off:off + n]
+        assert seq[:3] == [5, 6, 7] and seq[-1] == 1 and (seq[3] < 20) == (j % 2 == 0)
+        off += n
+    with pytest.raises(RuntimeError):
+        make_dataset(DatasetAbstraction("rw_pair", args=dict(dataset_builder=lambda: [
+            dict(id="x", prompt_ids=[1], pos_answer_ids=[[2]], neg_answer_ids=[])])), seed=1, dp_rank=0, world_size=1)
+    pi = torch.tensor([-1.0, -3.0, -2.0, -2.5], requires_grad=True)
+    ref = torch.tensor([-2.0, -2.0, -2.0, -2.0])
+    loss, pos, neg, kl = dpo_loss(pi, ref, beta=0.5)
+    want = -torch.nn.functional.logsigmoid(torch.tensor([0.5 * 2.0, 0.5 * 0.5])).mean()
+    assert float(loss) == pytest.approx(float(want)) and float(pos) == pytest.approx(0.5) and float(neg) == pytest.approx(-0.75)
+    loss.backward()
+    assert pi.grad[0] < 0 < pi.grad[1]  # raise the chosen log-prob, lower the rejected one
+
+
+def test_experiment_checks_and_cluster_spec(tmp_path):
+    import json
+
+    from areal_vllm_amd.api.alloc_mode import ParallelStrategy
+    from areal_vllm_amd.base.cluster import ClusterSpec, load_spec_from_file
+    from areal_vllm_amd.experiments import check
+    from areal_vllm_amd.experiments.common import ModelTrainEvalConfig
+
+    ok = ModelTrainEvalConfig(path="tiny", init_from_scratch=True)
+    check.check_experiment({"actor": ok}, ParallelStrategy(data_parallel_size=2), 8)
+    with pytest.raises(ValueError):
+        check.check_valid_model_and_path("actor", ModelTrainEvalConfig(path="tiny", init_from_scratch=False))
+    with pytest.raises(FileNotFoundError):
+        check.check_valid_model_and_path("actor", ModelTrainEvalConfig(path="/nonexistent/ckpt"))
+    with pytest.raises(ValueError):
+        check.check_valid_parallel_batch_size("b", 4, ParallelStrategy(data_parallel_size=2, pipeline_parallel_size=2))
+    with pytest.raises(ValueError):
+        check.check_valid_rollout_server(0.9, colocated_with_trainer=True)
+    bad = ModelTrainEvalConfig(path="tiny", init_from_scratch=True)
+    bad.optimizer.lr = 0.0
+    with pytest.raises(ValueError):
+        check.check_valid_optimizer("actor", bad)
+    f = tmp_path / "cluster.json"
+    f.write_text(json.dumps(dict(cluster_name="c", n_nodes=3, n_gpus_per_node=8, node_name_prefix="mi", junk=1)))
+    spec = load_spec_from_file(str(f))
+    assert spec.n_gpus == 24 and spec.node_names() == ["mi01", "mi02", "mi03"] and ClusterSpec().gpu_memory_gb == 288
