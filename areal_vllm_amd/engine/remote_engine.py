@@ -124,6 +124,8 @@ class RemoteInferenceEngine(InferenceEngine):
                                     "min_new_tokens": min_new, "temperature": 0.0 if g.greedy else g.temperature,
                                     "stop_token_ids": g.stop_token_ids, "frequency_penalty": g.frequency_penalty},
             }
+            if req.image_data:  # base64 images; the server runs its own image processor on them
+                payload["image_data"] = list(req.image_data)
             result = await arequest_with_retry(addr=addr, endpoint="/generate", payload=payload, method="POST",
                                                max_retries=self.config.request_retries,
                                                timeout=self.config.request_timeout)

@@ -363,9 +363,39 @@ class NativeTrainEngine(TrainEngine):
         pos = mb["position_ids"].to(torch.int32)
         cu = mb["cu_seqlens"].to(torch.int32)
         sp = self.model.sp
+        if self.model_config.vision is not None and mb.get("multi_modal_input") is not None:
+            assert sp is None, "vision-language batches do not combine with context parallelism"
+            return self._run_multimodal(mb, ids, cu, hidden_in, residual_in)
         if sp is not None:
             ids, pos = sp.local_slice(ids), sp.local_slice(pos)
         return self.model(ids, pos, cu, int(mb["max_seqlen"]), hidden_in, residual_in)
+
+    def _run_multimodal(self, mb: Dict[str, Any], ids: torch.Tensor, cu: torch.Tensor, hidden_in, residual_in):
+        """Packed vision-language micro-batch: `multi_modal_input[i]` holds the pixel patches and grids of the
+        images of sequence i. Image placeholders take the vision tower's outputs; every sequence gets its
+        own 3-D rotary positions (the appended padding sequence, which has no entry, counts as text)."""
+        from ..models.vision import mrope_position_ids
+
+        mc = self.model_config
+        mm = list(mb["multi_modal_input"])
+        bounds = cu.tolist()
+        host_ids = ids.tolist()
+        img_tokens = [t for t in (mc.image_token_id, mc.video_token_id) if t is not None]
+        merge = int(mc.vision.get("spatial_merge_size", 2))
+        pos3, pixels, grids = [], [], []
+        for i in range(len(bounds) - 1):
+            item = mm[i] if i < len(mm) else None
+            g = item["image_grid_thw"] if item is not None and item.get("image_grid_thw") is not None else None
+            g_list = g.tolist() if g is not None else []
+            pos3.append(mrope_position_ids(host_ids[bounds[i]:bounds[i + 1]], g_list, img_tokens, merge)[0])
+            if g is not None and len(g_list) > 0:
+                pixels.append(item["pixel_values"])
+                grids.append(g)
+        positions = torch.cat(pos3, 1).to(ids.device)
+        if self.model.has_embed and hidden_in is None:
+            px = torch.cat(pixels, 0) if pixels else None
+            hidden_in = self.model.embed_multimodal(ids, px, torch.cat(grids, 0) if grids else None)
+        return self.model(None, positions, cu, int(mb["max_seqlen"]), hidden_in, residual_in)
 
     def _proxy(self, hidden: torch.Tensor, pad_len: int) -> LogitsProxy:
         nc = self.config.native

@@ -92,6 +92,7 @@ class NativeInferenceEngine:
                           prompt_tokens=0, aborted=0)
         self._copy_stream = None
         self._stream = None
+        self._mm_ids: Dict[str, int] = {}  # request id -> scheduler id of requests that carry images
         self.update_group = None
         # tensor-parallel serving: rank 0 of the TP group owns the scheduler and tells the other ranks
         # what to run (see inference/tp_worker.py)
@@ -266,11 +267,18 @@ class NativeInferenceEngine:
     def _drain_requests(self):
         while True:
             try:
-                rid, prompt, sp = self._req_q.get_nowait()
+                rid, prompt, sp, mm = self._req_q.get_nowait()
             except queue.Empty:
                 return
-            self.sched.add_request(rid, prompt, sp["max_new_tokens"], sp["min_new_tokens"], sp["temperature"],
-                                   sp["top_p"], sp["top_k"], sp["stop_token_ids"])
+            sched_prompt = prompt
+            if mm is not None and self.runner.is_vl:
+                assert self.tp_size == 1, "vision-language serving is single-rank"
+                sched_prompt = self.runner.salted_prompt(prompt, mm["pixel_values"])
+            req_id = self.sched.add_request(rid, sched_prompt, sp["max_new_tokens"], sp["min_new_tokens"],
+                                            sp["temperature"], sp["top_p"], sp["top_k"], sp["stop_token_ids"])
+            if mm is not None and self.runner.is_vl:
+                self.runner.register_multimodal(req_id, prompt, mm["pixel_values"], mm["image_grid_thw"])
+                self._mm_ids[rid] = req_id
 
     def _drain_control(self):
         while True:
@@ -292,6 +300,8 @@ class NativeInferenceEngine:
                                    output_versions=list(f["output_versions"]), finish_reason=f["finish_reason"],
                                    prompt_len=f["prompt_len"], latency=f["latency"], ttft=f["ttft"], itl=list(f["itl"]))
             self.stats["gen_tokens"] += len(res.output_tokens)
+            if res.rid in self._mm_ids:
+                self.runner.release_multimodal(self._mm_ids.pop(res.rid))
             if res.finish_reason == "abort":
                 self.stats["aborted"] += 1
             with self._lock:
@@ -323,7 +333,10 @@ class NativeInferenceEngine:
     def submit(self, rid: str, input_ids: List[int], *, max_new_tokens: int, min_new_tokens: int = 0,
                temperature: float = 1.0, top_p: float = 1.0, top_k: int = 1 << 30,
                stop_token_ids: Optional[List[int]] = None, greedy: bool = False,
-               callback: Optional[Callable[[GenerationResult], None]] = None):
+               callback: Optional[Callable[[GenerationResult], None]] = None,
+               multimodal: Optional[Dict[str, torch.Tensor]] = None):
+        """`multimodal`: {"pixel_values" [n_patches, C*tp*P*P], "image_grid_thw" [n_images, 3]} for prompts
+        whose `input_ids` contain image placeholder tokens (vision-language models)."""
         sp = dict(max_new_tokens=int(max_new_tokens), min_new_tokens=int(min_new_tokens),
                   temperature=0.0 if greedy else float(temperature), top_p=float(top_p),
                   top_k=int(min(top_k, 1 << 30)), stop_token_ids=[int(x) for x in (stop_token_ids or [])])
@@ -331,7 +344,12 @@ class NativeInferenceEngine:
             if rid in self._waiters:
                 raise ValueError(f"duplicate request id {rid}")
             self._waiters[rid] = callback or (lambda r: None)
-        self._req_q.put((rid, [int(t) for t in input_ids], sp))
+        if multimodal is not None and multimodal.get("pixel_values") is not None:
+            multimodal = dict(pixel_values=multimodal["pixel_values"].detach().cpu(),
+                              image_grid_thw=torch.as_tensor(multimodal["image_grid_thw"]).cpu().long())
+        else:
+            multimodal = None
+        self._req_q.put((rid, [int(t) for t in input_ids], sp, multimodal))
         self._wake.set()
 
     async def agenerate_once(self, rid: str, input_ids: List[int], **sampling) -> GenerationResult:

@@ -59,6 +59,71 @@ class ModelRunner:
         self.V = cfg.vocab_size
         self.n_prefill_tokens = 0
         self.n_decode_tokens = 0
+        # vision-language requests: scheduler request id -> positions / image features (see register_multimodal)
+        self.is_vl = cfg.vision is not None
+        self.mm: Dict[int, Dict[str, Any]] = {}
+
+    # ------------------------------------------------------------------- vision-language requests
+    def salted_prompt(self, prompt_ids: List[int], pixel_values: torch.Tensor) -> List[int]:
+        """Token ids handed to the scheduler for a prompt with images: every image placeholder becomes an
+        id >= vocab_size derived from the pixel data and its index, so that the prefix cache can only match
+        prompts that show the same images (samples of one group still share their prefill)."""
+        cfg = self.cfg
+        img = {t for t in (cfg.image_token_id, cfg.video_token_id) if t is not None}
+        salt = int(torch.frombuffer(bytearray(pixel_values.float().sum(-1).numpy().tobytes()), dtype=torch.int32)
+                   .long().sum()) & 0x3FFFFFFF
+        span = (1 << 31) - self.V - 1
+        out, j = [], 0
+        for t in prompt_ids:
+            if t in img:
+                out.append(self.V + (salt + 7919 * j) % span)
+                j += 1
+            else:
+                out.append(int(t))
+        return out
+
+    def register_multimodal(self, req_id: int, prompt_ids: List[int], pixel_values: torch.Tensor,
+                            grid_thw: torch.Tensor):
+        from ..models.vision import mrope_position_ids
+
+        cfg = self.cfg
+        img = [t for t in (cfg.image_token_id, cfg.video_token_id) if t is not None]
+        pos3, delta = mrope_position_ids(prompt_ids, grid_thw.tolist(), img, int(cfg.vision.get("spatial_merge_size", 2)))
+        is_img = torch.tensor([t in img for t in prompt_ids])
+        img_index = torch.where(is_img, torch.cumsum(is_img.long(), 0) - 1, torch.full_like(is_img.long(), -1))
+        self.mm[int(req_id)] = dict(pos3=pos3, delta=int(delta), img_index=img_index, pixel_values=pixel_values,
+                                    grid_thw=grid_thw, embeds=None)
+
+    def release_multimodal(self, req_id: int):
+        self.mm.pop(int(req_id), None)
+
+    def _multimodal_prefill_inputs(self, plan, ids: torch.Tensor):
+        """-> (hidden [T, H] with image features in place, 3-D rotary positions [3, T]) for a prefill plan.
+        Tokens are addressed by their absolute position in the request: prompt positions use the request's
+        precomputed tables, positions past the prompt (re-prefill after preemption) are text."""
+        dev = self.device
+        abs_pos = torch.from_numpy(plan["positions"].astype(np.int64))
+        cu = plan["cu_q"].astype(np.int64)
+        T = abs_pos.numel()
+        pos3 = abs_pos.view(1, T).repeat(3, 1)
+        h = self.model.embed_tokens(torch.where(ids >= self.V, torch.full_like(ids, self.cfg.image_token_id), ids))
+        for i, rid in enumerate(plan["req_ids"].tolist()):
+            m = self.mm.get(int(rid))
+            if m is None:
+                continue
+            lo, hi = int(cu[i]), int(cu[i + 1])
+            ap = abs_pos[lo:hi]
+            P = m["pos3"].shape[1]
+            inside = ap < P
+            apc = ap.clamp(max=P - 1)
+            pos3[:, lo:hi] = torch.where(inside, m["pos3"][:, apc], ap + m["delta"])
+            idx = torch.where(inside, m["img_index"][apc], torch.full_like(ap, -1))
+            sel = (idx >= 0).nonzero().flatten()
+            if sel.numel():
+                if m["embeds"] is None:
+                    m["embeds"] = self.model.visual(m["pixel_values"].to(dev), m["grid_thw"].to(dev)).to(h.dtype)
+                h[(sel + lo).to(dev)] = m["embeds"][idx[sel].to(dev)]
+        return h, pos3.to(dev)
 
     # ------------------------------------------------------------------------ model pieces
     def _layer(self, blk, h, residual, positions, slots, attn_fn):
@@ -111,14 +176,20 @@ class ModelRunner:
         hq, hkv, D = self.hq, self.hkv, self.cfg.head_dim
         self.n_prefill_tokens += T
 
-        h = self.model.embed_tokens(ids)
+        rope = self.rope
+        if self.is_vl and any(int(r) in self.mm for r in plan["req_ids"].tolist()):
+            h, pos3 = self._multimodal_prefill_inputs(plan, ids)
+            rope = self.model.mrope(pos3)  # per-token table, addressed by the token's index in the plan
+            pos = torch.arange(T, dtype=torch.int32, device=dev)
+        else:
+            h = self.model.embed_tokens(ids)
         residual = None
         for li, blk in enumerate(self.model.layers):
             kc, vc = self.kv[li]
 
             def attn_fn(blk_, qkv2d, kc=kc, vc=vc):
                 qkv = qkv2d.view(T, hq + 2 * hkv, D)
-                ops.rope_and_cache_write_(qkv, pos, slots, self.rope, kc, vc, hq, hkv)
+                ops.rope_and_cache_write_(qkv, pos, slots, rope, kc, vc, hq, hkv)
                 q = qkv[:, :hq]
                 if has_prefix:
                     k, v = ops.cache_gather(kc, vc, ctx_slots)
@@ -159,6 +230,8 @@ class ModelRunner:
             temperature=torch.ones(Bp, dtype=torch.float32, device=dev),
             top_p=torch.ones(Bp, dtype=torch.float32, device=dev),
             top_k=torch.full((Bp,), self.V, dtype=torch.int32, device=dev),
+            rope_delta=torch.zeros(Bp, dtype=torch.int32, device=dev),
+            rope_pos=torch.zeros(Bp, dtype=torch.int32, device=dev),
             out_tokens=torch.zeros(k, Bp, dtype=torch.int64, device=dev),
             out_logprobs=torch.zeros(k, Bp, dtype=torch.float32, device=dev),
         )
@@ -167,7 +240,7 @@ class ModelRunner:
         # pinned host mirrors for one-shot uploads
         if dev.type == "cuda":
             st["h_i64"] = torch.zeros(2, Bp, dtype=torch.int64).pin_memory()
-            st["h_i32"] = torch.zeros(3, Bp, dtype=torch.int32).pin_memory()
+            st["h_i32"] = torch.zeros(4, Bp, dtype=torch.int32).pin_memory()
             st["h_f32"] = torch.zeros(2, Bp, dtype=torch.float32).pin_memory()
             st["h_bt"] = torch.zeros(Bp, self.max_pages, dtype=torch.int32).pin_memory()
         return st
@@ -180,12 +253,16 @@ class ModelRunner:
         for s in range(self.decode_steps):
             h = self.model.embed_tokens(st["input_ids"])
             residual = None
+            rope_pos = st["positions"]
+            if self.is_vl:  # generated tokens of a request with images sit `delta` away from their index
+                torch.add(st["positions"], st["rope_delta"], out=st["rope_pos"])
+                rope_pos = st["rope_pos"]
             for li, blk in enumerate(self.model.layers):
                 kc, vc = self.kv[li]
 
-                def attn_fn(blk_, qkv2d, kc=kc, vc=vc):
+                def attn_fn(blk_, qkv2d, kc=kc, vc=vc, rope_pos=rope_pos):
                     qkv = qkv2d.view(Bp, hq + 2 * hkv, D)
-                    ops.rope_and_cache_write_(qkv, st["positions"], st["slots"], self.rope, kc, vc, hq, hkv)
+                    ops.rope_and_cache_write_(qkv, rope_pos, st["slots"], self.rope, kc, vc, hq, hkv)
                     return ops.paged_attention_decode(qkv[:, :hq], kc, vc, st["block_tables"], st["context_lens"],
                                                       nsplit=st["nsplit"], workspace=st["ws"],
                                                       q_row_stride=qkv_stride)
@@ -253,6 +330,10 @@ class ModelRunner:
             hi32[0, :B] = torch.from_numpy(plan["positions"])
             hi32[1, :B] = torch.from_numpy(plan["context_lens"])
             hi32[2, :B] = torch.from_numpy(np.minimum(plan["top_k"], self.V).astype(np.int32))
+            if self.is_vl:
+                hi32[3, :B] = torch.tensor([self.mm.get(int(r), {}).get("delta", 0) for r in plan["req_ids"].tolist()],
+                                           dtype=torch.int32)
+                st["rope_delta"].copy_(hi32[3], non_blocking=True)
             hf32[0, :B] = torch.from_numpy(plan["temperature"])
             hf32[1, :B] = torch.from_numpy(plan["top_p"])
             hbt[:B, :mp] = torch.from_numpy(plan["block_tables"])
@@ -274,6 +355,10 @@ class ModelRunner:
                 st[name][:B] = torch.from_numpy(src)
             st["block_tables"].zero_()
             st["block_tables"][:B, :mp] = torch.from_numpy(plan["block_tables"])
+            if self.is_vl:
+                st["rope_delta"].zero_()
+                st["rope_delta"][:B] = torch.tensor(
+                    [self.mm.get(int(r), {}).get("delta", 0) for r in plan["req_ids"].tolist()], dtype=torch.int32)
         if g is not None:
             g.replay()
         else:

@@ -48,6 +48,7 @@ class InferenceServer:
     def __init__(self, engine: NativeInferenceEngine):
         self.engine = engine
         self.update_group = None
+        self._image_processor = None
         self.start_time = time.time()
         self.app = web.Application(client_max_size=1024**3)
         r = self.app.router
@@ -98,11 +99,17 @@ class InferenceServer:
         sp = body.get("sampling_params", {}) or {}
         rid = body.get("rid") or uuid.uuid4().hex
         temp = float(sp.get("temperature", 1.0))
+        multimodal = None
+        if body.get("image_data"):
+            try:
+                multimodal = await self._offload(self._process_images, body["image_data"])
+            except Exception as e:
+                return web.json_response({"error": f"cannot process image_data: {e!r}"}, status=400)
         res = await self.engine.agenerate_once(
             f"{rid}-{uuid.uuid4().hex[:8]}", ids, max_new_tokens=int(sp.get("max_new_tokens", 128)),
             min_new_tokens=int(sp.get("min_new_tokens", 0)), temperature=temp, top_p=float(sp.get("top_p", 1.0)),
             top_k=int(sp.get("top_k", 1 << 30)) if int(sp.get("top_k", -1)) > 0 else 1 << 30,
-            stop_token_ids=sp.get("stop_token_ids") or [], greedy=temp <= 0.0)
+            stop_token_ids=sp.get("stop_token_ids") or [], greedy=temp <= 0.0, multimodal=multimodal)
         meta = {
             "id": rid, "finish_reason": _finish(res.finish_reason), "prompt_tokens": res.prompt_len,
             "completion_tokens": len(res.output_tokens),
@@ -111,6 +118,21 @@ class InferenceServer:
             "e2e_latency": res.latency, "ttft": res.ttft,
         }
         return web.json_response({"text": "", "output_ids": res.output_tokens, "meta_info": meta})
+
+    def _process_images(self, image_data: List[str]) -> Dict[str, torch.Tensor]:
+        """base64 images -> patch tensor + grids with the checkpoint's own image processor (the request's
+        `input_ids` already hold one placeholder token per merged patch, as the HF processor emits them)."""
+        if self.engine.model_config.vision is None:
+            raise ValueError("this server hosts a text-only model")
+        if self._image_processor is None:
+            from transformers import AutoProcessor
+
+            path = getattr(self.engine.config, "tokenizer_path", None) or self.engine.config.model_path
+            self._image_processor = AutoProcessor.from_pretrained(path).image_processor
+        from ..utils.image import base642image
+
+        out = self._image_processor(images=[base642image(x).convert("RGB") for x in image_data], return_tensors="pt")
+        return dict(pixel_values=out["pixel_values"], image_grid_thw=out["image_grid_thw"])
 
     async def _offload(self, fn, *a, **k):
         return await asyncio.get_running_loop().run_in_executor(None, lambda: fn(*a, **k))

@@ -7,7 +7,7 @@ gemma}.py`` plus MoE (``mixtral``, ``qwen3_moe``) through the ``n_experts`` fiel
 import dataclasses
 import json
 import os
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional
 
 
 @dataclasses.dataclass
@@ -39,6 +39,14 @@ class ModelConfig:
     bos_token_id: Optional[int] = None
     eos_token_id: Optional[int] = None
     pad_token_id: Optional[int] = None
+    # vision-language models (Qwen2-VL layout): settings of the vision tower (models/vision.py) and the
+    # split of the rotary pairs over (temporal, row, column) positions; None = text-only
+    vision: Optional[Dict[str, Any]] = None
+    mrope_section: Optional[List[int]] = None
+    image_token_id: Optional[int] = None
+    video_token_id: Optional[int] = None
+    vision_start_token_id: Optional[int] = None
+    vision_end_token_id: Optional[int] = None
 
     @property
     def q_dim(self) -> int:
@@ -73,6 +81,20 @@ class ModelConfig:
     # ------------------------------------------------------------------ HF interop
     @classmethod
     def from_hf_dict(cls, d: Dict[str, Any], is_critic: bool = False) -> "ModelConfig":
+        if d.get("model_type") in ("qwen2_vl", "qwen2_5_vl") and "text_config" in d:
+            # nested layout: language model settings under text_config, tower under vision_config
+            text = dict(d["text_config"])
+            text["model_type"] = "qwen2"
+            text.setdefault("tie_word_embeddings", d.get("tie_word_embeddings", False))
+            cfg = cls.from_hf_dict(text, is_critic=is_critic)
+            cfg.family = d["model_type"]
+            cfg.vision = dict(d["vision_config"])
+            rp = text.get("rope_parameters") or text.get("rope_scaling") or {}
+            cfg.mrope_section = list(rp.get("mrope_section") or []) or None
+            for k in ("image_token_id", "video_token_id", "vision_start_token_id", "vision_end_token_id"):
+                setattr(cfg, k, d.get(k))
+            cfg.qkv_bias = bool(text.get("attention_bias", True))
+            return cfg
         mt = d.get("model_type", "qwen2")
         H = d["hidden_size"]
         nq = d["num_attention_heads"]
@@ -121,6 +143,20 @@ class ModelConfig:
             return cls.from_hf_dict(json.load(f), is_critic=is_critic)
 
     def to_hf_dict(self) -> Dict[str, Any]:
+        if self.vision is not None:
+            text = dataclasses.replace(self, vision=None, family="qwen2").to_hf_dict()
+            text.pop("architectures")
+            text["model_type"] = "qwen2_vl_text"
+            text["rope_parameters"] = {"rope_type": "default", "type": "mrope", "rope_theta": self.rope_theta,
+                                       "mrope_section": list(self.mrope_section or [])}
+            text["rope_scaling"] = {"type": "mrope", "mrope_section": list(self.mrope_section or [])}
+            vis = dict(self.vision)
+            vis.setdefault("model_type", "qwen2_vl_vision")
+            return {"architectures": ["Qwen2VLForConditionalGeneration"], "model_type": self.family,
+                    "text_config": text, "vision_config": vis, "tie_word_embeddings": self.tie_word_embeddings,
+                    "image_token_id": self.image_token_id, "video_token_id": self.video_token_id,
+                    "vision_start_token_id": self.vision_start_token_id,
+                    "vision_end_token_id": self.vision_end_token_id, "torch_dtype": "bfloat16"}
         arch = {
             "qwen2": "Qwen2ForCausalLM", "qwen3": "Qwen3ForCausalLM", "llama": "LlamaForCausalLM",
             "mistral": "MistralForCausalLM", "gemma": "GemmaForCausalLM", "mixtral": "MixtralForCausalLM",
@@ -179,6 +215,12 @@ PRESETS: Dict[str, Dict[str, Any]] = {
     "small": dict(family="qwen2", vocab_size=4096, hidden_size=512, n_layers=4, n_q_heads=4, n_kv_heads=2,
                   head_dim=128, intermediate_size=1536, tie_word_embeddings=True, qkv_bias=True, rope_theta=1e4,
                   max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
+    "tiny-vl": dict(family="qwen2_vl", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
+                    head_dim=128, intermediate_size=512, tie_word_embeddings=False, qkv_bias=True, rope_theta=1e4,
+                    max_position_embeddings=4096, eos_token_id=1, pad_token_id=0, mrope_section=[16, 24, 24],
+                    image_token_id=500, video_token_id=501, vision_start_token_id=502, vision_end_token_id=503,
+                    vision=dict(depth=2, embed_dim=64, hidden_size=256, num_heads=4, mlp_ratio=2, patch_size=14,
+                                spatial_merge_size=2, temporal_patch_size=2, in_channels=3)),
     "tiny-moe": dict(family="qwen3_moe", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
                      head_dim=128, intermediate_size=512, tie_word_embeddings=False, qkv_bias=False, qk_norm=True,
                      rope_theta=1e4, max_position_embeddings=4096, n_experts=4, n_experts_per_tok=2,

@@ -130,6 +130,9 @@ def load_hf_weights(model, path: str, strict: bool = True) -> None:
 
     if model.has_embed:
         put("embed", rd.get("model.embed_tokens.weight"))
+        for n in params:  # vision tower: parameter names are the checkpoint names
+            if n.startswith("visual."):
+                put(n, rd.get(n))
     if model.has_head:
         put("norm", rd.get("model.norm.weight"))
         if "head" in params:
@@ -211,6 +214,10 @@ def native_to_hf_state(model, gather: bool = True, experts_only: bool = False) -
     params = dict(model.named_parameters())
     if model.has_embed:
         yield "model.embed_tokens.weight", params["embed"].data
+        if model.tp_rank == 0 or not gather:  # the tower is replicated over tensor-parallel ranks
+            for n, p in params.items():
+                if n.startswith("visual."):
+                    yield n, p.data
     lo_layer, _ = model.layer_range
     for li, blk in enumerate(model.layers):
         i = lo_layer + li

@@ -276,6 +276,10 @@ class Transformer(nn.Module):
                 self.head = nn.Parameter(torch.empty(1, cfg.hidden_size, dtype=dtype, device=device))
             elif not (cfg.tie_word_embeddings and has_embed):
                 self.head = nn.Parameter(torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device))
+        if cfg.vision is not None and has_embed:
+            from .vision import VisionConfig, VisionTower
+
+            self.visual = VisionTower(VisionConfig.from_dict(cfg.vision), dtype=dtype, device=device)
         self._rope: Optional[ops.RotaryTable] = None
         self.flat: Optional[FlatParams] = None
         self.flat_experts: Optional[FlatParams] = None
@@ -284,7 +288,9 @@ class Transformer(nn.Module):
     def init_weights(self, seed: int = 0, std: float = 0.02):
         g = torch.Generator(device="cpu").manual_seed(seed)
         for n, p in self.named_parameters():
-            if p.dim() >= 2:
+            if n.startswith("visual.") and p.dim() == 1:
+                p.data.fill_(1.0 if n.endswith("weight") else 0.0)  # LayerNorm weights / biases of the tower
+            elif p.dim() >= 2:
                 # generate in fp32 on host in slabs to bound memory, same values on every device type
                 flat = p.data.view(-1)
                 step = 1 << 24
@@ -330,6 +336,31 @@ class Transformer(nn.Module):
             h = h * math.sqrt(self.cfg.hidden_size)
         return h
 
+    def embed_multimodal(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor],
+                         grid_thw: Optional[torch.Tensor]) -> torch.Tensor:
+        """Token embeddings with the image placeholder positions replaced, in order, by the vision tower's
+        outputs for `pixel_values` (all images of the packed batch concatenated)."""
+        h = self.embed_tokens(input_ids)
+        if pixel_values is None or pixel_values.numel() == 0:
+            return h
+        img = self.visual(pixel_values.to(h.device), grid_thw.to(h.device)).to(h.dtype)
+        mask = (input_ids == self.cfg.image_token_id)
+        if self.cfg.video_token_id is not None:
+            mask = mask | (input_ids == self.cfg.video_token_id)
+        n = int(mask.sum())
+        assert n == img.shape[0], f"{n} image placeholder tokens but {img.shape[0]} image embeddings"
+        return h.masked_scatter(mask.unsqueeze(-1), img)
+
+    def mrope(self, positions3: torch.Tensor) -> ops.RotaryTable:
+        """Per-token rotary table for 3-D positions [3, T] (index it with arange(T))."""
+        from .vision import mrope_table
+
+        tab = ops.RotaryTable.__new__(ops.RotaryTable)
+        tab.head_dim, tab.max_pos = self.cfg.head_dim, positions3.shape[1]
+        tab.cos, tab.sin = mrope_table(positions3, self.cfg.head_dim, self.cfg.rope_theta,
+                                       self.cfg.mrope_section or [self.cfg.head_dim // 2, 0, 0])
+        return tab
+
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor, cu_seqlens: torch.Tensor,
                 max_seqlen: int, hidden_in: Optional[torch.Tensor] = None,
                 residual_in: Optional[torch.Tensor] = None):
@@ -339,7 +370,11 @@ class Transformer(nn.Module):
         else:
             h = hidden_in
         residual = residual_in
-        rope = self.rope(h.device)
+        if positions.dim() == 2:  # M-RoPE: [3, T] (temporal, row, column) positions of a vision-language batch
+            rope = self.mrope(positions)
+            positions = torch.arange(positions.shape[1], dtype=torch.int32, device=positions.device)
+        else:
+            rope = self.rope(h.device)
         for blk in self.layers:
             if self.gradient_checkpointing and self.training and torch.is_grad_enabled():
                 from torch.utils.checkpoint import checkpoint

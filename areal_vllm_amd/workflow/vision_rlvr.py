@@ -35,8 +35,11 @@ class VisionRLVRWorkflow(RLVRWorkflow):
         processed = self.processor(images=images, text=data["messages"], padding=False, return_tensors="pt")
         input_ids = processed["input_ids"].tolist()[0]
         n = self.gconfig.n_samples
+        # remote servers get the images themselves (base64), an in-process engine the processed patches
         req = ModelRequest(rid=uuid.uuid4().hex, input_ids=input_ids, image_data=image2base64(images),
-                           gconfig=self.gconfig.new(n_samples=1), tokenizer=self.tokenizer, processor=self.processor)
+                           gconfig=self.gconfig.new(n_samples=1), tokenizer=self.tokenizer, processor=self.processor,
+                           metadata={"multi_modal_input": {"pixel_values": processed["pixel_values"],
+                                                           "image_grid_thw": processed["image_grid_thw"]}})
         resps = await asyncio.gather(*[engine.agenerate(req.copy()) for _ in range(n)])
         version = engine.get_version()
         prompt_str = self.tokenizer.decode(input_ids)
