@@ -214,7 +214,9 @@ class NativeTrainEngine(TrainEngine):
             layer_range=lr, has_embed=g.coord.pp == 0, has_head=g.coord.pp == g.pp - 1,
             ep_size=g.ep, ep_rank=g.rank_in("ep"), ep_group=g.group("ep"),
             gradient_checkpointing=cfg.gradient_checkpointing,
+            sequence_parallel=cfg.native.sequence_parallel and g.tp > 1,
         )
+        assert not (self.model.seq_par and g.cp > 1), "choose tensor-parallel sequence parallelism or cp, not both"
         if g.cp > 1:
             if cfg.native.context_parallel_mode == "zigzag":
                 from ..parallel.context_parallel import ZigZagContext
@@ -307,11 +309,24 @@ class NativeTrainEngine(TrainEngine):
                 flat[a:b].copy_(packed[o:o + (b - a)])
                 o += b - a
 
+    def _partial_grad_ranges(self) -> List[Tuple[int, int, int]]:
+        """Replicated parameters whose gradient on one tp rank is only a partial sum: per-head q/k norm
+        weights see only the local heads; under sequence parallelism the block norms and the final norm
+        see only the local tokens (reference: ``realhf/impl/model/backend/megatron.py:227-259``)."""
+        names = {"q_norm", "k_norm"}
+        if self.model.seq_par:
+            names |= {"ln1", "ln2", "norm"}
+        return sorted((o, o + numel, self.grid.tp) for n, (o, numel) in self.model.flat.offsets.items()
+                      if n.split(".")[-1] in names)
+
     def _sync_replicated_kv_grads(self):
         """When tp exceeds the KV heads, `kv_rep` neighbouring ranks hold the same K/V projection but each
-        sees only the gradient that flows through its own query heads: sum them inside every replica set."""
+        sees only the gradient that flows through its own query heads: sum them inside every replica set.
+        Partial gradients of other replicated parameters are summed over the whole tp group."""
         if self.grid.tp > 1 and self._kv_replication() > 1:
             self._replica_sync(self.model.flat.main_grad, self._kv_ranges(), "sum")
+        if self.grid.tp > 1:
+            self._replica_sync(self.model.flat.main_grad, self._partial_grad_ranges(), "sum")
 
     def destroy(self):
         self.model = None

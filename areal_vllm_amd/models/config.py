@@ -215,6 +215,9 @@ PRESETS: Dict[str, Dict[str, Any]] = {
     "small": dict(family="qwen2", vocab_size=4096, hidden_size=512, n_layers=4, n_q_heads=4, n_kv_heads=2,
                   head_dim=128, intermediate_size=1536, tie_word_embeddings=True, qkv_bias=True, rope_theta=1e4,
                   max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
+    "tiny-qknorm": dict(family="qwen3", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=4, n_kv_heads=2,
+                        head_dim=64, intermediate_size=512, tie_word_embeddings=False, qkv_bias=False, qk_norm=True,
+                        rope_theta=1e4, max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
     "tiny-vl": dict(family="qwen2_vl", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
                     head_dim=128, intermediate_size=512, tie_word_embeddings=False, qkv_bias=True, rope_theta=1e4,
                     max_position_embeddings=4096, eos_token_id=1, pad_token_id=0, mrope_section=[16, 24, 24],

@@ -130,11 +130,11 @@ class Attention(nn.Module):
             self.q_norm = nn.Parameter(torch.ones(D, dtype=dtype, device=device))
             self.k_norm = nn.Parameter(torch.ones(D, dtype=dtype, device=device))
 
-    def project_qkv(self, x):
+    def project_qkv(self, x, reduce_dx_group=None):
         """Fused q|k|v projection, returned 2-D [T, (hq + 2 hkv) * D] (not a view, RoPE runs in place)."""
         T = x.shape[0]
         D = self.cfg.head_dim
-        qkv = ops.linear(x, self.qkv, self.qkv_bias)
+        qkv = ops.linear(x, self.qkv, self.qkv_bias, reduce_dx_group=reduce_dx_group)
         if self.cfg.qk_norm:
             q3 = qkv.view(T, self.hq + 2 * self.hkv, D)
             q, _ = ops.rmsnorm(q3[:, :self.hq], self.q_norm, self.cfg.rms_norm_eps)
@@ -142,17 +142,23 @@ class Attention(nn.Module):
             qkv = torch.cat([q, k, q3[:, self.hq + self.hkv:]], 1).view(T, -1)
         return qkv
 
-    def forward(self, x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None):
-        T = x.shape[0]
+    def forward(self, x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None, seq_par=False):
         D = self.cfg.head_dim
-        x = _AllReduceBwd.apply(x, tp_group)
-        qkv = self.project_qkv(x)
+        if seq_par:  # token-sharded input: all-gather (backward: reduce-scatter)
+            from ..parallel.tensor_parallel import GatherFromSP, ReduceScatterToSP
+
+            qkv = self.project_qkv(GatherFromSP.apply(x, tp_group))
+        else:  # replicated input: the input-gradient all-reduce overlaps the weight-gradient GEMM
+            qkv = self.project_qkv(x, reduce_dx_group=tp_group)
+        T = qkv.shape[0]
         qkv = ops.apply_rope(qkv, positions, rope, self.hq + self.hkv, D).view(T, self.hq + 2 * self.hkv, D)
         if sp is not None:
             attn = sp.attention(qkv, self.hq, self.hkv, cu_seqlens, max_seqlen)
         else:
             attn = ops.flash_attn_varlen_qkv(qkv, cu_seqlens, max_seqlen, self.hq, self.hkv)
         out = ops.linear(attn.reshape(T, -1), self.o)
+        if seq_par:
+            return ReduceScatterToSP.apply(out, tp_group)
         return _AllReduceFwd.apply(out, tp_group)
 
 
@@ -165,9 +171,13 @@ class MLP(nn.Module):
         self.gate_up = nn.Parameter(torch.empty(2 * f, hidden, dtype=dtype, device=device))
         self.down = nn.Parameter(torch.empty(hidden, f, dtype=dtype, device=device))
 
-    def forward(self, x, tp_group):
-        x = _AllReduceBwd.apply(x, tp_group)
-        h = ops.swiglu(ops.linear(x, self.gate_up), self.act)
+    def forward(self, x, tp_group, seq_par=False):
+        if seq_par:
+            from ..parallel.tensor_parallel import GatherFromSP, ReduceScatterToSP
+
+            h = ops.swiglu(ops.linear(GatherFromSP.apply(x, tp_group), self.gate_up), self.act)
+            return ReduceScatterToSP.apply(ops.linear(h, self.down), tp_group)
+        h = ops.swiglu(ops.linear(x, self.gate_up, reduce_dx_group=tp_group), self.act)
         return _AllReduceFwd.apply(ops.linear(h, self.down), tp_group)
 
 
@@ -237,15 +247,16 @@ class Block(nn.Module):
         else:
             self.mlp = MLP(cfg.hidden_size, cfg.intermediate_size, tp_size, dtype, device, cfg.hidden_act)
 
-    def forward(self, h, residual, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None, ep_group=None):
+    def forward(self, h, residual, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None, ep_group=None,
+                seq_par=False):
         cfg = self.cfg
         x, residual = ops.rmsnorm(h, self.ln1, cfg.rms_norm_eps, residual, cfg.gemma_norm)
-        h = self.attn(x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp)
+        h = self.attn(x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp, seq_par)
         x, residual = ops.rmsnorm(h, self.ln2, cfg.rms_norm_eps, residual, cfg.gemma_norm)
         if cfg.n_experts > 0:
             h = self.mlp(x, tp_group, ep_group)
         else:
-            h = self.mlp(x, tp_group)
+            h = self.mlp(x, tp_group, seq_par)
         return h, residual
 
 
@@ -255,8 +266,13 @@ class Transformer(nn.Module):
     def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cpu", tp_size: int = 1, tp_rank: int = 0,
                  tp_group=None, layer_range: Optional[Tuple[int, int]] = None, has_embed: bool = True,
                  has_head: bool = True, ep_size: int = 1, ep_rank: int = 0, ep_group=None,
-                 gradient_checkpointing: bool = False):
+                 gradient_checkpointing: bool = False, sequence_parallel: bool = False):
         super().__init__()
+        # Megatron-style sequence parallelism: between the tensor-parallel regions the residual stream,
+        # norms and their activations hold only T/tp tokens per rank (all-gather before a column-parallel
+        # GEMM, reduce-scatter after a row-parallel one: the same bytes over xGMI as the all-reduce pair)
+        self.seq_par = bool(sequence_parallel) and tp_size > 1
+        assert not (self.seq_par and cfg.n_experts > 0), "sequence parallelism is implemented for dense MLPs"
         self.cfg = cfg
         self.dtype = dtype
         self.tp_size, self.tp_rank, self.tp_group = tp_size, tp_rank, tp_group
@@ -367,6 +383,10 @@ class Transformer(nn.Module):
         """Returns the final-norm hidden states [T, H] on the last stage, else (h, residual)."""
         if self.has_embed and hidden_in is None:
             h = self.embed_tokens(input_ids)
+            if self.seq_par:
+                from ..parallel.tensor_parallel import ScatterToSP
+
+                h = ScatterToSP.apply(h, self.tp_group)
         else:
             h = hidden_in
         residual = residual_in
@@ -380,13 +400,17 @@ class Transformer(nn.Module):
                 from torch.utils.checkpoint import checkpoint
 
                 h, residual = checkpoint(blk, h, residual, positions, rope, cu_seqlens, max_seqlen, self.tp_group,
-                                         self.sp, self.ep_group, use_reentrant=False)
+                                         self.sp, self.ep_group, self.seq_par, use_reentrant=False)
             else:
                 h, residual = blk(h, residual, positions, rope, cu_seqlens, max_seqlen, self.tp_group, self.sp,
-                                  self.ep_group)
+                                  self.ep_group, self.seq_par)
         if not self.has_head:
             return h, residual
         x, _ = ops.rmsnorm(h, self.norm, self.cfg.rms_norm_eps, residual, self.cfg.gemma_norm)
+        if self.seq_par:  # the LM head / value head sees all tokens again
+            from ..parallel.tensor_parallel import GatherForReplicatedUse
+
+            x = GatherForReplicatedUse.apply(x, self.tp_group)
         return x
 
     def logits(self, hidden: torch.Tensor) -> torch.Tensor:

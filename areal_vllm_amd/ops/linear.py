@@ -11,6 +11,7 @@ summed in fp32 without a rounding step and without a separate add kernel. This i
 from typing import Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn.functional as F
 
 
@@ -24,25 +25,46 @@ def _accumulate_wgrad(weight: torch.Tensor, dy2: torch.Tensor, x2: torch.Tensor)
 
 class _LinearMainGrad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, reduce_dx_group):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.group = reduce_dx_group
         return F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        dx = None
+        dx, work = None, None
         if ctx.needs_input_grad[0]:
             dx = torch.mm(dy2, weight).view(x.shape)
+            if ctx.group is not None:
+                # column-parallel layer: the input gradient is a partial sum over the tensor-parallel
+                # ranks. Its all-reduce is started here and runs on the communicator's stream while the
+                # weight-gradient GEMM below keeps the compute units busy.
+                work = dist.all_reduce(dx, group=ctx.group, async_op=True)
+        main = getattr(weight, "main_grad", None) is not None
+        dw = None
         if ctx.needs_input_grad[1]:
-            _accumulate_wgrad(weight, dy2, x.reshape(-1, x.shape[-1]))
+            if main:
+                _accumulate_wgrad(weight, dy2, x.reshape(-1, x.shape[-1]))
+            else:
+                dw = torch.mm(dy2.t(), x.reshape(-1, x.shape[-1]))
         db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, None, db
+        if work is not None:
+            work.wait()
+        return dx, dw, db, None
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    if torch.is_grad_enabled() and weight.requires_grad and getattr(weight, "main_grad", None) is not None:
-        return _LinearMainGrad.apply(x, weight, bias)
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+           reduce_dx_group=None) -> torch.Tensor:
+    """`reduce_dx_group`: tensor-parallel group of a column-parallel layer whose input is replicated; the
+    backward all-reduces the input gradient over it, overlapped with the weight-gradient GEMM (the
+    reference's async-communication linear, ``realhf/impl/model/parallelism/tensor_parallel/modules.py:
+    242-402``, without its dependence on a single hardware queue)."""
+    if reduce_dx_group is not None and (not dist.is_initialized() or dist.get_world_size(reduce_dx_group) == 1):
+        reduce_dx_group = None
+    if torch.is_grad_enabled() and (reduce_dx_group is not None or (
+            weight.requires_grad and getattr(weight, "main_grad", None) is not None)):
+        return _LinearMainGrad.apply(x, weight, bias, reduce_dx_group)
     return F.linear(x, weight, bias)

@@ -53,6 +53,8 @@ def _act_like(engine, pmb) -> Tuple[Tuple[int, int, int], torch.dtype, torch.dev
     T = int(pmb["input_ids"].shape[0])
     if engine.model.sp is not None:
         T //= engine.model.sp.size
+    if engine.model.seq_par:  # token-sharded residual stream between tensor-parallel regions
+        T //= engine.model.tp_size
     return (2, T, engine.model_config.hidden_size), engine.model.dtype, engine.device
 
 

@@ -71,6 +71,27 @@ class GatherFromSP(torch.autograd.Function):
         return comm.reduce_scatter_rows(g, ctx.group), None
 
 
+class GatherForReplicatedUse(torch.autograd.Function):
+    """Token-sharded [T/tp, H] -> [T, H] for a consumer that every rank evaluates identically (replicated
+    LM head and loss): the upstream gradient is the same on all ranks, so the backward keeps this rank's
+    slice instead of summing tp copies."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        n = _size(group)
+        if n == 1:
+            return x
+        ctx.rank, ctx.rows = dist.get_rank(group), x.shape[0]
+        return comm.all_gather_cat(x, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        if _size(ctx.group) == 1:
+            return g, None
+        return g[ctx.rank * ctx.rows:(ctx.rank + 1) * ctx.rows].contiguous(), None
+
+
 class ReduceScatterToSP(torch.autograd.Function):
     """Partial sums [T, H] -> token-sharded reduced [T/tp, H]; backward all-gathers."""
 

@@ -61,6 +61,7 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
                             mb_spec=MicroBatchSpec(n_mbs=n_mbs, max_tokens_per_mb=4096))
     strategy_kwargs = dict(strategy_kwargs)
     cfg.native.context_parallel_mode = strategy_kwargs.pop("_cp_mode", "ulysses")
+    cfg.native.sequence_parallel = strategy_kwargs.pop("_seq_par", False)
     eng = NativeTrainEngine(cfg)
     st = ParallelStrategy(**strategy_kwargs)
     eng.create_process_group(st)
@@ -147,6 +148,9 @@ def _compare(ref, out, atol=2e-5):
     ("dp2pp2", 4, dict(data_parallel_size=2, pipeline_parallel_size=2), 2),
     ("dp2tp2", 4, dict(data_parallel_size=2, tensor_parallel_size=2), 1),
     ("cp2pp2", 4, dict(context_parallel_size=2, pipeline_parallel_size=2), 2),
+    ("tp2sp", 2, dict(tensor_parallel_size=2, _seq_par=True), 2),
+    ("dp2tp2sp", 4, dict(data_parallel_size=2, tensor_parallel_size=2, _seq_par=True), 1),
+    ("tp2pp2sp", 4, dict(tensor_parallel_size=2, pipeline_parallel_size=2, _seq_par=True), 2),
     ("zigzag2", 2, dict(context_parallel_size=2, _cp_mode="zigzag"), 2),
     ("zigzag4", 4, dict(context_parallel_size=4, _cp_mode="zigzag"), 1),
     ("zigzag2tp2", 4, dict(context_parallel_size=2, tensor_parallel_size=2, _cp_mode="zigzag"), 2),
@@ -172,4 +176,15 @@ def test_expert_parallel_matches_single_process():
     _run(1, {}, None, init, preset_name="tiny-moe")
     _run(1, {}, init, ref, preset_name="tiny-moe")
     _run(2, dict(data_parallel_size=2, expert_parallel_size=2), init, out, preset_name="tiny-moe")
+    _compare(ref, out, atol=5e-5)
+
+
+def test_qk_norm_weights_under_tensor_parallel():
+    """Per-head q/k norm weights are replicated over tp but every rank only sees its own heads: their
+    gradients must be summed over the tp group or the replicas drift apart."""
+    d = tempfile.mkdtemp(prefix="areal_qkn_")
+    init, ref, out = (os.path.join(d, x) for x in ("init", "ref", "tp2"))
+    _run(1, {}, None, init, preset_name="tiny-qknorm")
+    _run(1, {}, init, ref, preset_name="tiny-qknorm")
+    _run(2, dict(tensor_parallel_size=2), init, out, preset_name="tiny-qknorm")
     _compare(ref, out, atol=5e-5)
