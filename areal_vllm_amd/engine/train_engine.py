@@ -397,19 +397,22 @@ class NativeTrainEngine(TrainEngine):
         host_ids = ids.tolist()
         img_tokens = [t for t in (mc.image_token_id, mc.video_token_id) if t is not None]
         merge = int(mc.vision.get("spatial_merge_size", 2))
-        pos3, pixels, grids = [], [], []
+        pos3, masks, pixels, grids = [], [], [], []
         for i in range(len(bounds) - 1):
             item = mm[i] if i < len(mm) else None
             g = item["image_grid_thw"] if item is not None and item.get("image_grid_thw") is not None else None
             g_list = g.tolist() if g is not None else []
-            pos3.append(mrope_position_ids(host_ids[bounds[i]:bounds[i + 1]], g_list, img_tokens, merge)[0])
+            p3, _, msk = mrope_position_ids(host_ids[bounds[i]:bounds[i + 1]], g_list, img_tokens, merge, True)
+            pos3.append(p3)
+            masks.append(msk)
             if g is not None and len(g_list) > 0:
                 pixels.append(item["pixel_values"])
                 grids.append(g)
         positions = torch.cat(pos3, 1).to(ids.device)
         if self.model.has_embed and hidden_in is None:
             px = torch.cat(pixels, 0) if pixels else None
-            hidden_in = self.model.embed_multimodal(ids, px, torch.cat(grids, 0) if grids else None)
+            hidden_in = self.model.embed_multimodal(ids, px, torch.cat(grids, 0) if grids else None,
+                                                    torch.cat(masks))
         return self.model(None, positions, cu, int(mb["max_seqlen"]), hidden_in, residual_in)
 
     def _proxy(self, hidden: torch.Tensor, pad_len: int) -> LogitsProxy:

@@ -273,7 +273,7 @@ class NativeInferenceEngine:
             sched_prompt = prompt
             if mm is not None and self.runner.is_vl:
                 assert self.tp_size == 1, "vision-language serving is single-rank"
-                sched_prompt = self.runner.salted_prompt(prompt, mm["pixel_values"])
+                sched_prompt = self.runner.salted_prompt(prompt, mm["pixel_values"], mm["image_grid_thw"])
             req_id = self.sched.add_request(rid, sched_prompt, sp["max_new_tokens"], sp["min_new_tokens"],
                                             sp["temperature"], sp["top_p"], sp["top_k"], sp["stop_token_ids"])
             if mm is not None and self.runner.is_vl:

@@ -64,18 +64,25 @@ class ModelRunner:
         self.mm: Dict[int, Dict[str, Any]] = {}
 
     # ------------------------------------------------------------------- vision-language requests
-    def salted_prompt(self, prompt_ids: List[int], pixel_values: torch.Tensor) -> List[int]:
+    def _placeholder_mask(self, prompt_ids: List[int], grid_thw: torch.Tensor):
+        from ..models.vision import mrope_position_ids
+
+        cfg = self.cfg
+        img = [t for t in (cfg.image_token_id, cfg.video_token_id) if t is not None]
+        return mrope_position_ids(prompt_ids, grid_thw.tolist(), img, int(cfg.vision.get("spatial_merge_size", 2)), True)
+
+    def salted_prompt(self, prompt_ids: List[int], pixel_values: torch.Tensor, grid_thw: torch.Tensor) -> List[int]:
         """Token ids handed to the scheduler for a prompt with images: every image placeholder becomes an
         id >= vocab_size derived from the pixel data and its index, so that the prefix cache can only match
         prompts that show the same images (samples of one group still share their prefill)."""
         cfg = self.cfg
-        img = {t for t in (cfg.image_token_id, cfg.video_token_id) if t is not None}
         salt = int(torch.frombuffer(bytearray(pixel_values.float().sum(-1).numpy().tobytes()), dtype=torch.int32)
                    .long().sum()) & 0x3FFFFFFF
         span = (1 << 31) - self.V - 1
+        is_img = self._placeholder_mask(prompt_ids, grid_thw)[2].tolist()
         out, j = [], 0
-        for t in prompt_ids:
-            if t in img:
+        for t, m in zip(prompt_ids, is_img):
+            if m:
                 out.append(self.V + (salt + 7919 * j) % span)
                 j += 1
             else:
@@ -84,12 +91,7 @@ class ModelRunner:
 
     def register_multimodal(self, req_id: int, prompt_ids: List[int], pixel_values: torch.Tensor,
                             grid_thw: torch.Tensor):
-        from ..models.vision import mrope_position_ids
-
-        cfg = self.cfg
-        img = [t for t in (cfg.image_token_id, cfg.video_token_id) if t is not None]
-        pos3, delta = mrope_position_ids(prompt_ids, grid_thw.tolist(), img, int(cfg.vision.get("spatial_merge_size", 2)))
-        is_img = torch.tensor([t in img for t in prompt_ids])
+        pos3, delta, is_img = self._placeholder_mask(prompt_ids, grid_thw)
         img_index = torch.where(is_img, torch.cumsum(is_img.long(), 0) - 1, torch.full_like(is_img.long(), -1))
         self.mm[int(req_id)] = dict(pos3=pos3, delta=int(delta), img_index=img_index, pixel_values=pixel_values,
                                     grid_thw=grid_thw, embeds=None)

@@ -353,16 +353,19 @@ class Transformer(nn.Module):
         return h
 
     def embed_multimodal(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor],
-                         grid_thw: Optional[torch.Tensor]) -> torch.Tensor:
-        """Token embeddings with the image placeholder positions replaced, in order, by the vision tower's
-        outputs for `pixel_values` (all images of the packed batch concatenated)."""
+                         grid_thw: Optional[torch.Tensor], mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Token embeddings with the image placeholder positions (`mask`, default: every placeholder id)
+        replaced, in order, by the vision tower's outputs for `pixel_values` (all images of the packed
+        batch concatenated)."""
         h = self.embed_tokens(input_ids)
         if pixel_values is None or pixel_values.numel() == 0:
             return h
         img = self.visual(pixel_values.to(h.device), grid_thw.to(h.device)).to(h.dtype)
-        mask = (input_ids == self.cfg.image_token_id)
-        if self.cfg.video_token_id is not None:
-            mask = mask | (input_ids == self.cfg.video_token_id)
+        if mask is None:
+            mask = (input_ids == self.cfg.image_token_id)
+            if self.cfg.video_token_id is not None:
+                mask = mask | (input_ids == self.cfg.video_token_id)
+        mask = mask.to(h.device)
         n = int(mask.sum())
         assert n == img.shape[0], f"{n} image placeholder tokens but {img.shape[0]} image embeddings"
         return h.masked_scatter(mask.unsqueeze(-1), img)

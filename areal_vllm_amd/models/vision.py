@@ -184,21 +184,24 @@ class VisionTower(nn.Module):
 
 # ------------------------------------------------------------------------------------ M-RoPE
 def mrope_position_ids(input_ids: Sequence[int], grids: Sequence[Sequence[int]], image_token_ids: Sequence[int],
-                       spatial_merge_size: int) -> Tuple[torch.Tensor, int]:
+                       spatial_merge_size: int, return_mask: bool = False):
     """3-D rotary positions [3, S] (temporal, row, column) of one sequence and its position delta
     (``max position + 1 - S``: what generated text tokens add to their sequence index).
 
     Text tokens count up on all three axes; every run of image placeholder tokens takes the next grid
     from `grids` and is numbered by (frame, merged row, merged column) relative to the running position,
-    which then advances by max(rows, columns) of the merged grid."""
+    which then advances by max(rows, columns) of the merged grid. Placeholder ids that appear after all
+    grids are used up (a policy can sample them) are ordinary text. With `return_mask` the boolean mask of
+    the positions that take image features is returned as a third value."""
     ids = list(input_ids)
     S = len(ids)
     img = set(int(x) for x in image_token_ids)
     out = torch.empty(3, S, dtype=torch.long)
+    mask = torch.zeros(S, dtype=torch.bool)
     cur, i, g = 0, 0, 0
     while i < S:
         j = i
-        if ids[i] in img:
+        if ids[i] in img and g < len(grids):
             t, h, w = (int(x) for x in grids[g])
             g += 1
             hh, ww = h // spatial_merge_size, w // spatial_merge_size
@@ -208,15 +211,19 @@ def mrope_position_ids(input_ids: Sequence[int], grids: Sequence[Sequence[int]],
             hp = torch.arange(hh).view(1, hh, 1).expand(t, hh, ww).reshape(-1)
             wp = torch.arange(ww).view(1, 1, ww).expand(t, hh, ww).reshape(-1)
             out[:, i:i + n] = torch.stack([tt, hp, wp]) + cur
+            mask[i:i + n] = True
             cur += max(hh, ww)
             i += n
         else:
-            while j < S and ids[j] not in img:
+            j += 1
+            while j < S and not (ids[j] in img and g < len(grids)):
                 j += 1
             out[:, i:j] = torch.arange(j - i).view(1, -1) + cur
             cur += j - i
             i = j
     delta = int(out.max()) + 1 - S if S else 0
+    if return_mask:
+        return out, delta, mask
     return out, delta
 
 

@@ -304,3 +304,67 @@ def test_driver_smoke_entry():
     import __graft_entry__ as entry
 
     entry.smoke()
+
+
+def test_vision_language_rollout_matches_trainer_on_gpu():
+    """Vision-language requests through the GPU engine (graph decode with per-request position deltas,
+    image features at prefill) against the train engine's recomputation."""
+    import threading
+
+    _env()
+    from areal_vllm_amd.api.cli_args import InferenceServerConfig, MicroBatchSpec, OptimizerConfig, TrainEngineConfig
+    from areal_vllm_amd.api.io_struct import FinetuneSpec
+    from areal_vllm_amd.engine.train_engine import NativeTrainEngine
+    from areal_vllm_amd.inference.engine import NativeInferenceEngine
+    from areal_vllm_amd.utils.data import concat_padded_tensors
+
+    IMG, VS, VE = 500, 502, 503
+    cfg = TrainEngineConfig(experiment_name="v", trial_name="v", path="tiny-vl", init_from_scratch=True,
+                            dtype="bfloat16", gradient_checkpointing=False,
+                            optimizer=OptimizerConfig(lr=1e-3, gradient_clipping=1.0),
+                            mb_spec=MicroBatchSpec(max_tokens_per_mb=1024))
+    eng = NativeTrainEngine(cfg)
+    eng.create_process_group()
+    eng.initialize(None, FinetuneSpec(1, 8, 4))
+    dev = torch.device("cuda", 0)
+    srv = InferenceServerConfig(model_path="tiny-vl", dtype="bfloat16", context_length=512, max_running_requests=8,
+                                num_continuous_decode_steps=4, random_seed=5)
+    roll = NativeInferenceEngine(srv, model_config=eng.model_config, device=dev, num_pages=128)
+    roll.initialize(load_weights=False)
+    roll.load_weights_from_trainer(eng.model, version=0)
+    try:
+        g = torch.Generator().manual_seed(7)
+        cases = []
+        for n_text, grid in ((5, (1, 4, 6)), (40, (1, 8, 8)), (17, (1, 6, 4))):
+            t, h, w = grid
+            txt = torch.randint(3, 480, (n_text + 3,), generator=g).tolist()
+            ids = txt[:n_text] + [VS] + [IMG] * (t * h * w // 4) + [VE] + txt[n_text:]
+            cases.append((ids, dict(pixel_values=torch.randn(t * h * w, 1176, generator=g),
+                                    image_grid_thw=torch.tensor([list(grid)]))))
+        done, ev = {}, threading.Event()
+
+        def cb(i):
+            def f(res):
+                done[i] = res
+                if len(done) == len(cases):
+                    ev.set()
+            return f
+
+        for i, (ids, mm) in enumerate(cases):
+            roll.submit(f"r{i}", ids, max_new_tokens=40, temperature=1.0, callback=cb(i), multimodal=mm)
+        assert ev.wait(120)
+        rows = []
+        for i, (ids, mm) in enumerate(cases):
+            seq = ids + done[i].output_tokens
+            rows.append(dict(input_ids=torch.tensor(seq).unsqueeze(0),
+                             attention_mask=torch.ones(1, len(seq), dtype=torch.bool),
+                             loss_mask=torch.tensor([0] * len(ids) + [1] * 40).unsqueeze(0), multi_modal_input=[mm]))
+        batch = concat_padded_tensors(rows)
+        lp = eng.forward(batch, post_hook=_logp_hook).float().cpu()
+        for b, (ids, _) in enumerate(cases):
+            got = lp[b, len(ids) - 1:len(ids) - 1 + 40]
+            diff = (got - torch.tensor(done[b].output_logprobs)).abs()
+            assert float(diff.mean()) < 0.03 and float(diff.max()) < 0.3, (b, float(diff.mean()), float(diff.max()))
+    finally:
+        roll.destroy()
+        eng.destroy()

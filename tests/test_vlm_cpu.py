@@ -78,8 +78,14 @@ def test_vl_rollout_matches_trainer_and_trains():
             torch.testing.assert_close(got, torch.tensor(bl), atol=2e-3, rtol=1e-3)
         # a different image under the same text must not reuse the first request's cached prefix
         other = dict(cases[0][1], pixel_values=cases[0][1]["pixel_values"] + 1.0)
-        assert roll.runner.salted_prompt(cases[0][0], other["pixel_values"]) != roll.runner.salted_prompt(
-            cases[0][0], cases[0][1]["pixel_values"])
+        grid = cases[0][1]["image_grid_thw"]
+        assert roll.runner.salted_prompt(cases[0][0], other["pixel_values"], grid) != roll.runner.salted_prompt(
+            cases[0][0], cases[0][1]["pixel_values"], grid)
+        # a placeholder id sampled by the policy after the image is ordinary text, for both engines
+        from areal_vllm_amd.models.vision import mrope_position_ids
+        stray = cases[0][0] + [IMG, 7, IMG]
+        p3, _, msk = mrope_position_ids(stray, grid.tolist(), [IMG], 2, True)
+        assert int(msk.sum()) == 6 and not bool(msk[-1]) and p3[:, -1].tolist() == [int(p3[0, -2]) + 1] * 3
 
         before = {n: p.detach().clone() for n, p in eng.model.named_parameters() if n.startswith("visual.blocks.0.attn")}
 
