@@ -173,6 +173,10 @@ class PPOActorConfig(TrainEngineConfig):
     gae_lambda: float = 1.0
     kl_ctl: float = 0.1
     recompute_logprob: bool = False
+    fuse_proximal_logp: bool = field(default=False, metadata={
+        "help": "decoupled loss with ppo_n_minibatches == 1 only: take the proximal log-probs from the training "
+                "forward pass itself (same weights, so the same values as a separate recompute pass) instead of "
+                "running an extra forward over the batch"})
     use_decoupled_loss: bool = False
     behav_imp_weight_cap: Optional[float] = None
     dynamic_sampling: bool = False

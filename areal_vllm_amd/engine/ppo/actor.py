@@ -204,6 +204,10 @@ class PPOActor:
         data["loss_mask"] = loss_mask
         data["logprobs"] = old_logp
 
+    def fuses_proximal_logp(self) -> bool:
+        c = self.config
+        return bool(c.fuse_proximal_logp and c.use_decoupled_loss and c.ppo_n_minibatches == 1)
+
     def ppo_update(self, data: Dict[str, Any]) -> List[Dict[str, float]]:
         cfg = self.config
         if self.dynamic_sampling and len(data["rewards"]) % self.group_size == 0:
@@ -269,7 +273,6 @@ def grpo_loss_fn(logits, input_data: Dict, temperature: float, eps_clip: float, 
     old_logp = input_data["logprobs"]
     advantages = input_data["advantages"]
     loss_mask = input_data["loss_mask"].bool()
-    prox_logp = input_data["prox_logp"]
     labels = torch.roll(input_ids, shifts=-1, dims=-1)
     if isinstance(logits, LogitsProxy):
         logprobs, entropy = logits.logprobs_entropy(labels, temperature)
@@ -278,6 +281,9 @@ def grpo_loss_fn(logits, input_data: Dict, temperature: float, eps_clip: float, 
         logprobs, entropy = ops.gather_logprobs_entropy(logits, labels, temperature)
         n_rows = logits.shape[0]
     entropy = entropy.detach()
+    # fused proximal policy (config.fuse_proximal_logp): with a single minibatch per update the proximal
+    # policy IS the policy this forward pass evaluates, so its log-probs are the detached current ones
+    prox_logp = input_data["prox_logp"] if "prox_logp" in input_data else logprobs.detach()
     loss, stat = ppo_actor_loss_fn(logprobs=logprobs, old_logprobs=old_logp, advantages=advantages, eps_clip=eps_clip,
                                    eps_clip_higher=eps_clip_higher, loss_mask=loss_mask, c_clip=c_clip,
                                    proximal_logprobs=prox_logp, behav_imp_weight_cap=behav_imp_weight_cap)

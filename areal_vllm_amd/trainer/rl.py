@@ -190,7 +190,9 @@ def run_grpo(argv, reward_fn: Optional[Callable] = None,
                                                group=actor.context_and_model_parallel_group)
         sync()
 
-        if config.actor.recompute_logprob or config.actor.use_decoupled_loss:
+        fused_prox = (config.actor.fuse_proximal_logp and config.actor.use_decoupled_loss
+                      and config.actor.ppo_n_minibatches == 1)
+        if (config.actor.recompute_logprob or config.actor.use_decoupled_loss) and not fused_prox:
             with stats_tracker.record_timing("recompute_logp"):
                 batch["prox_logp"] = actor.compute_logp(batch)
         if ref is not None:

@@ -55,6 +55,9 @@ def parse_args():
                    help="keep the KV cache of running generations across weight updates (no re-prefill)")
     p.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
                    help="cpu = gloo rehearsal of the multi-rank control flow with a tiny model (not a benchmark)")
+    p.add_argument("--fuse-prox", action="store_true",
+                   help="take proximal log-probs from the training forward (valid for ppo_n_minibatches=1) instead of "
+                        "a separate recompute pass; off by default to keep the reference's per-step work")
     p.add_argument("--profile-phases", action="store_true", help="print per-phase timings on rank 0 (stderr)")
     return p.parse_args()
 
@@ -110,6 +113,7 @@ def main():
                                   lr_scheduler_type="constant", gradient_clipping=1.0, warmup_steps_proportion=0.001),
         group_size=args.n_samples, eps_clip=0.4, temperature=1.0, reward_scaling=10.0, reward_bias=-0.5, kl_ctl=0.0,
         ppo_n_minibatches=1, recompute_logprob=True, use_decoupled_loss=True, behav_imp_weight_cap=5.0,
+        fuse_proximal_logp=args.fuse_prox,
         adv_norm=AdvNormConfig(mean_level="group", std_level="group", group_size=args.n_samples),
         max_new_tokens=args.max_new_tokens,
     )
@@ -195,8 +199,9 @@ def main():
             tot["all_tokens"] += int(batch["attention_mask"].sum())
             lm = batch["loss_mask"].bool()
             tot["stale_sum"] = tot.get("stale_sum", 0.0) + float((step - batch["versions"][lm]).float().mean())
-        with timed("recompute_logp"):
-            batch["prox_logp"] = actor.compute_logp(batch)
+        if not args.fuse_prox:
+            with timed("recompute_logp"):
+                batch["prox_logp"] = actor.compute_logp(batch)
         with timed("advantages"):
             actor.compute_advantages(batch)
         with timed("train"):
@@ -259,7 +264,8 @@ def main():
                        "max_new_tokens": args.max_new_tokens, "parallelism": f"dp{world} colocated rollout+train",
                        "async_training": args.eta > 0, "max_head_offpolicyness": args.eta,
                        "interrupt_on_weight_update": "retain-kv" if args.retain_kv else "abort+recompute",
-                       "algo": "GRPO, decoupled PPO loss, recompute_logprob, ppo_n_minibatches=1",
+                       "algo": "GRPO, decoupled PPO loss, recompute_logprob, ppo_n_minibatches=1"
+                               + (", proximal log-probs fused into the training forward" if args.fuse_prox else ""),
                        "max_tokens_per_mb": args.max_tokens_per_mb, "decode_steps_per_plan": args.decode_steps},
         }
         print(json.dumps(out), flush=True)

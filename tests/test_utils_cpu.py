@@ -479,3 +479,41 @@ def test_countdown_dataset_and_reward():
     d0 = get_custom_dataset("countdown", 0, 2, type="rl", split="train", n_rows=64)
     d1 = get_custom_dataset("countdown", 1, 2, type="rl", split="train", n_rows=64)
     assert len(d0) == len(d1) == 32 and d0[0]["query_id"] != d1[0]["query_id"]
+
+
+def test_fused_proximal_logp_gives_the_same_update():
+    """With one minibatch per update the proximal log-probs taken from the training forward equal the
+    separately recomputed ones, so both variants must take the same optimizer step."""
+    import os
+
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", AREAL_PLATFORM="cpu")
+    from areal_vllm_amd.api.cli_args import AdvNormConfig, MicroBatchSpec, OptimizerConfig, PPOActorConfig
+    from areal_vllm_amd.api.io_struct import FinetuneSpec
+    from areal_vllm_amd.engine.ppo.actor import NativePPOActor
+
+    def run(fuse):
+        cfg = PPOActorConfig(experiment_name="f", trial_name="f", path="tiny", init_from_scratch=True, dtype="float32",
+                             optimizer=OptimizerConfig(lr=1e-3, gradient_clipping=1.0), group_size=2,
+                             mb_spec=MicroBatchSpec(max_tokens_per_mb=4096), ppo_n_minibatches=1, use_decoupled_loss=True,
+                             recompute_logprob=True, fuse_proximal_logp=fuse, kl_ctl=0.0, gradient_checkpointing=False,
+                             adv_norm=AdvNormConfig("group", "group", 2), behav_imp_weight_cap=5.0)
+        a = NativePPOActor(cfg)
+        a.create_process_group()
+        a.initialize(None, FinetuneSpec(1, 8, 4))
+        g = torch.Generator().manual_seed(0)
+        B, S = 4, 24
+        batch = dict(input_ids=torch.randint(2, 500, (B, S), generator=g), attention_mask=torch.ones(B, S, dtype=torch.bool),
+                     loss_mask=torch.cat([torch.zeros(B, 8), torch.ones(B, S - 8)], 1).long(),
+                     logprobs=-torch.rand(B, S, generator=g) - 5.0, versions=torch.zeros(B, S, dtype=torch.long),
+                     rewards=torch.tensor([1.0, 0.0, 0.0, 1.0]))
+        if not a.actor.fuses_proximal_logp():
+            batch["prox_logp"] = a.compute_logp(batch)
+        a.compute_advantages(batch)
+        st = a.ppo_update(batch)
+        w = a.model.flat.flat.clone()
+        a.destroy()
+        return st[0]["grad_norm"], w
+
+    g0, w0 = run(False)
+    g1, w1 = run(True)
+    assert g0 == pytest.approx(g1, rel=1e-5) and torch.allclose(w0, w1, atol=1e-6)
