@@ -368,3 +368,105 @@ def test_vision_language_rollout_matches_trainer_on_gpu():
     finally:
         roll.destroy()
         eng.destroy()
+
+
+def test_decoupled_server_process_with_disk_weight_updates(tmp_path):
+    """Decoupled deployment on one GPU: the rollout engine runs as its own HTTP server process, the trainer
+    talks to it through the remote client, publishes weights as a HF checkpoint on disk, and after every
+    update the server's behaviour log-probs must agree with the trainer's recomputation (which proves that
+    the new weights arrived)."""
+    import socket
+    import subprocess
+    import time
+
+    import requests
+
+    _env()
+    from areal_vllm_amd.api.cli_args import (AdvNormConfig, GenerationHyperparameters, InferenceEngineConfig,
+                                             MicroBatchSpec, OptimizerConfig, PPOActorConfig)
+    from areal_vllm_amd.api.io_struct import FinetuneSpec, WeightUpdateMeta
+    from areal_vllm_amd.engine.ppo.actor import NativePPOActor
+    from areal_vllm_amd.engine.remote_engine import RemoteInferenceEngine
+    from areal_vllm_amd.utils import name_resolve
+    from areal_vllm_amd.workflow.rlvr import RLVRWorkflow
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, AREAL_LOG_LEVEL="WARNING")
+    srv = subprocess.Popen([sys.executable, "-m", "areal_vllm_amd.inference.server", "--model-path", "small", "--dtype",
+                            "bfloat16", "--port", str(port), "--kv-cache-gb", "1", "--context-length", "1024",
+                            "--max-running-requests", "32", "--num-continuous-decode-steps", "4"], env=env, cwd=ROOT)
+    actor = client = None
+    try:
+        deadline = time.time() + 150
+        while True:
+            try:
+                if requests.get(f"http://127.0.0.1:{port}/health", timeout=2).status_code == 200:
+                    break
+            except requests.RequestException:
+                pass
+            assert srv.poll() is None, "server exited"
+            assert time.time() < deadline, "server did not come up"
+            time.sleep(0.5)
+        name_resolve.reconfigure("memory")
+        cfg = PPOActorConfig(experiment_name="dec", trial_name="t", path="small", init_from_scratch=True,
+                             dtype="bfloat16", optimizer=OptimizerConfig(lr=5e-3, gradient_clipping=1.0), group_size=2,
+                             mb_spec=MicroBatchSpec(max_tokens_per_mb=4096), ppo_n_minibatches=1,
+                             use_decoupled_loss=True, recompute_logprob=True, kl_ctl=0.0, gradient_checkpointing=False,
+                             adv_norm=AdvNormConfig("group", "group", 2))
+        actor = NativePPOActor(cfg)
+        actor.create_process_group()
+        actor.initialize(None, FinetuneSpec(1, 100, 4))
+        actor.model.flat.flat.mul_(1.25)  # make the trainer differ from the server's own random init
+        actor.optimizer.resync_master_from_params()
+        client = RemoteInferenceEngine(InferenceEngineConfig(experiment_name="dec", trial_name="t", setup_timeout=60,
+                                                             max_concurrent_rollouts=16, consumer_batch_size=8))
+        client.initialize(addr=f"127.0.0.1:{port}", train_data_parallel_size=1)
+        meta = WeightUpdateMeta.from_disk("dec", "t", str(tmp_path))
+        g = GenerationHyperparameters(n_samples=2, max_new_tokens=48, temperature=1.0, stop_token_ids=[1])
+        wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: float(sum(ci) % 2), g, reward_in_process=True)
+        gen = torch.Generator().manual_seed(11)
+        prompts = [dict(input_ids=torch.randint(2, 4000, (n,), generator=gen).tolist()) for n in (9, 33, 70, 140)]
+        dev = actor.device
+
+        def publish(version):
+            client.pause()
+            fut = client.update_weights(meta)
+            actor.upload_weights(meta)
+            assert fut.result(timeout=300)
+            actor.set_version(version)
+            client.set_version(version)
+            client.resume()
+
+        def agreement(version):
+            batch = client.rollout_batch(prompts, workflow=wf)
+            batch = {k: v.to(dev) if torch.is_tensor(v) else v for k, v in batch.items()}
+            lm = batch["loss_mask"].bool()
+            assert torch.all(batch["versions"][lm] == version)
+            prox = actor.compute_logp(batch)
+            m = torch.roll(lm, -1, 1)
+            m[:, -1] = False
+            return batch, prox, float((prox.float() - torch.roll(batch["logprobs"], -1, 1).float()).abs()[m].mean())
+
+        _, _, d_before = agreement(0)
+        assert d_before > 0.05, d_before  # different weights: log-probs disagree
+        publish(1)
+        batch, prox, d1 = agreement(1)
+        assert d1 < 0.02, d1
+        batch["prox_logp"] = prox
+        actor.compute_advantages(batch)
+        actor.ppo_update(batch)
+        publish(2)
+        _, _, d2 = agreement(2)
+        assert d2 < 0.02, d2
+    finally:
+        if client is not None:
+            client.destroy()
+        if actor is not None:
+            actor.destroy()
+        srv.terminate()
+        try:
+            srv.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            srv.kill()
