@@ -177,19 +177,27 @@ def allocate_balanced_mbs_synced(mb_spec: MicroBatchSpec, lens: List[int], group
     groups = allocate_balanced_mbs(mb_spec, lens)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return groups
-    while True:
-        n = torch.tensor([len(groups)], dtype=torch.int64)
-        dev = _group_device(group)
-        n = n.to(dev)
+    dev = _group_device(group)
+    for _ in range(8):
+        # one MAX all-reduce of (count, -count) gives the group-wide maximum and minimum; the loop ends on
+        # a condition every rank evaluates identically, so all ranks issue the same number of collectives
+        n = torch.tensor([len(groups), -len(groups)], dtype=torch.int64, device=dev)
         dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
-        if int(n.item()) == len(groups):
+        hi, lo = int(n[0].item()), -int(n[1].item())
+        if hi == lo:
             return groups
-        groups = allocate_balanced_mbs(MicroBatchSpec.new(mb_spec, n_mbs=int(n.item())), lens)
+        if len(groups) != hi:
+            groups = allocate_balanced_mbs(MicroBatchSpec.new(mb_spec, n_mbs=hi), lens)
+    raise RuntimeError("data-parallel ranks could not agree on a micro-batch count")
 
 
 def _group_device(group=None):
-    backend = dist.get_backend(group)
-    return torch.device("cuda", torch.cuda.current_device()) if "nccl" in str(backend) else torch.device("cpu")
+    """Device for small host-side bookkeeping collectives: the CPU whenever the group has a gloo side
+    (the default "cpu:gloo,cuda:nccl" groups do), so reading the result does not synchronise the GPU."""
+    backend = str(dist.get_backend(group))
+    if "gloo" in backend or "nccl" not in backend:
+        return torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 @dataclasses.dataclass

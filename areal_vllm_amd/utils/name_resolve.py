@@ -500,9 +500,15 @@ _bind()
 atexit.register(lambda: DEFAULT_REPOSITORY.reset())
 
 
-def reconfigure(config):
-    """Switch the module-level repository (called by ``load_expr_config`` on every process)."""
+def reconfigure(config, **kwargs):
+    """Switch the module-level repository (called by ``load_expr_config`` on every process). `config` is a
+    ``NameResolveConfig``-like object or just the type name with its settings as keywords, e.g.
+    ``reconfigure("nfs", nfs_record_root="/tmp/x")`` or ``reconfigure("memory")``."""
     global DEFAULT_REPOSITORY
+    if isinstance(config, str):
+        import types
+
+        config = types.SimpleNamespace(type=config, **kwargs)
     try:
         DEFAULT_REPOSITORY.reset()
     except Exception:

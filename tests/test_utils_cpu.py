@@ -517,3 +517,48 @@ def test_fused_proximal_logp_gives_the_same_update():
     g0, w0 = run(False)
     g1, w1 = run(True)
     assert g0 == pytest.approx(g1, rel=1e-5) and torch.allclose(w0, w1, atol=1e-6)
+
+
+def _harness_body(rank, world, shared):
+    import torch.distributed as dist
+
+    from areal_vllm_amd.utils import name_resolve
+
+    t = torch.tensor([float(rank + shared["bias"])])
+    dist.all_reduce(t)
+    name_resolve.add_subentry("harness/peers", str(rank))
+    dist.barrier()
+    return float(t), sorted(name_resolve.get_subtree("harness/peers"))
+
+
+def test_local_multiprocess_harness():
+    from areal_vllm_amd.base.testing import LocalMultiProcessTest
+
+    res = LocalMultiProcessTest(3, _harness_body, shared=dict(bias=1)).launch()
+    assert all(r[0] == 6.0 and r[1] == ["0", "1", "2"] for r in res)
+
+    def boom(rank, world, shared):
+        raise ValueError("x")
+
+    with pytest.raises(Exception):
+        LocalMultiProcessTest(1, _harness_body, shared=None).launch()  # shared=None -> TypeError inside the rank
+
+
+def _mb_sync_body(rank, world, shared):
+    from areal_vllm_amd.api.cli_args import MicroBatchSpec
+    from areal_vllm_amd.utils.data import allocate_balanced_mbs_synced
+
+    lens = [[100] * 4, [100] * 9, [100] * 3][rank]  # 1, 3 and 1 micro-batches of <= 400 tokens on their own
+    out = []
+    for _ in range(3):  # repeated calls must stay aligned (no rank may skip a collective)
+        groups = allocate_balanced_mbs_synced(MicroBatchSpec(max_tokens_per_mb=400), lens)
+        out.append((len(groups), sorted(i for g in groups for i in g) == list(range(len(lens)))))
+    return out
+
+
+def test_micro_batch_count_is_synchronised_across_ranks():
+    from areal_vllm_amd.base.testing import LocalMultiProcessTest
+
+    res = LocalMultiProcessTest(3, _mb_sync_body, timeout=120).launch()
+    counts = {c for r in res for c, _ in r}
+    assert len(counts) == 1 and counts.pop() >= 3 and all(ok for r in res for _, ok in r)
