@@ -236,7 +236,15 @@ def get(name: str = "") -> DistributedStatsTracker:
 def export_all(reduce_group=None, reset=True) -> Dict[str, float]:
     out: Dict[str, float] = {}
     dup = set()
-    for tracker in list(TRACKERS.values()):
+    names = list(TRACKERS.keys())
+    if reduce_group is not None and dist.is_initialized() and dist.get_world_size(reduce_group) > 1:
+        # named trackers are created lazily (e.g. by the first rollout that reports a reward): every rank
+        # must walk the same list in the same order or the per-tracker collectives would pair up wrongly
+        gathered = [None] * dist.get_world_size(reduce_group)
+        dist.all_gather_object(gathered, names, group=reduce_group)
+        names = sorted(set(n for ns in gathered for n in ns))
+    for name in names:
+        tracker = get(name)
         x = tracker.export(reduce_group=reduce_group, reset=reset)
         dup |= set(x) & set(out)
         out.update(x)
