@@ -212,6 +212,11 @@ def _update_from_disk(experiment_name, trial_name, model_version, addresses, pat
 
 def _update_from_distributed(meta: WeightUpdateMeta, addresses, retries, timeout, init_group, next_version):
     if init_group:
+        from ..platforms import current_platform
+
+        # RCCL between GPUs; on the CPU platform the same broadcast protocol runs over gloo (the trainer side
+        # makes the same choice in NativeTrainEngine._init_weight_update_group)
+        backend = "gloo" if (meta.type == "gloo" or current_platform.device_type == "cpu") else "nccl"
         tp = meta.alloc_mode.gen.tp_size if meta.alloc_mode is not None else 1
         world = (meta.alloc_mode.gen.world_size if meta.alloc_mode is not None else len(addresses)) + 1
 
@@ -222,7 +227,7 @@ def _update_from_distributed(meta: WeightUpdateMeta, addresses, retries, timeout
                     arequest_with_retry(addr=a, session=session, endpoint="/init_weights_update_group", method="POST",
                                         payload=dict(master_address=meta.nccl_master_address,
                                                      master_port=str(meta.nccl_master_port), rank_offset=1 + i * tp,
-                                                     world_size=world, backend="nccl" if meta.type != "gloo" else "gloo",
+                                                     world_size=world, backend=backend,
                                                      group_name=meta.nccl_group_name),
                                         max_retries=retries, timeout=timeout) for i, a in enumerate(addresses)])
 

@@ -139,3 +139,86 @@ def test_interrupted_generation_spans_versions(server):
     assert vs <= {base, base + 1} and (base + 1) in vs
     assert resp.output_versions == sorted(resp.output_versions)
     client.destroy()
+
+
+def test_collective_weight_update_into_server_process(tmp_path):
+    """Default weight path of the decoupled allocation: trainer rank 0 and the rollout server join a second
+    process group and the trainer broadcasts every HF-named parameter chunk by chunk (gloo on CPU, RCCL on
+    GPUs). Afterwards the server scores its own samples like the trainer does."""
+    import subprocess
+
+    from areal_vllm_amd.api.alloc_mode import AllocationMode
+    from areal_vllm_amd.api.cli_args import (AdvNormConfig, GenerationHyperparameters, InferenceEngineConfig,
+                                             MicroBatchSpec, OptimizerConfig, PPOActorConfig)
+    from areal_vllm_amd.api.io_struct import FinetuneSpec, WeightUpdateMeta
+    from areal_vllm_amd.engine.ppo.actor import NativePPOActor
+    from areal_vllm_amd.engine.remote_engine import RemoteInferenceEngine
+    from areal_vllm_amd.workflow.rlvr import RLVRWorkflow
+
+    os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+                      AREAL_PLATFORM="cpu", GLOO_SOCKET_IFNAME="lo")
+    port = _free_port()
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    srv = subprocess.Popen([sys.executable, "-m", "areal_vllm_amd.inference.server", "--model-path", "tiny", "--dtype",
+                            "float32", "--device", "cpu", "--num-pages", "64", "--context-length", "128",
+                            "--max-running-requests", "8", "--port", str(port)], env=env, cwd=ROOT)
+    actor = client = None
+    try:
+        deadline = time.time() + 120
+        while True:
+            try:
+                if requests.get(f"http://127.0.0.1:{port}/health", timeout=2).status_code == 200:
+                    break
+            except requests.RequestException:
+                pass
+            assert srv.poll() is None and time.time() < deadline
+            time.sleep(0.5)
+        cfg = PPOActorConfig(experiment_name="col", trial_name="t", path="tiny", init_from_scratch=True, dtype="float32",
+                             optimizer=OptimizerConfig(lr=1e-3), group_size=2, mb_spec=MicroBatchSpec(max_tokens_per_mb=2048),
+                             ppo_n_minibatches=1, use_decoupled_loss=True, recompute_logprob=True, kl_ctl=0.0,
+                             adv_norm=AdvNormConfig("group", "group", 2), gradient_checkpointing=False)
+        actor = NativePPOActor(cfg)
+        actor.create_process_group()
+        actor.initialize(None, FinetuneSpec(1, 16, 4))
+        actor.model.flat.flat.mul_(1.3)
+        client = RemoteInferenceEngine(InferenceEngineConfig(experiment_name="col", trial_name="t", setup_timeout=60,
+                                                             max_concurrent_rollouts=8, consumer_batch_size=4))
+        client.initialize(addr=f"127.0.0.1:{port}", train_data_parallel_size=1)
+        meta = WeightUpdateMeta.from_fsdp_nccl(AllocationMode.from_str("native:d1+native:d1"), actor,
+                                               weight_chunked_mem_mb=1)
+        meta.nccl_master_address = "127.0.0.1"
+        assert len(meta.nccl_param_specs) > 1  # several chunks
+        wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: 1.0, GenerationHyperparameters(n_samples=2, max_new_tokens=10),
+                          reward_in_process=True)
+        prompts = [dict(input_ids=[5, 6, 7, 8]), dict(input_ids=[9, 10, 11])]
+
+        def gap():
+            b = client.rollout_batch(prompts, workflow=wf)
+            prox = actor.compute_logp(b)
+            lm = torch.roll(b["loss_mask"].bool(), -1, 1)
+            lm[:, -1] = False
+            return float((prox - torch.roll(b["logprobs"], -1, 1)).abs()[lm].max()), b
+
+        g0, _ = gap()
+        assert g0 > 1e-2
+        for version in (1, 2):  # the second round reuses the group
+            client.pause()
+            fut = client.update_weights(meta)
+            actor.upload_weights(meta)
+            assert fut.result(timeout=120)
+            client.set_version(version)
+            client.resume()
+            g, b = gap()
+            assert g < 1e-3, g
+            assert (b["versions"][b["loss_mask"].bool()] == version).all()
+            actor.model.flat.flat.mul_(0.9)
+    finally:
+        if client is not None:
+            client.destroy()
+        if actor is not None:
+            actor.destroy()
+        srv.terminate()
+        try:
+            srv.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            srv.kill()
