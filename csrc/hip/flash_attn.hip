@@ -67,9 +67,17 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
 
   // 1-D grid, query-tile rank first: rank 0 is the LAST (heaviest under causal masking) tile of every
   // (sequence, head), so heavy workgroups of all sequences start first and light ones fill the tail.
-  const int n_bh = Hq * nbatch;
-  const int rank = blockIdx.x / n_bh, bh = blockIdx.x - rank * n_bh;
-  const int b = bh / Hq, head = bh - b * Hq;
+  // XCD placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2. Inside
+  // a rank the (sequence, kv head) group index g runs fastest over an extent padded to a multiple of 8, so
+  // id % 8 == g % 8: every query head and every query tile that reads the K/V of one group runs on the
+  // same XCD and finds those tiles in its L2 instead of fetching them from HBM once per XCD.
+  const int G = Hq / Hkv;
+  const int n_g = Hkv * nbatch, n_g_pad = (n_g + 7) & ~7;
+  const int per_rank = G * n_g_pad;
+  const int rank = blockIdx.x / per_rank, rem = blockIdx.x - rank * per_rank;
+  const int hj = rem / n_g_pad, g = rem - hj * n_g_pad;
+  if (g >= n_g) return;
+  const int b = g / Hkv, head = (g - b * Hkv) * G + hj;
   const int q_beg = cu_q[b], q_len = cu_q[b + 1] - q_beg;
   const int k_beg = cu_k[b], k_len = cu_k[b + 1] - k_beg;
   const int ntile_q = (q_len + 127) / 128;
@@ -227,7 +235,8 @@ extern "C" int areal_flash_fwd(const void* q, const void* k, const void* v, void
   if (Hq % Hkv != 0) return -2;
   if ((q_stride | k_stride | v_stride | o_stride) % 8 != 0) return -3;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 != 0) return -4;
-  dim3 grid((unsigned)(((max_q + 127) / 128) * Hq * B)), block(256);
+  const int n_g_pad = (Hkv * B + 7) & ~7;  // see the XCD placement note in the kernel
+  dim3 grid((unsigned)(((max_q + 127) / 128) * (Hq / Hkv) * n_g_pad)), block(256);
   hipLaunchKernelGGL(flash_fwd_kernel, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
                      (const bf16_t*)v, (bf16_t*)o, lse, cu_q, cu_k, q_stride, k_stride, v_stride,
                      o_stride, Hq, Hkv, B, total_q, softmax_scale * 1.4426950408889634f, causal);
@@ -287,6 +296,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
   // key-block index (later keys are seen by fewer queries), so the heaviest workgroups of ALL sequences
   // are dispatched first and the light ones fill the tail (longest-processing-time-first scheduling;
   // a (block, head, sequence) grid leaves CUs idle behind each sequence's heavy blocks).
+  // (No XCD grouping here, unlike the forward: pinning all key blocks of a group to one XCD cut HBM reads by
+  // 30 % but cost 5 % run time on 50 groups, because 50 groups do not spread evenly over 8 XCDs and this
+  // kernel runs one workgroup per CU.)
   const int n_bh = Hkv * nbatch;
   const int bid = blockIdx.x;
   const int kblk = bid / n_bh, bh = bid - kblk * n_bh;
