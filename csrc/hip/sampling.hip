@@ -6,7 +6,8 @@
 // realhf/impl/model/nn/real_llm_generate.py:30-146) and SGLang's sampler.
 //
 //  * greedy (temperature == 0): arg-max.
-//  * unfiltered (top_k >= V and top_p >= 1): Gumbel-max over z = logit / T. One pass, no sort.
+//  * unfiltered (top_k >= V and top_p >= 1): Gumbel-max over z = logit / T, in the same single pass
+//    over the row (16-byte loads) that accumulates the running max / sum-exp for the log-prob.
 //  * filtered: thresholds for top-k (k-th largest z) and top-p (smallest set whose mass
 //    reaches top_p of the top-k mass) are found by bisection on z, then Gumbel-max runs over
 //    the surviving entries. No sort, no [B, V] temporaries.
@@ -51,6 +52,33 @@ DEVINL ArgMax block_argmax(ArgMax x, float* redv, int* redi) {
 template <typename T>
 DEVINL float ldz(const T* p, int i) { return (float)p[i]; }
 
+// 8 consecutive entries of a row as floats (one 16-byte load for bf16, two for fp32)
+DEVINL void load8(const bf16_t* p, float* z) {
+  const bf16x8 v = ld8(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) z[j] = (float)v[j];
+}
+DEVINL void load8(const float* p, float* z) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { z[j] = a[j]; z[4 + j] = b[j]; }
+}
+
+// f(i, z_i) over one row: vector loads over [0, V8), scalar loads over the tail [V8, V)
+template <typename T, typename F>
+DEVINL void for_each_z(const T* p, int V, int V8, float inv_t, F f) {
+  for (int i8 = threadIdx.x * 8; i8 < V8; i8 += blockDim.x * 8) {
+    float z[8];
+    load8(p + i8, z);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f(i8 + j, z[j] * inv_t);
+  }
+  for (int i = V8 + threadIdx.x; i < V; i += blockDim.x) f(i, ldz(p, i) * inv_t);
+}
+
+DEVINL float gumbel(uint32_t bits) { return -__logf(-__logf(u32_to_unit(bits) * 0.99999994f)); }
+
 template <typename T>
 __global__ __launch_bounds__(1024) void sample_kernel(
     const T* __restrict__ logits, int64_t ld, int V, const float* __restrict__ temperature,
@@ -68,24 +96,76 @@ __global__ __launch_bounds__(1024) void sample_kernel(
   const int k = top_k ? top_k[row] : V;
   const float tp = top_p ? top_p[row] : 1.f;
   const uint64_t step = step_ptr ? (uint64_t)step_ptr[0] : 0;
+  const bool filtered = !greedy && ((k < V && k >= 1) || tp < 1.f);
+  // noise word of entry i: word i & 3 of the Philox block with counter ctr0 + i / 4
+  const uint64_t ctr0 = step * (uint64_t)((V + 3) / 4);
+  const int V8 = (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? (V & ~7) : 0;
 
-  // pass 1: max / min of z
-  float mx = -INFINITY, mn = INFINITY;
-  for (int i = threadIdx.x; i < V; i += blockDim.x) {
-    const float z = ldz(p, i) * inv_t;
-    mx = fmaxf(mx, z);
-    mn = fminf(mn, z);
+  // pass 1: running max / sum-exp (rescaled when the max moves) and min of z. Without filtering the
+  // arg-max of z (+ Gumbel noise unless greedy) is taken in the same pass, so the row is read once.
+  const bool pick_now = !filtered;
+  const bool noise = !greedy;
+  float mx = -INFINITY, mn = INFINITY, se = 0.f;
+  ArgMax best;
+  best.v = -INFINITY;
+  best.i = 0x7fffffff;
+  for (int i8 = threadIdx.x * 8; i8 < V8; i8 += blockDim.x * 8) {
+    float z[8];
+    load8(p + i8, z);
+    float m8 = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      z[j] *= inv_t;
+      m8 = fmaxf(m8, z[j]);
+      mn = fminf(mn, z[j]);
+    }
+    if (m8 > mx) {
+      se *= __expf(mx - m8);
+      mx = m8;
+    }
+    if (mx > -INFINITY) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) se += __expf(z[j] - mx);
+    }
+    if (pick_now) {
+      u32x4 r0, r1;
+      if (noise) {
+        r0 = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i8 >> 2));
+        r1 = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i8 >> 2) + 1);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ArgMax c;
+        c.v = noise ? z[j] + gumbel(j < 4 ? r0[j] : r1[j - 4]) : z[j];
+        c.i = i8 + j;
+        best = amax(best, c);
+      }
+    }
   }
-  mx = block_max(mx, red);
+  for (int i = V8 + threadIdx.x; i < V; i += blockDim.x) {
+    const float z = ldz(p, i) * inv_t;
+    mn = fminf(mn, z);
+    if (z > mx) {
+      se *= __expf(mx - z);
+      mx = z;
+    }
+    if (mx > -INFINITY) se += __expf(z - mx);
+    if (pick_now) {
+      ArgMax c;
+      c.v = z;
+      c.i = i;
+      if (noise) c.v += gumbel(Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i >> 2))[i & 3]);
+      best = amax(best, c);
+    }
+  }
+  const float mx_all = block_max(mx, red);
   mn = -block_max(-mn, red);
-  // pass 2: sum exp
-  float se = 0.f;
-  for (int i = threadIdx.x; i < V; i += blockDim.x) se += __expf(ldz(p, i) * inv_t - mx);
-  se = block_sum(se, red);
+  se = block_sum(mx > -INFINITY ? se * __expf(mx - mx_all) : 0.f, red);
+  mx = mx_all;
   const float lse = mx + __logf(se);
 
-  float thr = -INFINITY;
-  if (!greedy && (k < V || tp < 1.f)) {
+  if (filtered) {
+    float thr = -INFINITY;
     float lo, hi;
     float mass_k = se;  // mass (relative to exp(-mx)) of the top-k set
     if (k < V && k >= 1) {
@@ -94,16 +174,13 @@ __global__ __launch_bounds__(1024) void sample_kernel(
       for (int it = 0; it < 32; ++it) {
         const float mid = 0.5f * (lo + hi);
         float cnt = 0.f;
-        for (int i = threadIdx.x; i < V; i += blockDim.x) cnt += (ldz(p, i) * inv_t >= mid) ? 1.f : 0.f;
+        for_each_z(p, V, V8, inv_t, [&](int, float z) { cnt += z >= mid ? 1.f : 0.f; });
         cnt = block_sum(cnt, red);
         if (cnt >= (float)k) lo = mid; else hi = mid;
       }
       thr = lo;
       float mk = 0.f;
-      for (int i = threadIdx.x; i < V; i += blockDim.x) {
-        const float z = ldz(p, i) * inv_t;
-        mk += z >= thr ? __expf(z - mx) : 0.f;
-      }
+      for_each_z(p, V, V8, inv_t, [&](int, float z) { mk += z >= thr ? __expf(z - mx) : 0.f; });
       mass_k = block_sum(mk, red);
     }
     if (tp < 1.f) {
@@ -113,35 +190,26 @@ __global__ __launch_bounds__(1024) void sample_kernel(
       for (int it = 0; it < 32; ++it) {
         const float mid = 0.5f * (lo + hi);
         float ms = 0.f;
-        for (int i = threadIdx.x; i < V; i += blockDim.x) {
-          const float z = ldz(p, i) * inv_t;
-          ms += z >= mid ? __expf(z - mx) : 0.f;
-        }
+        for_each_z(p, V, V8, inv_t, [&](int, float z) { ms += z >= mid ? __expf(z - mx) : 0.f; });
         ms = block_sum(ms, red);
         if (ms >= target) lo = mid; else hi = mid;
       }
       thr = fmaxf(thr, lo);
     }
-  }
-
-  // final pass: arg-max of z (+ Gumbel noise unless greedy) over entries with z >= thr
-  ArgMax best;
-  best.v = -INFINITY;
-  best.i = 0x7fffffff;
-  for (int i4 = threadIdx.x * 4; i4 < V; i4 += blockDim.x * 4) {
-    u32x4 r;
-    if (!greedy) r = Philox::gen(seed, (uint64_t)row, step * (uint64_t)((V + 3) / 4) + (uint64_t)(i4 >> 2));
+    // arg-max of z + Gumbel noise over the entries that survive the threshold
+    for (int i4 = threadIdx.x * 4; i4 < V; i4 += blockDim.x * 4) {
+      const u32x4 r = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i4 >> 2));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = i4 + j;
-      if (i < V) {
-        float z = ldz(p, i) * inv_t;
-        if (z >= thr) {
-          if (!greedy) z += -__logf(-__logf(u32_to_unit(r[j]) * 0.99999994f));
-          ArgMax c;
-          c.v = z;
-          c.i = i;
-          best = amax(best, c);
+      for (int j = 0; j < 4; ++j) {
+        const int i = i4 + j;
+        if (i < V) {
+          const float z = ldz(p, i) * inv_t;
+          if (z >= thr) {
+            ArgMax c;
+            c.v = z + gumbel(r[j]);
+            c.i = i;
+            best = amax(best, c);
+          }
         }
       }
     }
