@@ -275,7 +275,8 @@ class NativeTrainEngine(TrainEngine):
         """(lo, hi, replication) flat ranges of parameters that more than one tp rank holds."""
         rep = []
         for n, (o, numel) in self.model.flat.offsets.items():
-            if n.split(".")[-1] in ("ln1", "ln2", "norm", "q_norm", "k_norm", "embed", "head", "router"):
+            if n.split(".")[-1] in ("ln1", "ln2", "norm", "q_norm", "k_norm", "embed", "head", "router", "ln1_bias",
+                                    "ln2_bias", "norm_bias", "pos_embed", "o_bias", "proj_bias"):
                 rep.append((o, o + numel, self.grid.tp))
         if self._kv_replication() > 1:
             rep += self._kv_ranges()

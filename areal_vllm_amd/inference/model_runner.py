@@ -47,6 +47,10 @@ class ModelRunner:
         if not self.buckets or self.buckets[-1] < max_batch:
             self.buckets.append(max_batch)
         cfg = self.cfg
+        if cfg.norm_type != "rms" or cfg.pos_embed != "rope" or not cfg.mlp_gated or cfg.linear_bias:
+            raise NotImplementedError(
+                f"the rollout engine serves the RMSNorm / rotary / gated-MLP families; {cfg.family} is a "
+                "training-side family (train engine, checkpoint conversion)")
         self.hq = model.layers[0].attn.hq
         self.hkv = model.layers[0].attn.hkv
         self.kv = [ops.alloc_kv_cache(num_pages, self.hkv, cfg.head_dim, self.dtype, self.device)

@@ -1,7 +1,9 @@
 """Architecture description of the native transformer and its mapping from HF ``config.json``.
 
 Covers the dense families the reference converts in ``realhf/api/from_hf/{llama,qwen2,qwen3,mistral,
-gemma}.py`` plus MoE (``mixtral``, ``qwen3_moe``) through the ``n_experts`` fields. The reference's
+gemma,gpt2}.py`` plus MoE (``mixtral``, ``qwen3_moe``) through the ``n_experts`` fields. GPT-2 differs
+from the rest in four switches: LayerNorm with bias (``norm_type``), learned absolute positions
+(``pos_embed``), a plain two-matrix MLP (``mlp_gated``) and biases on every linear (``linear_bias``). The reference's
 ``ReaLModelConfig`` (``realhf/api/core/model_api.py:340``) is the analogue.
 """
 import dataclasses
@@ -29,6 +31,10 @@ class ModelConfig:
     qk_norm: bool = False  # per-head RMSNorm on q and k (Qwen3)
     gemma_norm: bool = False  # (1 + w) RMSNorm weights and sqrt(H) embedding scale (Gemma)
     hidden_act: str = "silu"  # gate activation of the MLP: "silu" (SwiGLU) or "gelu_tanh" (GeGLU, Gemma)
+    norm_type: str = "rms"  # "rms" or "layer" (LayerNorm with bias, GPT-2)
+    pos_embed: str = "rope"  # "rope" or "learned" (absolute position table added to the embeddings, GPT-2)
+    mlp_gated: bool = True  # False: fc -> activation -> proj without a gate (GPT-2)
+    linear_bias: bool = False  # biases on the attention output and MLP projections (GPT-2)
     is_critic: bool = False  # value head [1, H] instead of the LM head
     # mixture of experts (0 = dense)
     n_experts: int = 0
@@ -62,6 +68,14 @@ class ModelConfig:
 
     def n_params(self, with_embedding: bool = True) -> int:
         H, F, L = self.hidden_size, self.intermediate_size, self.n_layers
+        if not self.mlp_gated:  # GPT-2 layout: biases everywhere, two norms with bias, fc / proj
+            per_layer = H * self.qkv_dim + self.qkv_dim + self.q_dim * H + H + 4 * H + 2 * H * F + F + H
+            n = L * per_layer + 2 * H
+            if with_embedding:
+                n += (self.vocab_size + self.max_position_embeddings) * H
+                if not self.tie_word_embeddings and not self.is_critic:
+                    n += self.vocab_size * H
+            return n + (H if self.is_critic else 0)
         per_layer = H * self.qkv_dim + (self.qkv_dim if self.qkv_bias else 0) + self.q_dim * H + 2 * H
         if self.n_experts > 0:
             per_layer += H * self.n_experts + self.n_experts * 3 * H * self.moe_intermediate_size
@@ -96,6 +110,15 @@ class ModelConfig:
             cfg.qkv_bias = bool(text.get("attention_bias", True))
             return cfg
         mt = d.get("model_type", "qwen2")
+        if mt == "gpt2":
+            H, nq = d["n_embd"], d["n_head"]
+            return cls(family="gpt2", vocab_size=d["vocab_size"], hidden_size=H, n_layers=d["n_layer"], n_q_heads=nq,
+                       n_kv_heads=nq, head_dim=H // nq, intermediate_size=d.get("n_inner") or 4 * H,
+                       rms_norm_eps=d.get("layer_norm_epsilon", 1e-5), max_position_embeddings=d.get("n_positions", 1024),
+                       tie_word_embeddings=bool(d.get("tie_word_embeddings", True)), qkv_bias=True,
+                       hidden_act="gelu_tanh", norm_type="layer", pos_embed="learned", mlp_gated=False,
+                       linear_bias=True, is_critic=is_critic, bos_token_id=d.get("bos_token_id"),
+                       eos_token_id=d.get("eos_token_id"), pad_token_id=d.get("pad_token_id"))
         H = d["hidden_size"]
         nq = d["num_attention_heads"]
         nkv = d.get("num_key_value_heads", nq)
@@ -157,6 +180,14 @@ class ModelConfig:
                     "image_token_id": self.image_token_id, "video_token_id": self.video_token_id,
                     "vision_start_token_id": self.vision_start_token_id,
                     "vision_end_token_id": self.vision_end_token_id, "torch_dtype": "bfloat16"}
+        if self.family == "gpt2":
+            return {"architectures": ["GPT2LMHeadModel"], "model_type": "gpt2", "vocab_size": self.vocab_size,
+                    "n_embd": self.hidden_size, "n_layer": self.n_layers, "n_head": self.n_q_heads,
+                    "n_inner": self.intermediate_size, "n_positions": self.max_position_embeddings,
+                    "n_ctx": self.max_position_embeddings, "layer_norm_epsilon": self.rms_norm_eps,
+                    "activation_function": "gelu_new", "tie_word_embeddings": self.tie_word_embeddings,
+                    "torch_dtype": "bfloat16", "bos_token_id": self.bos_token_id, "eos_token_id": self.eos_token_id,
+                    "pad_token_id": self.pad_token_id}
         arch = {
             "qwen2": "Qwen2ForCausalLM", "qwen3": "Qwen3ForCausalLM", "llama": "LlamaForCausalLM",
             "mistral": "MistralForCausalLM", "gemma": "GemmaForCausalLM", "mixtral": "MixtralForCausalLM",
@@ -218,6 +249,11 @@ PRESETS: Dict[str, Dict[str, Any]] = {
     "tiny-qknorm": dict(family="qwen3", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=4, n_kv_heads=2,
                         head_dim=64, intermediate_size=512, tie_word_embeddings=False, qkv_bias=False, qk_norm=True,
                         rope_theta=1e4, max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
+    "tiny-gpt2": dict(family="gpt2", vocab_size=512, hidden_size=128, n_layers=2, n_q_heads=2, n_kv_heads=2,
+                      head_dim=64, intermediate_size=512, tie_word_embeddings=True, qkv_bias=True,
+                      hidden_act="gelu_tanh", norm_type="layer", pos_embed="learned", mlp_gated=False,
+                      linear_bias=True, rms_norm_eps=1e-5, max_position_embeddings=1024, eos_token_id=1,
+                      pad_token_id=0),
     "tiny-vl": dict(family="qwen2_vl", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
                     head_dim=128, intermediate_size=512, tie_word_embeddings=False, qkv_bias=True, rope_theta=1e4,
                     max_position_embeddings=4096, eos_token_id=1, pad_token_id=0, mrope_section=[16, 24, 24],

@@ -128,6 +128,8 @@ def load_hf_weights(model, path: str, strict: bool = True) -> None:
         assert tuple(p.shape) == tuple(t.shape), f"{name}: {tuple(p.shape)} vs checkpoint {tuple(t.shape)}"
         p.data.copy_(t.to(p.dtype))
 
+    if cfg.family == "gpt2":
+        return _load_gpt2(model, rd, put)
     if model.has_embed:
         put("embed", rd.get("model.embed_tokens.weight"))
         for n in params:  # vision tower: parameter names are the checkpoint names
@@ -190,6 +192,73 @@ def load_hf_weights(model, path: str, strict: bool = True) -> None:
             put(pre + "mlp.down", rd.get_cols(names["mlp.down"][0], f_lo, f_hi))
 
 
+# ------------------------------------------------------------------------------------- GPT-2
+# GPT-2 checkpoints store every linear as Conv1D, i.e. weight [in, out] (the transpose of nn.Linear), q|k|v
+# fused in `c_attn` along the output axis, and (for the original hub files) names without the
+# `transformer.` prefix. Reference converter: ``realhf/api/from_hf/gpt2.py``.
+def _load_gpt2(model, rd: "_ShardReader", put) -> None:
+    cfg: ModelConfig = model.cfg
+    tp, tr = model.tp_size, model.tp_rank
+    D, H = cfg.head_dim, cfg.hidden_size
+    pre_hf = "transformer." if rd.has("transformer.wte.weight") or rd.has("transformer.h.0.ln_1.weight") else ""
+    if model.has_embed:
+        put("embed", rd.get(pre_hf + "wte.weight"))
+        put("pos_embed", rd.get(pre_hf + "wpe.weight"))
+    if model.has_head:
+        put("norm", rd.get(pre_hf + "ln_f.weight"))
+        put("norm_bias", rd.get(pre_hf + "ln_f.bias"))
+        if "head" in dict(model.named_parameters()):
+            if cfg.is_critic:
+                put("head", rd.get("score.weight"))
+            else:
+                put("head", rd.get("lm_head.weight" if rd.has("lm_head.weight") else pre_hf + "wte.weight"))
+    q_lo, q_hi = (x * D for x in _tp_range(cfg.n_q_heads, tp, tr))
+    f_lo, f_hi = _tp_range(cfg.intermediate_size, tp, tr)
+    lo_layer, hi_layer = model.layer_range
+    for li, i in enumerate(range(lo_layer, hi_layer)):
+        b, pre = f"{pre_hf}h.{i}.", f"layers.{li}."
+        for ours, theirs in (("ln1", "ln_1.weight"), ("ln1_bias", "ln_1.bias"), ("ln2", "ln_2.weight"),
+                             ("ln2_bias", "ln_2.bias"), ("attn.o_bias", "attn.c_proj.bias"),
+                             ("mlp.proj_bias", "mlp.c_proj.bias")):
+            put(pre + ours, rd.get(b + theirs))
+        w, bias = rd.get(b + "attn.c_attn.weight"), rd.get(b + "attn.c_attn.bias")
+        put(pre + "attn.qkv", torch.cat([w[:, o + q_lo:o + q_hi] for o in (0, H, 2 * H)], 1).t().contiguous())
+        put(pre + "attn.qkv_bias", torch.cat([bias[o + q_lo:o + q_hi] for o in (0, H, 2 * H)], 0))
+        put(pre + "attn.o", rd.get_rows(b + "attn.c_proj.weight", q_lo, q_hi).t().contiguous())
+        put(pre + "mlp.fc", rd.get_cols(b + "mlp.c_fc.weight", f_lo, f_hi).t().contiguous())
+        put(pre + "mlp.fc_bias", rd.get(b + "mlp.c_fc.bias")[f_lo:f_hi])
+        put(pre + "mlp.proj", rd.get_rows(b + "mlp.c_proj.weight", f_lo, f_hi).t().contiguous())
+
+
+def _gpt2_state(model, g) -> Iterable[Tuple[str, torch.Tensor]]:
+    cfg: ModelConfig = model.cfg
+    params = dict(model.named_parameters())
+    if model.has_embed:
+        yield "transformer.wte.weight", params["embed"].data
+        yield "transformer.wpe.weight", params["pos_embed"].data
+    lo_layer, _ = model.layer_range
+    for li, blk in enumerate(model.layers):
+        b, pre = f"transformer.h.{lo_layer + li}.", f"layers.{li}."
+        for ours, theirs in (("ln1", "ln_1.weight"), ("ln1_bias", "ln_1.bias"), ("ln2", "ln_2.weight"),
+                             ("ln2_bias", "ln_2.bias"), ("attn.o_bias", "attn.c_proj.bias"),
+                             ("mlp.proj_bias", "mlp.c_proj.bias")):
+            yield b + theirs, params[pre + ours].data
+        n = blk.attn.hq * cfg.head_dim
+        qkv, qb = params[pre + "attn.qkv"].data, params[pre + "attn.qkv_bias"].data
+        yield b + "attn.c_attn.weight", torch.cat([_gather_tp(qkv[o:o + n], 0, g) for o in (0, n, 2 * n)], 0).t().contiguous()
+        yield b + "attn.c_attn.bias", torch.cat([_gather_tp(qb[o:o + n], 0, g) for o in (0, n, 2 * n)], 0)
+        yield b + "attn.c_proj.weight", _gather_tp(params[pre + "attn.o"].data, 1, g).t().contiguous()
+        yield b + "mlp.c_fc.weight", _gather_tp(params[pre + "mlp.fc"].data, 0, g).t().contiguous()
+        yield b + "mlp.c_fc.bias", _gather_tp(params[pre + "mlp.fc_bias"].data, 0, g)
+        yield b + "mlp.c_proj.weight", _gather_tp(params[pre + "mlp.proj"].data, 1, g).t().contiguous()
+    if model.has_head:
+        yield "transformer.ln_f.weight", params["norm"].data
+        yield "transformer.ln_f.bias", params["norm_bias"].data
+        tied_copy = cfg.tie_word_embeddings and not cfg.is_critic and not model.has_embed
+        if "head" in params and not tied_copy:
+            yield ("score.weight" if cfg.is_critic else "lm_head.weight"), params["head"].data
+
+
 # -------------------------------------------------------------------------------------- save
 def _gather_tp(t: torch.Tensor, dim: int, group) -> torch.Tensor:
     if group is None or dist.get_world_size(group) == 1:
@@ -209,6 +278,9 @@ def native_to_hf_state(model, gather: bool = True, experts_only: bool = False) -
         return
     cfg: ModelConfig = model.cfg
     g = model.tp_group if gather else None
+    if cfg.family == "gpt2":
+        yield from _gpt2_state(model, g)
+        return
     tp = model.tp_size
     D = cfg.head_dim
     params = dict(model.named_parameters())

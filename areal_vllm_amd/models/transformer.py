@@ -1,5 +1,5 @@
-"""Native decoder-only transformer (Qwen2/2.5/3, Llama, Mistral, Gemma, Mixtral/Qwen-MoE) built on the
-HIP ops of this package.
+"""Native decoder-only transformer (Qwen2/2.5/3, Llama, Mistral, Gemma, Mixtral/Qwen-MoE, GPT-2) built on
+the HIP ops of this package.
 
 Design points (MI355X-first rather than a port of ``realhf/impl/model/nn/real_llm_api.py:100-834``):
 
@@ -126,6 +126,8 @@ class Attention(nn.Module):
             nn.Parameter(torch.zeros((self.hq + 2 * self.hkv) * D, dtype=dtype, device=device)) if cfg.qkv_bias else None
         )
         self.o = nn.Parameter(torch.empty(cfg.hidden_size, self.hq * D, dtype=dtype, device=device))
+        if cfg.linear_bias:  # added once, after the row-parallel reduction
+            self.o_bias = nn.Parameter(torch.zeros(cfg.hidden_size, dtype=dtype, device=device))
         if cfg.qk_norm:
             self.q_norm = nn.Parameter(torch.ones(D, dtype=dtype, device=device))
             self.k_norm = nn.Parameter(torch.ones(D, dtype=dtype, device=device))
@@ -151,7 +153,9 @@ class Attention(nn.Module):
         else:  # replicated input: the input-gradient all-reduce overlaps the weight-gradient GEMM
             qkv = self.project_qkv(x, reduce_dx_group=tp_group)
         T = qkv.shape[0]
-        qkv = ops.apply_rope(qkv, positions, rope, self.hq + self.hkv, D).view(T, self.hq + 2 * self.hkv, D)
+        if rope is not None:
+            qkv = ops.apply_rope(qkv, positions, rope, self.hq + self.hkv, D)
+        qkv = qkv.view(T, self.hq + 2 * self.hkv, D)
         if sp is not None:
             attn = sp.attention(qkv, self.hq, self.hkv, cu_seqlens, max_seqlen)
         else:
@@ -159,7 +163,8 @@ class Attention(nn.Module):
         out = ops.linear(attn.reshape(T, -1), self.o)
         if seq_par:
             return ReduceScatterToSP.apply(out, tp_group)
-        return _AllReduceFwd.apply(out, tp_group)
+        out = _AllReduceFwd.apply(out, tp_group)
+        return out + self.o_bias if self.cfg.linear_bias else out
 
 
 class MLP(nn.Module):
@@ -179,6 +184,27 @@ class MLP(nn.Module):
             return ReduceScatterToSP.apply(ops.linear(h, self.down), tp_group)
         h = ops.swiglu(ops.linear(x, self.gate_up, reduce_dx_group=tp_group), self.act)
         return _AllReduceFwd.apply(ops.linear(h, self.down), tp_group)
+
+
+class DenseMLP(nn.Module):
+    """fc -> activation -> proj without a gate, biases on both (GPT-2): column-parallel fc, row-parallel
+    proj whose bias is added once after the reduction."""
+
+    def __init__(self, hidden, inter, tp_size, dtype, device, act: str = "gelu_tanh"):
+        super().__init__()
+        assert inter % tp_size == 0 and act in ("gelu_tanh", "silu")
+        self.act = act
+        f = inter // tp_size
+        self.fc = nn.Parameter(torch.empty(f, hidden, dtype=dtype, device=device))
+        self.fc_bias = nn.Parameter(torch.zeros(f, dtype=dtype, device=device))
+        self.proj = nn.Parameter(torch.empty(hidden, f, dtype=dtype, device=device))
+        self.proj_bias = nn.Parameter(torch.zeros(hidden, dtype=dtype, device=device))
+
+    def forward(self, x, tp_group, seq_par=False):
+        assert not seq_par, "sequence parallelism is implemented for the gated MLP"
+        h = ops.linear(x, self.fc, self.fc_bias, reduce_dx_group=tp_group)
+        h = F.gelu(h, approximate="tanh") if self.act == "gelu_tanh" else F.silu(h)
+        return _AllReduceFwd.apply(ops.linear(h, self.proj), tp_group) + self.proj_bias
 
 
 class MoE(nn.Module):
@@ -235,6 +261,16 @@ class MoE(nn.Module):
         return _AllReduceFwd.apply(out, tp_group)
 
 
+def add_norm(cfg: ModelConfig, h, weight, bias, residual):
+    """(norm(h + residual), h + residual): the fused residual-add RMSNorm kernel, or LayerNorm with bias
+    (fp32 statistics) for the families that use it."""
+    if cfg.norm_type == "layer":
+        residual = h if residual is None else h + residual
+        x = F.layer_norm(residual.float(), (residual.shape[-1],), weight.float(), bias.float(), cfg.rms_norm_eps)
+        return x.to(h.dtype), residual
+    return ops.rmsnorm(h, weight, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+
+
 class Block(nn.Module):
     def __init__(self, cfg: ModelConfig, tp_size, dtype, device, ep_size=1, ep_rank=0):
         super().__init__()
@@ -242,17 +278,22 @@ class Block(nn.Module):
         self.ln1 = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
         self.attn = Attention(cfg, tp_size, dtype, device)
         self.ln2 = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
+        if cfg.norm_type == "layer":
+            self.ln1_bias = nn.Parameter(torch.zeros(cfg.hidden_size, dtype=dtype, device=device))
+            self.ln2_bias = nn.Parameter(torch.zeros(cfg.hidden_size, dtype=dtype, device=device))
         if cfg.n_experts > 0:
             self.mlp = MoE(cfg, tp_size, dtype, device, ep_size, ep_rank)
-        else:
+        elif cfg.mlp_gated:
             self.mlp = MLP(cfg.hidden_size, cfg.intermediate_size, tp_size, dtype, device, cfg.hidden_act)
+        else:
+            self.mlp = DenseMLP(cfg.hidden_size, cfg.intermediate_size, tp_size, dtype, device, cfg.hidden_act)
 
     def forward(self, h, residual, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None, ep_group=None,
                 seq_par=False):
         cfg = self.cfg
-        x, residual = ops.rmsnorm(h, self.ln1, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+        x, residual = add_norm(cfg, h, self.ln1, getattr(self, "ln1_bias", None), residual)
         h = self.attn(x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp, seq_par)
-        x, residual = ops.rmsnorm(h, self.ln2, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+        x, residual = add_norm(cfg, h, self.ln2, getattr(self, "ln2_bias", None), residual)
         if cfg.n_experts > 0:
             h = self.mlp(x, tp_group, ep_group)
         else:
@@ -272,7 +313,8 @@ class Transformer(nn.Module):
         # norms and their activations hold only T/tp tokens per rank (all-gather before a column-parallel
         # GEMM, reduce-scatter after a row-parallel one: the same bytes over xGMI as the all-reduce pair)
         self.seq_par = bool(sequence_parallel) and tp_size > 1
-        assert not (self.seq_par and cfg.n_experts > 0), "sequence parallelism is implemented for dense MLPs"
+        assert not (self.seq_par and (cfg.n_experts > 0 or not cfg.mlp_gated or cfg.linear_bias)), \
+            "sequence parallelism is implemented for gated dense MLPs without output biases"
         self.cfg = cfg
         self.dtype = dtype
         self.tp_size, self.tp_rank, self.tp_group = tp_size, tp_rank, tp_group
@@ -283,11 +325,16 @@ class Transformer(nn.Module):
         self.sp = None  # Ulysses sequence-parallel context (parallel/ulysses.py)
         if has_embed:
             self.embed = nn.Parameter(torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device))
+            if cfg.pos_embed == "learned":
+                self.pos_embed = nn.Parameter(torch.empty(cfg.max_position_embeddings, cfg.hidden_size, dtype=dtype,
+                                                          device=device))
         self.layers = nn.ModuleList(
             [Block(cfg, tp_size, dtype, device, ep_size, ep_rank) for _ in range(*self.layer_range)]
         )
         if has_head:
             self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
+            if cfg.norm_type == "layer":
+                self.norm_bias = nn.Parameter(torch.zeros(cfg.hidden_size, dtype=dtype, device=device))
             if cfg.is_critic:
                 self.head = nn.Parameter(torch.empty(1, cfg.hidden_size, dtype=dtype, device=device))
             elif not (cfg.tie_word_embeddings and has_embed):
@@ -346,10 +393,12 @@ class Transformer(nn.Module):
         return self.embed
 
     # --------------------------------------------------------------------------- forward
-    def embed_tokens(self, input_ids):
+    def embed_tokens(self, input_ids, positions=None):
         h = F.embedding(input_ids, self.embed)
         if self.cfg.gemma_norm:
             h = h * math.sqrt(self.cfg.hidden_size)
+        if self.cfg.pos_embed == "learned":
+            h = h + F.embedding(positions.long(), self.pos_embed)
         return h
 
     def embed_multimodal(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor],
@@ -385,7 +434,7 @@ class Transformer(nn.Module):
                 residual_in: Optional[torch.Tensor] = None):
         """Returns the final-norm hidden states [T, H] on the last stage, else (h, residual)."""
         if self.has_embed and hidden_in is None:
-            h = self.embed_tokens(input_ids)
+            h = self.embed_tokens(input_ids, positions)
             if self.seq_par:
                 from ..parallel.tensor_parallel import ScatterToSP
 
@@ -393,7 +442,9 @@ class Transformer(nn.Module):
         else:
             h = hidden_in
         residual = residual_in
-        if positions.dim() == 2:  # M-RoPE: [3, T] (temporal, row, column) positions of a vision-language batch
+        if self.cfg.pos_embed != "rope":
+            rope = None
+        elif positions.dim() == 2:  # M-RoPE: [3, T] (temporal, row, column) positions of a vision-language batch
             rope = self.mrope(positions)
             positions = torch.arange(positions.shape[1], dtype=torch.int32, device=positions.device)
         else:
@@ -409,7 +460,7 @@ class Transformer(nn.Module):
                                   self.ep_group, self.seq_par)
         if not self.has_head:
             return h, residual
-        x, _ = ops.rmsnorm(h, self.norm, self.cfg.rms_norm_eps, residual, self.cfg.gemma_norm)
+        x, _ = add_norm(self.cfg, h, self.norm, getattr(self, "norm_bias", None), residual)
         if self.seq_par:  # the LM head / value head sees all tokens again
             from ..parallel.tensor_parallel import GatherForReplicatedUse
 

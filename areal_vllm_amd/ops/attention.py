@@ -48,6 +48,36 @@ def attention_varlen_ref(q, k, v, cu_q, cu_k, scale, causal=True):
     return out.to(q.dtype), lse
 
 
+def attention_varlen_sdpa(q, k, v, cu_q, cu_k, scale, causal=True):
+    """Head sizes other than 128 on the GPU (the MFMA kernels are specialised for D = 128, the head size
+    of the Qwen2 / Llama-3 8B+ families): PyTorch's fused attention, one call per packed sequence, the
+    causal mask aligned to the bottom-right corner. Differentiable through autograd; returns out only."""
+    import torch.nn.functional as F
+
+    Hq, Hkv = q.shape[1], k.shape[1]
+    cq, ck = cu_q.tolist(), cu_k.tolist()
+    outs = []
+    for b in range(len(cq) - 1):
+        Lq, Lk = cq[b + 1] - cq[b], ck[b + 1] - ck[b]
+        if Lq == 0:
+            continue
+        qs = q[cq[b]:cq[b + 1]].transpose(0, 1).unsqueeze(0)
+        ks = k[ck[b]:ck[b + 1]].transpose(0, 1).unsqueeze(0)
+        vs = v[ck[b]:ck[b + 1]].transpose(0, 1).unsqueeze(0)
+        mask = None
+        if causal and Lq != Lk:
+            i = torch.arange(Lq, device=q.device).unsqueeze(1)
+            j = torch.arange(Lk, device=q.device).unsqueeze(0)
+            mask = j <= i + (Lk - Lq)
+        o = F.scaled_dot_product_attention(qs, ks, vs, attn_mask=mask, is_causal=causal and mask is None, scale=scale,
+                                           enable_gqa=Hq != Hkv)
+        outs.append(o[0].transpose(0, 1))
+    return torch.cat(outs, 0)
+
+
+HIP_HEAD_DIM = 128  # the head size flash_attn.hip / paged_attn.hip are built for
+
+
 # ------------------------------------------------------------------------------- autograd op
 class _FlashVarlenFn(torch.autograd.Function):
     """Attention over the fused projection qkv [T, Hq + 2*Hkv, D] (q heads | k heads | v heads)."""
@@ -99,6 +129,9 @@ def flash_attn_varlen_qkv(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqle
     """Differentiable packed self-attention on a fused qkv tensor; returns [T, Hq, D]."""
     if scale is None:
         scale = 1.0 / math.sqrt(qkv.shape[-1])
+    if L.use_hip(qkv) and qkv.shape[-1] != HIP_HEAD_DIM:
+        q, k, v = qkv.split([n_q_heads, n_kv_heads, n_kv_heads], 1)
+        return attention_varlen_sdpa(q, k, v, cu_seqlens, cu_seqlens, float(scale), causal)
     return _FlashVarlenFn.apply(qkv, cu_seqlens, int(max_seqlen), n_q_heads, n_kv_heads, float(scale), causal)
 
 
@@ -187,6 +220,8 @@ def flash_attn_varlen_sep(q, k, v, cu_q, cu_k, max_q: int, max_k: int, scale: Op
     of queries against the keys of its sequences up to the chunk's end)."""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
+    if L.use_hip(q) and q.shape[-1] != HIP_HEAD_DIM:
+        return attention_varlen_sdpa(q, k, v, cu_q, cu_k, float(scale), causal)
     return _FlashVarlenSepFn.apply(q, k, v, cu_q, cu_k, int(max_q), int(max_k), float(scale), causal)
 
 
@@ -196,6 +231,8 @@ def flash_attn_varlen(q, k, v, cu_q, cu_k, max_q, scale=None, causal=True):
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
     if L.use_hip(q):
+        if q.shape[-1] != HIP_HEAD_DIM:  # no log-sum-exp on this path (the prefill does not need it)
+            return attention_varlen_sdpa(q, k, v, cu_q, cu_k, float(scale), causal), None
         return _flash_fwd_hip(q, k, v, cu_q, cu_k, max_q, scale, causal)
     return attention_varlen_ref(q, k, v, cu_q, cu_k, scale, causal)
 

@@ -6,6 +6,7 @@ trackers, ``export_all``). The export path differs: local partials of ALL keys a
 vectors and reduced with one SUM, one MIN and one MAX all-reduce, and the result is read back with a
 single device-to-host copy (the reference all-reduces and synchronises per key).
 """
+import os
 import time
 from collections import defaultdict
 from contextlib import contextmanager
@@ -19,6 +20,9 @@ import torch.distributed as dist
 from . import logging
 
 logger = logging.getLogger("StatsTracker")
+
+
+_ROCTX = os.environ.get("AREAL_ROCTX", "0") == "1"
 
 
 class ReduceType(Enum):
@@ -68,10 +72,19 @@ class DistributedStatsTracker:
 
     @contextmanager
     def record_timing(self, key):
+        """Wall time of a loop phase under ``timeperf/<key>``. With ``AREAL_ROCTX=1`` the phase is also a
+        roctx range (through the marker API PyTorch-ROCm exposes as ``torch.cuda.nvtx``), so a
+        ``rocprofv3 --marker-trace`` timeline shows the kernels grouped by rollout / recompute / train /
+        weight update (the reference times the same phases, ``areal/utils/stats_tracker.py:71-80``)."""
+        marked = _ROCTX and torch.cuda.is_available()
+        if marked:
+            torch.cuda.nvtx.range_push(str(key))
         t0 = time.perf_counter()
         try:
             yield
         finally:
+            if marked:
+                torch.cuda.nvtx.range_pop()
             with self.lock:
                 fk = f"timeperf/{key}"
                 self.reduce_types[fk] = ReduceType.SCALAR

@@ -182,6 +182,49 @@ def test_train_steps_reduce_loss_and_hf_round_trip(engine, tmp_path):
     assert torch.allclose(engine.model.flat.flat.float(), e2.model.flat.flat.float(), atol=1e-3)
 
 
+def test_gpt2_family_trains_on_gpu():
+    """GPT-2 (LayerNorm with bias, learned positions, head size 64, ungated MLP): bf16 log-probs on the GPU
+    agree with the same weights run in fp32 on the CPU, and optimizer steps reduce the loss."""
+    _env()
+    from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
+    from areal_vllm_amd.api.io_struct import FinetuneSpec
+    from areal_vllm_amd.engine.train_engine import NativeTrainEngine
+    from areal_vllm_amd.models.transformer import Transformer
+
+    cfg = TrainEngineConfig(experiment_name="t", trial_name="g", path="tiny-gpt2", init_from_scratch=True,
+                            dtype="bfloat16", gradient_checkpointing=False,
+                            optimizer=OptimizerConfig(lr=2e-3, weight_decay=0.0, gradient_clipping=1.0,
+                                                      warmup_steps_proportion=0.0, lr_scheduler_type="constant"),
+                            mb_spec=MicroBatchSpec(max_tokens_per_mb=1024))
+    eng = NativeTrainEngine(cfg)
+    eng.create_process_group()
+    eng.initialize(None, FinetuneSpec(1, 64, 8))
+    try:
+        mc = eng.model_config
+        lens = [100, 31, 257, 64]
+        batch = _batch(mc.vocab_size, lens, seed=3)
+        got = eng.forward(batch, post_hook=_logp_hook).float().cpu()
+        ref = Transformer(mc, dtype=torch.float32, device="cpu")
+        ref.flatten()
+        ref.flat.flat.copy_(eng.model.flat.flat.float().cpu())
+        ref.eval()
+        for b, n in enumerate(lens):
+            ids = batch["input_ids"][b, :n]
+            with torch.no_grad():
+                h = ref(ids, torch.arange(n, dtype=torch.int32), torch.tensor([0, n], dtype=torch.int32), n)
+                lp = torch.log_softmax(ref.logits(h), -1)
+            want = lp[torch.arange(n - 1), ids[1:]]
+            assert float((got[b, :n - 1] - want).abs().mean()) < 0.02
+        l0 = float(eng.eval_batch(batch, _sft_loss, _weight))
+        for _ in range(8):
+            st = eng.train_batch(batch, _sft_loss, _weight)
+            assert st["update_successful"] == 1.0 and math.isfinite(st["grad_norm"])
+        l1 = float(eng.eval_batch(batch, _sft_loss, _weight))
+        assert l1 < l0 - 0.2, (l0, l1)
+    finally:
+        eng.destroy()
+
+
 def _rollout_pair(model="small", decode_steps=4, pages=512):
     _env()
     from areal_vllm_amd.api.cli_args import (AdvNormConfig, InferenceEngineConfig, InferenceServerConfig,

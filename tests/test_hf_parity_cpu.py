@@ -23,6 +23,9 @@ FAMILIES = {
     "qwen3_moe": ("Qwen3MoeConfig", dict(head_dim=32, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=48,
                                          norm_topk_prob=True, decoder_sparse_step=1, mlp_only_layers=[],
                                          tie_word_embeddings=False)),
+    # LayerNorm with bias, learned positions, ungated GELU MLP, Conv1D (transposed) weights, fused c_attn
+    "gpt2": ("GPT2Config", dict(vocab_size=320, n_embd=64, n_layer=2, n_head=4, n_inner=96, n_positions=256,
+                                attn_pdrop=0.0, embd_pdrop=0.0, resid_pdrop=0.0)),
 }
 
 
@@ -30,7 +33,7 @@ def _hf_model(family):
     cls_name, extra = FAMILIES[family]
     if not hasattr(transformers, cls_name):
         pytest.skip(f"transformers has no {cls_name}")
-    cfg = getattr(transformers, cls_name)(**{**COMMON, **extra})
+    cfg = getattr(transformers, cls_name)(**(extra if family == "gpt2" else {**COMMON, **extra}))
     cfg._attn_implementation = "eager"
     torch.manual_seed(0)
     model = transformers.AutoModelForCausalLM.from_config(cfg).float().eval()

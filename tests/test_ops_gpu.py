@@ -128,6 +128,34 @@ def test_flash_attn_fwd_bwd(Hq, Hkv, lens):
     _close(qkv.grad[:, Hq + Hkv:].cpu(), qf.grad[:, Hq + Hkv:], 3e-2, 5e-2, "dv")
 
 
+@pytest.mark.parametrize("D,Hq,Hkv", [(64, 8, 2), (256, 4, 1), (80, 4, 4)])
+def test_attention_head_sizes_other_than_128(D, Hq, Hkv):
+    """Head sizes the MFMA kernel is not built for take PyTorch's fused attention per sequence; forward,
+    backward and the bottom-right aligned mask of the separate-stream entry against the fp32 reference."""
+    torch.manual_seed(5)
+    lens = [33, 1, 130, 64]
+    T = sum(lens)
+    cu = torch.tensor([0] + np.cumsum(lens).tolist(), dtype=torch.int32, device=DEV)
+    qkv = (0.5 * torch.randn(T, Hq + 2 * Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
+    out = ops.flash_attn_varlen_qkv(qkv, cu, max(lens), Hq, Hkv)
+    g = torch.randn_like(out)
+    out.backward(g)
+    qf = qkv.detach().float().cpu().requires_grad_(True)
+    ref, _ = A.attention_varlen_ref(qf[:, :Hq], qf[:, Hq:Hq + Hkv], qf[:, Hq + Hkv:], cu.cpu(), cu.cpu(),
+                                    1.0 / math.sqrt(D), True)
+    ref.backward(g.float().cpu())
+    _close(out.cpu(), ref, 2e-2, 2e-2, "attn out")
+    _close(qkv.grad.cpu(), qf.grad, 3e-2, 5e-2, "dqkv")
+    lq = [5, 1, 40, 64]
+    cq = torch.tensor([0] + np.cumsum(lq).tolist(), dtype=torch.int32, device=DEV)
+    q = (0.5 * torch.randn(sum(lq), Hq, D, device=DEV)).bfloat16()
+    k, v = qkv.detach()[:, Hq:Hq + Hkv], qkv.detach()[:, Hq + Hkv:]
+    got, _ = ops.flash_attn_varlen(q, k, v, cq, cu, max(lq))
+    want, _ = A.attention_varlen_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), cq.cpu(), cu.cpu(),
+                                     1.0 / math.sqrt(D), True)
+    _close(got.cpu(), want, 2e-2, 2e-2, "prefix-extend out")
+
+
 def test_flash_attn_prefix_extend():
     """q shorter than k (cached prefix): causal mask aligned bottom-right."""
     torch.manual_seed(4)

@@ -188,3 +188,18 @@ def test_qk_norm_weights_under_tensor_parallel():
     _run(1, {}, init, ref, preset_name="tiny-qknorm")
     _run(2, dict(tensor_parallel_size=2), init, out, preset_name="tiny-qknorm")
     _compare(ref, out, atol=5e-5)
+
+
+def test_gpt2_family_under_tensor_and_pipeline_parallel():
+    """GPT-2 (LayerNorm with bias, learned positions, ungated MLP, biases after the row-parallel
+    reductions): two optimizer steps under tp=2 and under pp=2 end at the single-process weights, through
+    the Conv1D-layout checkpoint written and re-read in every layout."""
+    d = tempfile.mkdtemp(prefix="areal_gpt2_")
+    init, ref = os.path.join(d, "init"), os.path.join(d, "ref")
+    _run(1, {}, None, init, preset_name="tiny-gpt2")
+    assert "transformer.h.0.attn.c_attn.weight" in _load_ckpt(init)
+    _run(1, {}, init, ref, preset_name="tiny-gpt2")
+    for name, kw in (("tp2", dict(tensor_parallel_size=2)), ("pp2", dict(pipeline_parallel_size=2))):
+        out = os.path.join(d, name)
+        _run(2, kw, init, out, preset_name="tiny-gpt2", n_mbs=2)
+        _compare(ref, out, atol=5e-5)
