@@ -33,6 +33,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 # published comparator: ~20k tokens/s end-to-end for the 1.5B model on one 8xH800 node
 # (reference blog/AReaL_v0_2.md:54, assets/thpt_comparison.png)
 BASELINE_TOK_S_8GPU = 20000.0
+# the same figure's 7B point: ~26k tokens/s on 32 H800, i.e. per GPU
+BASELINE_TOK_S_PER_GPU = {"qwen2-1.5b": BASELINE_TOK_S_8GPU / 8.0, "qwen2.5-7b": 26000.0 / 32.0}
+MODEL_LABEL = {"qwen2-1.5b": "Qwen2-1.5B", "qwen2.5-7b": "Qwen2.5-7B"}
 
 
 def parse_args():
@@ -64,6 +67,11 @@ def parse_args():
 
 def main():
     args = parse_args()
+    # the result line is the only thing that may reach stdout: libraries (gloo's connection banner) print
+    # there too, so everything before the result goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -242,13 +250,15 @@ def main():
         value = samples / elapsed
         mean_len = all_tok / max(1.0, samples)
         tok_s = all_tok / elapsed
-        baseline_tok_s = BASELINE_TOK_S_8GPU * world / 8.0
+        per_gpu = BASELINE_TOK_S_PER_GPU.get(args.model)
+        baseline_tok_s = per_gpu * world if per_gpu else None
+        label = MODEL_LABEL.get(args.model, args.model)
         out = {
-            "metric": "RL samples/sec (whole node), Qwen2-1.5B GRPO end-to-end (rollout + train + weight update)",
+            "metric": f"RL samples/sec (whole node), {label} GRPO end-to-end (rollout + train + weight update)",
             "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(tok_s / baseline_tok_s, 4), "dtype": "bf16",
+            "vs_baseline": round(tok_s / baseline_tok_s, 4) if baseline_tok_s else None, "dtype": "bf16",
             "data": "synthetic prompts, random-init weights",
             "gen_tokens_per_s": round(gen_tok / elapsed, 1), "e2e_tokens_per_s": round(tok_s, 1),
             "mean_seq_len": round(mean_len, 1), "mean_gen_len": round(gen_tok / max(1.0, samples), 1),
@@ -256,10 +266,10 @@ def main():
             "grad_norm_last": stats[-1].get("grad_norm"),
             "mean_token_staleness_rank0": round(tot.get("stale_sum", 0.0) / args.steps, 3),
             "pipeline_prime_steps": prime,
-            "baseline_note": "vs_baseline = end-to-end tokens/s over (20k tok/s x n_gpus/8), the reference's "
-                             "published 1.5B single-node figure on 8xH800 (blog/AReaL_v0_2.md:54); it publishes no "
-                             "samples/s number",
-            "config": {"model": "Qwen2-1.5B (random init)" if args.model == "qwen2-1.5b" else f"{args.model} (random init)", "global_batch": int(args.prompts_per_gpu * world),
+            "baseline_note": "vs_baseline = end-to-end tokens/s over the reference's published per-GPU figure x n_gpus "
+                             "(1.5B: 20k tok/s on one 8xH800 node, 7B: 26k tok/s on 32 H800; blog/AReaL_v0_2.md:54); "
+                             "it publishes no samples/s number",
+            "config": {"model": f"{label} (random init)", "global_batch": int(args.prompts_per_gpu * world),
                        "n_samples": args.n_samples, "seq_len": args.prompt_len_max + args.max_new_tokens,
                        "max_new_tokens": args.max_new_tokens, "parallelism": f"dp{world} colocated rollout+train",
                        "async_training": args.eta > 0, "max_head_offpolicyness": args.eta,
@@ -268,7 +278,10 @@ def main():
                                + (", proximal log-probs fused into the training forward" if args.fuse_prox else ""),
                        "max_tokens_per_mb": args.max_tokens_per_mb, "decode_steps_per_plan": args.decode_steps},
         }
+        sys.stdout.flush()
+        os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
         if args.profile_phases:
             print(json.dumps(phase), file=sys.stderr)
     rollout.destroy()
