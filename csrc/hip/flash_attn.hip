@@ -68,14 +68,19 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
   // 1-D grid, query-tile rank first: rank 0 is the LAST (heaviest under causal masking) tile of every
   // (sequence, head), so heavy workgroups of all sequences start first and light ones fill the tail.
   // XCD placement: consecutive workgroup ids go round-robin over the 8 XCDs, each with its own L2. Inside
-  // a rank the (sequence, kv head) group index g runs fastest over an extent padded to a multiple of 8, so
-  // id % 8 == g % 8: every query head and every query tile that reads the K/V of one group runs on the
-  // same XCD and finds those tiles in its L2 instead of fetching them from HBM once per XCD.
+  // a rank the slot of the (sequence, kv head) group runs fastest over an extent padded to a multiple of 8,
+  // and group g sits in slot (g + rank) mod extent, so id % 8 == (g + rank) % 8: all query heads that read
+  // the K/V of one group for one query tile run on the same XCD and share those tiles in its L2, while the
+  // rotation by rank spreads a group's query tiles - and with them the padding slots and any remainder
+  // of the group count modulo 8 - evenly over the XCDs (without it a single long sequence with two kv
+  // heads would keep six of the eight XCDs idle).
   const int G = Hq / Hkv;
   const int n_g = Hkv * nbatch, n_g_pad = (n_g + 7) & ~7;
   const int per_rank = G * n_g_pad;
   const int rank = blockIdx.x / per_rank, rem = blockIdx.x - rank * per_rank;
-  const int hj = rem / n_g_pad, g = rem - hj * n_g_pad;
+  const int hj = rem / n_g_pad, slot = rem - hj * n_g_pad;
+  int g = slot - rank % n_g_pad;
+  g += g < 0 ? n_g_pad : 0;
   if (g >= n_g) return;
   const int b = g / Hkv, head = (g - b * Hkv) * G + hj;
   const int q_beg = cu_q[b], q_len = cu_q[b + 1] - q_beg;
@@ -137,6 +142,11 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
     store_tile();
   }
   __syncthreads();
+  // Every load issued so far (the Q fragments above all) has landed before the loop starts. Without this
+  // the compiler carries "Q may still be in flight" around the loop and, because the counter is in-order,
+  // makes each S^T MFMA wait for the NEXT tile's prefetch loads issued just before it: the global-load
+  // latency it was meant to hide then sits in every iteration.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
   for (int t = 0; t < ntile_k; ++t) {
     if (t + 1 < ntile_k) load_tile(t + 1);
@@ -147,9 +157,15 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
 #pragma unroll
       for (int j = 0; j < 16; ++j) sacc[kb][j] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        bf16x8 kf = lds_row_read(ks, 32 * kb + r, 2 * s + hf);
-        sacc[kb] = mfma32(kf, qf[s], sacc[kb]);
+      // fragments are read four at a time ahead of the MFMAs that use them, so that an MFMA waits for a
+      // read issued four instructions earlier instead of for the one just before it
+      for (int s0 = 0; s0 < 8; s0 += 4) {
+        bf16x8 kf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = lds_row_read(ks, 32 * kb + r, 2 * (s0 + s) + hf);
+        __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from sinking the reads back to their uses
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sacc[kb] = mfma32(kf[s], qf[s0 + s], sacc[kb]);
       }
     }
     // ---- online softmax; lane holds q row `my_q`, keys (reg&3)+8(reg>>2)+4hf of each block
@@ -192,14 +208,17 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
     // ---- O^T[d, q] += V^T[d, keys] . P^T[keys, q]
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      // group `grp`: rows = keys 16s + 4hf (+8), cols = d 32db + 16(grp&1); all eight transposed reads of
+      // a key slab are issued before its four MFMAs
+      bf16x4 a0[4], a1[4];
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        // group `grp`: rows = keys 16s + 4hf (+8), cols = d 32db + 16(grp&1)
         const int col0 = 32 * db + 16 * (grp & 1);
-        bf16x4 a0 = tr_read(vs, 16 * s + 4 * hf, col0, gl);
-        bf16x4 a1 = tr_read(vs, 16 * s + 8 + 4 * hf, col0, gl);
-        oacc[db] = mfma32(cat4(a0, a1), pf[s], oacc[db]);
+        a0[db] = tr_read(vs, 16 * s + 4 * hf, col0, gl);
+        a1[db] = tr_read(vs, 16 * s + 8 + 4 * hf, col0, gl);
       }
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[db] = mfma32(cat4(a0[db], a1[db]), pf[s], oacc[db]);
     }
     __syncthreads();
     if (t + 1 < ntile_k) store_tile();
@@ -371,11 +390,16 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
       const bool ok = qi < q_len;
       qi = ok ? qi : q_len - 1;
       // rows past the end get lse = +inf so that p = exp2(-inf) = 0
-      lse_r = ok ? lse[(size_t)head * total_q + q_beg + qi] * 1.4426950408889634f : INFINITY;
+      // (scaled to base 2 when staged: arithmetic here would wait for the load just issued)
+      lse_r = ok ? lse[(size_t)head * total_q + q_beg + qi] : INFINITY;
       dl_r = ok ? delta[(size_t)head * total_q + q_beg + qi] : 0.f;
     }
   };
   if (nwork > 0) prefetch(0);
+  // All loads issued so far (the K / V fragments of this wave) have landed before the loop: otherwise the
+  // compiler keeps them "possibly in flight" around the loop and, the counter being in-order, makes the
+  // S / dP MFMAs that read them wait for the prefetch of the NEXT slice issued just before.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
   for (int it = 0; it < nwork; ++it) {
     const int head = kvh * G + it / nslice;
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_kernel(
         lds_row_write(dos, lrow + 16 * i, lch, doreg[i]);
       }
       if (tid < 32) {
-        lse_s[tid] = lse_r;
+        lse_s[tid] = lse_r * 1.4426950408889634f;
         dl_s[tid] = dl_r;
       }
       if (it + 1 < nwork) prefetch(it + 1);
