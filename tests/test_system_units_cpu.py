@@ -565,3 +565,68 @@ def test_experiment_checks_and_cluster_spec(tmp_path):
     f.write_text(json.dumps(dict(cluster_name="c", n_nodes=3, n_gpus_per_node=8, node_name_prefix="mi", junk=1)))
     spec = load_spec_from_file(str(f))
     assert spec.n_gpus == 24 and spec.node_names() == ["mi01", "mi02", "mi03"] and ClusterSpec().gpu_memory_gb == 288
+
+
+def test_codeforces_elo_estimate_on_a_synthetic_contest(tmp_path):
+    """A virtual participant that solves what the top 10% of a 400-player field solved gets ranked there and
+    is assigned the rating whose expected rank equals that rank; a model that solves nothing lands at the
+    bottom; contests with too few rated participants are skipped."""
+    import json
+
+    import numpy as np
+
+    from areal_vllm_amd.evaluation import cf_elo
+
+    rng = np.random.default_rng(0)
+    n = 400
+    ratings = np.sort(rng.normal(1500, 350, n))[::-1].astype(int)  # standings order = rating order
+    problems = [dict(contestId=1900, index=c, points=p) for c, p in zip("ABCD", (500, 1000, 1500, 2000))]
+    pts = [5000 if i < 40 else 3000 if i < 120 else 1500 if i < 300 else 500 for i in range(n)]
+    rows = [dict(party=dict(members=[dict(handle=f"u{i}")]), points=pts[i], penalty=0) for i in range(n)]
+    changes = [dict(handle=f"u{i}", oldRating=int(ratings[i])) for i in range(n)]
+    contest = dict(standings=dict(status="OK", result=dict(problems=problems, rows=rows)),
+                   rating_changes=dict(status="OK", result=changes))
+    small = dict(standings=dict(status="OK", result=dict(problems=problems, rows=rows[:50])),
+                 rating_changes=dict(status="OK", result=changes[:50]))
+    contests = {"1900": contest, "1901": small}
+    hist = {str(r): 1 for r in range(800, 2600, 10)}
+    ids = ["1900A", "1900B", "1900C", "1900D", "1901A"]
+
+    # all four solved, D on the second attempt: 500 + 1000 + 1500 + 1950 = 4950 points -> behind the 40 with 5000
+    assert cf_elo.virtual_score(problems, {"1900A": [True], "1900D": [False, True]}, None) == (2450.0, 0)
+    strong = cf_elo.estimate_elo(ids, [[True], [True], [True], [False, True], [True]], contests,
+                                 sorted(float(k) for k in hist), pass_n=None)
+    weak = cf_elo.estimate_elo(ids, [[False]] * 5, contests, sorted(float(k) for k in hist), pass_n=1)
+    assert strong["contests_processed"] == 1 and strong["skipped_contest_ids"] == [1901]
+    r = strong["estimated_rating"]
+    assert ratings[40] <= r <= ratings[0] + 100, (r, ratings[40])  # rank 40 of 400 (win probabilities are smooth)
+    seed = 1 + np.sum(1 / (1 + 10 ** ((r - ratings) / 400)))
+    assert abs(seed - 40) < 1.0
+    assert weak["estimated_rating"] < ratings[-40] and strong["estimated_percentile"] > weak["estimated_percentile"]
+    # ICPC-style contests (no points): solved count, 10 penalty minutes per failed attempt
+    assert cf_elo.virtual_score([dict(contestId=7, index="A"), dict(contestId=7, index="B")],
+                                {"7A": [False, False, True], "7B": [False]}) == (1.0, 20)
+
+    for name, obj in (("meta.json", ids), ("hist.json", hist), ("contests.json", contests)):
+        (tmp_path / name).write_text(json.dumps(obj))
+    again = cf_elo.estimate_elo_from_files(
+        [dict(idx=i, score=s) for i, s in enumerate([[1], [1], [1], [0, 1], [1]])], str(tmp_path / "meta.json"),
+        str(tmp_path / "hist.json"), str(tmp_path / "contests.json"), pass_n=None)
+    assert again["estimated_rating"] == strong["estimated_rating"]
+
+
+def test_python_executor_and_result_table():
+    from areal_vllm_amd.evaluation.eval_and_aggregate import PROMPT_TYPES, format_table
+    from areal_vllm_amd.evaluation.python_executor import PythonExecutor, extract_program
+
+    ex = PythonExecutor(timeout=5.0)
+    text = "first\n```python\nprint(1)\n```\nthen\n```python\nimport sys\nprint(int(sys.stdin.read()) * 6)\n```"
+    assert extract_program(text) == "import sys\nprint(int(sys.stdin.read()) * 6)\n"
+    assert ex.run(extract_program(text), stdin="7") == ("42", "Done")
+    out = ex.batch_run(["print(sum(range(10)))", "raise ValueError('boom')", "while True: pass"])
+    assert out[0] == ("45", "Done") and "ValueError: boom" in out[1][1] and out[2][1] == "Timeout Error"
+    assert PythonExecutor(get_answer_from="solution()").run("def solution():\n    return 3 * 4")[0] == "12"
+    table = format_table({"aime24": {"greedy_acc": 30.0, "pass@8": 61.25}, "codeforces": {"greedy_acc": 5.0, "cf_rating": 1234.4}})
+    assert "aime24" in table and "61.2" in table and "1234" in table and "-" in table
+    assert all("{prompt}" in t for t in PROMPT_TYPES.values())
+    assert PROMPT_TYPES["r1-distilled-qwen"].format(prompt="2+2?").count("\\boxed{}") == 1
