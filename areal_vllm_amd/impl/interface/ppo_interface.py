@@ -61,7 +61,8 @@ class PPOActorInterface(ModelInterface):
                  max_reward_clip: float = 5.0, reward_output_scaling: float = 1.0, reward_output_bias: float = 0.0,
                  mask_no_eos_with_zero: bool = False, temperature: float = 1.0, use_decoupled_loss: bool = False,
                  behav_imp_weight_cap: Optional[float] = None, recompute_logprob: bool = False,
-                 enable_save: bool = True, generation_size: Optional[int] = None, **_):
+                 enable_save: bool = True, generation_size: Optional[int] = None, dataset_path: str = "",
+                 id2info: Optional[Dict] = None, **_):
         self.gconfig = generation_config if isinstance(generation_config, GenerationHyperparameters) else \
             GenerationHyperparameters(**(generation_config or {}))
         level = "none" if not adv_norm else ("group" if group_adv_norm else "batch")
@@ -74,7 +75,13 @@ class PPOActorInterface(ModelInterface):
             recompute_logprob=recompute_logprob, max_new_tokens=self.gconfig.max_new_tokens,
             adv_norm=None if level == "none" else AdvNormConfig(mean_level=level, std_level=level, group_size=group_size))
         self.enable_save = enable_save
-        self.generation_size = generation_size
+        # best-of-k: sample `generation_size` answers per prompt and train on the `group_size` best ones
+        # (``realhf/impl/model/interface/ppo_interface.py:376-405``); needs the verifier's problem metadata
+        self.group_size = group_size
+        self.generation_size = generation_size if generation_size is not None else None
+        if generation_size is not None:
+            assert generation_size >= group_size, (generation_size, group_size)
+        self._id2info, self._dataset_path = id2info, dataset_path
         self._actor: Optional[PPOActor] = None
         self._gen_engine = None
 
@@ -112,7 +119,8 @@ class PPOActorInterface(ModelInterface):
             self._gen_engine.initialize(load_weights=False)
         self._gen_engine.load_weights_from_trainer(eng.model, version=model.version.global_step)
         prompts = [p.data["packed_prompts"].tolist() for p in data.unpack()]
-        n = g.n_samples
+        best_of = self.generation_size is not None and self.generation_size > self.group_size
+        n = self.generation_size if best_of else g.n_samples
         stops = list(g.stop_token_ids or [])
         mc = eng.model_config
         for t in (mc.eos_token_id, mc.pad_token_id):
@@ -124,6 +132,8 @@ class PPOActorInterface(ModelInterface):
         ids, pmask, lps, no_eos, sl = [], [], [], [], []
         for i, p in enumerate(prompts):
             group = res[i * n:(i + 1) * n]
+            if best_of:
+                group = self._best_of(model, str(data.ids[i]).split("@")[0], group)
             lens = []
             for r in group:
                 seq = p + r.output_tokens
@@ -143,6 +153,24 @@ class PPOActorInterface(ModelInterface):
                        seq_no_eos_mask=[[1] * len(g_) for g_ in sl], version_start=[[1] * len(g_) for g_ in sl],
                        version_end=[[1] * len(g_) for g_ in sl])
         return SequenceSample(keys=set(out), ids=list(data.ids), seqlens=seqlens, data=out)
+
+    def _best_of(self, model: Model, qid: str, group: List) -> List:
+        """The `group_size` answers with the highest (verifier score, generated length), best first."""
+        from ...impl.environment.math_code_single_step_env import code_verify_call, extract_code, load_metadata, \
+            math_verify_call
+
+        if self._id2info is None:
+            assert self._dataset_path, "best-of-k needs dataset_path (or id2info) to score the answers"
+            self._id2info = load_metadata(self._dataset_path)[0]
+        tok = model.tokenizer
+        texts = [tok.decode(r.output_tokens, skip_special_tokens=True) if tok is not None
+                 else " ".join(map(str, r.output_tokens)) for r in group]
+        if self._id2info.get(qid, {}).get("task", "math") == "code":
+            scores = code_verify_call(self._id2info, [extract_code(t) or "" for t in texts], [qid] * len(texts))
+        else:
+            scores = math_verify_call(self._id2info, texts, [qid] * len(texts))
+        order = sorted(range(len(group)), key=lambda j: (float(scores[j]), len(group[j].output_tokens)), reverse=True)
+        return [group[j] for j in order[: self.group_size]]
 
     # --------------------------------------------------------------------------- inference
     @torch.no_grad()

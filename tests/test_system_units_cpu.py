@@ -630,3 +630,25 @@ def test_python_executor_and_result_table():
     assert "aime24" in table and "61.2" in table and "1234" in table and "-" in table
     assert all("{prompt}" in t for t in PROMPT_TYPES.values())
     assert PROMPT_TYPES["r1-distilled-qwen"].format(prompt="2+2?").count("\\boxed{}") == 1
+
+
+def test_best_of_k_keeps_the_highest_scored_longest_answers():
+    from types import SimpleNamespace
+
+    from areal_vllm_amd.impl.interface.ppo_interface import PPOActorInterface
+
+    texts = {1: "so the answer is \\boxed{4}", 2: "I think \\boxed{5}", 3: "long wrong " * 3 + "\\boxed{7}",
+             4: "it is clearly, after some thought, \\boxed{4}"}
+
+    class Tok:
+        def decode(self, ids, **kw):
+            return texts[ids[0]]
+
+    iface = PPOActorInterface(group_size=2, generation_size=4, generation_config=dict(n_samples=2, max_new_tokens=8),
+                              id2info={"q0": dict(query_id="q0", task="math", solutions=["\\boxed{4}"])})
+    group = [SimpleNamespace(output_tokens=[k] * n) for k, n in ((1, 3), (2, 9), (3, 12), (4, 6))]
+    kept = iface._best_of(SimpleNamespace(tokenizer=Tok()), "q0", group)
+    # the two correct answers first (the longer of them leading), wrong ones dropped however long they are
+    assert [r.output_tokens[0] for r in kept] == [4, 1]
+    with pytest.raises(AssertionError):
+        PPOActorInterface(group_size=4, generation_size=2)
