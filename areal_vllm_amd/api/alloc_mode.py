@@ -148,8 +148,10 @@ class _Parser:
 
     def dims(self, allowed: str) -> Dict[str, int]:
         out: Dict[str, int] = {}
-        while self.i < len(self.s) and self.peek() in allowed:
-            d = self.peek()
+        # "m" (model parallel) is the worker runtime's older spelling of "t": "sglang.d4p1m1+d2p2m1"
+        # (``realhf/experiments/common/utils.py:281-314``)
+        while self.i < len(self.s) and (self.peek() in allowed or (self.peek() == "m" and "t" in allowed)):
+            d = "t" if self.peek() == "m" else self.peek()
             save = self.i
             self.i += 1
             m = re.match(r"[1-9][0-9]*", self.s[self.i:])

@@ -16,7 +16,7 @@ from ..system.gserver_manager import GserverManagerConfig
 from ..system.system_api import (DatasetAbstraction, Experiment, ExperimentConfig, ExperimentSaveEvalControl,
                                  ExperimentScheduling, RolloutWorkerConfig, Scheduling, TasksGroup,
                                  register_experiment)
-from .common import ModelTrainEvalConfig, parse_layout, symmetric_model_workers
+from .common import resolve_allocation_mode, ModelTrainEvalConfig, parse_layout, symmetric_model_workers
 from .ppo_math_exp import PPOHyperparameters, ppo_rpcs
 
 
@@ -28,6 +28,7 @@ class AsyncPPOMATHExperiment(Experiment):
     ref: Optional[ModelTrainEvalConfig] = None
     critic: Optional[ModelTrainEvalConfig] = None
     ppo: PPOHyperparameters = dataclasses.field(default_factory=PPOHyperparameters)
+    allocation_mode: Optional[str] = None  # e.g. "sglang.d4p1m1+d2p2m1"; overrides layout / server counts
     layout: str = "d1t1p1"  # trainer layout; generation servers are data-parallel replicas with tp `gen_tp_size`
     n_generation_servers: int = 1
     gen_tp_size: int = 1
@@ -64,6 +65,7 @@ class AsyncPPOMATHExperiment(Experiment):
         return models
 
     def scheduling_setup(self) -> ExperimentScheduling:
+        resolve_allocation_mode(self)
         n = parse_layout(self.layout).world_size
         return ExperimentScheduling(
             master_worker=TasksGroup(1, Scheduling(cpu=4, mem=16000)),
@@ -73,6 +75,7 @@ class AsyncPPOMATHExperiment(Experiment):
             rollout_worker=TasksGroup(self.n_rollout_workers, Scheduling(cpu=4, mem=8000)))
 
     def initial_setup(self) -> ExperimentConfig:
+        resolve_allocation_mode(self)
         self.ppo.gen.n_samples = self.group_size
         rpcs = ppo_rpcs(self.ppo, self.group_size, self.train_bs_n_seqs, self.mb_spec, with_gen=False,
                         with_reward_mfc=False)

@@ -34,6 +34,23 @@ def parse_layout(s: str) -> ParallelStrategy:
                             pipeline_parallel_size=dims["p"])
 
 
+def resolve_allocation_mode(exp) -> None:
+    """`allocation_mode` (the reference's spelling of the device split, e.g. ``sglang.d4p1m1+d2p2m1`` or
+    ``d4p2m1``) overrides `layout` and, for experiments with generation servers, their count and
+    tensor-parallel size."""
+    mode = getattr(exp, "allocation_mode", None)
+    if not mode:
+        return
+    from ..api.alloc_mode import AllocationMode
+
+    a = AllocationMode.from_str(mode)
+    t = a.train if a.train is not None else a.gen
+    exp.layout = f"d{t.dp_size}t{t.tp_size}p{t.pp_size}"
+    if a.gen is not None and a.gen_backend is not None and hasattr(exp, "n_generation_servers"):
+        exp.n_generation_servers = a.gen.dp_size
+        exp.gen_tp_size = a.gen.tp_size
+
+
 def model_abstraction(m: ModelTrainEvalConfig, experiment_name: str, trial_name: str) -> ModelAbstraction:
     if m.backend == "null":
         return ModelAbstraction("null")

@@ -10,7 +10,7 @@ from ..api.cli_args import GenerationHyperparameters, MicroBatchSpec
 from ..system.dfg import MFCDef, ModelInterfaceAbstraction, ModelInterfaceType
 from ..system.system_api import (DatasetAbstraction, Experiment, ExperimentConfig, ExperimentSaveEvalControl,
                                  ExperimentScheduling, Scheduling, TasksGroup, register_experiment)
-from .common import ModelTrainEvalConfig, parse_layout, symmetric_model_workers
+from .common import resolve_allocation_mode, ModelTrainEvalConfig, parse_layout, symmetric_model_workers
 
 
 @dataclasses.dataclass
@@ -101,6 +101,7 @@ class PPOMATHExperiment(Experiment):
     ref: Optional[ModelTrainEvalConfig] = None
     critic: Optional[ModelTrainEvalConfig] = None
     ppo: PPOHyperparameters = dataclasses.field(default_factory=PPOHyperparameters)
+    allocation_mode: Optional[str] = None  # e.g. "sglang.d4p1m1+d2p2m1"; overrides layout / server counts
     layout: str = "d1t1p1"
     dataset: DatasetAbstraction = dataclasses.field(default_factory=lambda: DatasetAbstraction("math_code_prompt"))
     reward_args: Dict[str, Any] = dataclasses.field(default_factory=dict)
@@ -121,11 +122,13 @@ class PPOMATHExperiment(Experiment):
         return models
 
     def scheduling_setup(self) -> ExperimentScheduling:
+        resolve_allocation_mode(self)
         n = parse_layout(self.layout).world_size
         return ExperimentScheduling(master_worker=TasksGroup(1, Scheduling(cpu=4, mem=16000)),
                                     model_worker=TasksGroup(n, Scheduling(cpu=8, gpu=1, mem=64000)))
 
     def initial_setup(self) -> ExperimentConfig:
+        resolve_allocation_mode(self)
         self.ppo.gen.n_samples = self.group_size
         rpcs = ppo_rpcs(self.ppo, self.group_size, self.train_bs_n_seqs, self.mb_spec, with_gen=True,
                         with_reward_mfc=True, reward_args=self.reward_args)
