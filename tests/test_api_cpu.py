@@ -199,3 +199,24 @@ def test_pause_blocks_new_episodes():
         assert ex.wait(1, timeout=20)["input_ids"].shape[0] == 1
     finally:
         ex.destroy()
+
+
+def test_worker_runtime_allocation_mode_spelling():
+    """`m` is the older spelling of the tensor-parallel degree; experiments derive their trainer layout and
+    generation-server counts from `allocation_mode`."""
+    from areal_vllm_amd.api.alloc_mode import AllocationMode, AllocationType
+    from areal_vllm_amd.experiments.async_ppo_math_exp import AsyncPPOMATHExperiment
+    from areal_vllm_amd.experiments.sft_exp import SFTExperiment
+
+    a = AllocationMode.from_str("sglang.d4p1m2+d2p2m1")
+    assert a.type_ == AllocationType.DECOUPLED_TRAIN and a.gen.tp_size == 2 and a.gen.dp_size == 4
+    assert a.train.pp_size == 2 and a.train.dp_size == 2 and a.train.tp_size == 1
+    with pytest.raises(ValueError):
+        AllocationMode.from_str("d2m2t2")  # the same dimension twice
+    e = AsyncPPOMATHExperiment(allocation_mode="sglang.d4p1m2+d2p2m1")
+    sched = e.scheduling_setup()
+    assert (e.layout, e.n_generation_servers, e.gen_tp_size) == ("d2t1p2", 4, 2)
+    assert sched.generation_server.count == 4 and sched.model_worker.count == 4
+    s = SFTExperiment(allocation_mode="d4p2m1")
+    s.scheduling_setup()
+    assert s.layout == "d4t1p2"
