@@ -181,15 +181,22 @@ def main():
     loader = PromptLoader()
     phase = {}
 
+    trace = []  # (--profile-phases) per phase: name, seconds, tokens the rollout engine decoded / prefilled meanwhile
+
     def timed(name):
         class _T:
             def __enter__(s):
                 dev_sync()
                 s.t = time.perf_counter()
+                s.d, s.p = engine.runner.n_decode_tokens, engine.runner.n_prefill_tokens
 
             def __exit__(s, *a):
                 dev_sync()
-                phase[name] = phase.get(name, 0.0) + time.perf_counter() - s.t
+                dt = time.perf_counter() - s.t
+                phase[name] = phase.get(name, 0.0) + dt
+                if args.profile_phases:
+                    trace.append((name, round(dt, 3), engine.runner.n_decode_tokens - s.d,
+                                  engine.runner.n_prefill_tokens - s.p))
         return _T()
 
     tot = dict(samples=0, gen_tokens=0, all_tokens=0)
@@ -284,6 +291,8 @@ def main():
         os.dup2(2, 1)
         if args.profile_phases:
             print(json.dumps(phase), file=sys.stderr)
+            for row in trace:
+                print("phase %-15s %7.3fs  decoded %7d  prefilled %7d" % row, file=sys.stderr)
     rollout.destroy()
     engine.destroy()
     if world > 1:

@@ -43,7 +43,12 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--target-wgs", type=int, default=0, help="override the split-KV workgroup target (experiment)")
     args = ap.parse_args()
+    if args.target_wgs:
+        from areal_vllm_amd.ops import attention as _att
+
+        _att.DECODE_TARGET_WORKGROUPS = args.target_wgs
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     cfg = preset(args.model)
