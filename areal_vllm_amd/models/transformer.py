@@ -394,11 +394,11 @@ class Transformer(nn.Module):
 
     # --------------------------------------------------------------------------- forward
     def embed_tokens(self, input_ids, positions=None):
-        h = F.embedding(input_ids, self.embed)
+        h = ops.embedding(input_ids, self.embed)
         if self.cfg.gemma_norm:
             h = h * math.sqrt(self.cfg.hidden_size)
         if self.cfg.pos_embed == "learned":
-            h = h + F.embedding(positions.long(), self.pos_embed)
+            h = h + ops.embedding(positions.long(), self.pos_embed)
         return h
 
     def embed_multimodal(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor],
