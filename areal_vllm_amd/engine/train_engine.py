@@ -160,6 +160,9 @@ class NativeTrainEngine(TrainEngine):
             return
         if parallel_strategy is None:
             parallel_strategy = ParallelStrategy(data_parallel_size=dist.get_world_size())
+        if (getattr(parallel_strategy, "virtual_pipeline_parallel_size", None) or 1) > 1:
+            raise NotImplementedError("interleaved (virtual-stage) pipeline schedules are not implemented; "
+                                      "use contiguous stages (virtual_pipeline_parallel_size=1)")
         self.parallel_strategy = parallel_strategy
         assert parallel_strategy.world_size == dist.get_world_size(), (
             f"parallel strategy {parallel_strategy} needs {parallel_strategy.world_size} ranks, "
