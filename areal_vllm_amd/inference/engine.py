@@ -16,6 +16,7 @@ Each generated token carries the weight version that sampled it.
 """
 import asyncio
 import dataclasses
+import math
 import os
 import queue
 import threading
@@ -441,19 +442,23 @@ class NativeInferenceEngine:
             if abort_running:
                 self.sched.abort_all()
                 self._deliver()
-            dst = self.model.flat.flat
-            assert dst.numel() == src.numel(), "trainer and rollout parameter layouts differ"
+            # Same parameters at the same offsets; only the zero padding at the end differs (the trainer
+            # pads its buffer to a multiple of the data-parallel size for the ZeRO shards).
+            assert trainer_model.flat.specs == self.model.flat.specs, "trainer and rollout parameter layouts differ"
+            name, off, shape = self.model.flat.specs[-1]
+            n = off + int(math.prod(shape))
+            dst, src_ = self.model.flat.flat[:n], src[:n]
             if cuda:
                 if self._copy_stream is None:
                     self._copy_stream = torch.cuda.Stream(device=self.device)
                 self._copy_stream.wait_stream(torch.cuda.current_stream())
                 self._copy_stream.wait_event(ready)
                 with torch.cuda.stream(self._copy_stream):
-                    dst.copy_(src, non_blocking=True)
+                    dst.copy_(src_, non_blocking=True)
                     done.record(self._copy_stream)
                 torch.cuda.current_stream().wait_stream(self._copy_stream)
             else:
-                dst.copy_(src)
+                dst.copy_(src_)
             self._after_weight_change(version)
         self._control(f)
         if cuda:  # the caller must not overwrite `src` before the copy has read it

@@ -222,3 +222,28 @@ def test_collective_weight_update_into_server_process(tmp_path):
             srv.wait(timeout=20)
         except subprocess.TimeoutExpired:
             srv.kill()
+
+
+def test_colocated_weight_copy_with_trainer_side_padding():
+    """The trainer pads its flat parameter buffer to a multiple of the data-parallel size (ZeRO shards); the
+    colocated copy into the rollout engine must move the parameters, not compare buffer lengths."""
+    from areal_vllm_amd.api.cli_args import InferenceServerConfig
+    from areal_vllm_amd.inference.engine import NativeInferenceEngine
+    from areal_vllm_amd.models.config import preset
+    from areal_vllm_amd.models.transformer import Transformer
+
+    cfg = InferenceServerConfig(model_path="tiny", dtype="float32", context_length=128, max_running_requests=4)
+    eng = NativeInferenceEngine(cfg, device=torch.device("cpu"), num_pages=32).initialize(load_weights=False)
+    try:
+        for world in (1, 3, 8):
+            trainer = Transformer(preset("tiny"), dtype=torch.float32, device="cpu")
+            trainer.flatten(pad_to=world)
+            trainer.init_weights(seed=10 + world)
+            eng.load_weights_from_trainer(trainer, version=world)
+            for (n, a), (_, b) in zip(eng.model.named_parameters(), trainer.named_parameters()):
+                assert torch.equal(a, b), n
+            assert eng.get_version() == world
+        if trainer.flat.numel == eng.model.flat.numel:  # make sure the case that used to fail is covered
+            pytest.skip("padding did not change the buffer length for this model")
+    finally:
+        eng.destroy()
