@@ -562,3 +562,33 @@ def test_micro_batch_count_is_synchronised_across_ranks():
     res = LocalMultiProcessTest(3, _mb_sync_body, timeout=120).launch()
     counts = {c for r in res for c, _ in r}
     assert len(counts) == 1 and counts.pop() >= 3 and all(ok for r in res for _, ok in r)
+
+
+def test_embedding_and_linear_accumulate_into_main_grad():
+    """Embedding rows and linear weights add their gradients straight into the fp32 `main_grad` buffer
+    (no dense `.grad`), over several micro-batches, and match plain autograd."""
+    import torch
+    import torch.nn.functional as F
+
+    from areal_vllm_amd import ops
+
+    torch.manual_seed(0)
+    V, H, N = 50, 16, 24
+    emb = torch.nn.Parameter(torch.randn(V, H))
+    w = torch.nn.Parameter(torch.randn(N, H))
+    for p in (emb, w):
+        p.main_grad = torch.zeros_like(p, dtype=torch.float32)
+    ref_e, ref_w = emb.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    for step in range(3):
+        ids = torch.randint(0, V, (7, 5))
+        ids[0, :3] = 4  # repeated rows accumulate
+        g = torch.randn(7, 5, N)
+        ops.linear(ops.embedding(ids, emb), w).backward(g)
+        F.linear(F.embedding(ids, ref_e), ref_w).backward(g)
+    assert emb.grad is None and w.grad is None
+    torch.testing.assert_close(emb.main_grad, ref_e.grad)
+    torch.testing.assert_close(w.main_grad, ref_w.grad, atol=1e-4, rtol=1e-4)
+    # without a main_grad buffer (plain modules, inference) both fall back to the stock ops
+    e2 = torch.nn.Parameter(torch.randn(V, H))
+    ops.embedding(torch.tensor([1, 2]), e2).sum().backward()
+    assert e2.grad is not None
