@@ -1,0 +1,45 @@
+"""The benchmark entry point's contract, rehearsed on CPU (gloo): launched the way the scaling runs launch it
+(one rank per device through torch.distributed.run), it prints exactly ONE line on stdout - the JSON result -
+with the whole-job aggregate, on 1 and on 4 ranks (the trainer pads its flat parameter buffer per data-parallel
+size, which the colocated weight copy must tolerate)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--device", "cpu", "--model", "tiny", "--steps", "2", "--warmup", "1", "--prompts-per-gpu", "3", "--n-samples", "2",
+        "--max-new-tokens", "8", "--prompt-len-min", "4", "--prompt-len-max", "8"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("n", [1, 4])
+def test_bench_prints_one_json_line(n):
+    env = dict(os.environ, AREAL_PLATFORM="cpu", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if n == 1:
+        cmd = [sys.executable, "bench.py", *ARGS]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), *ARGS]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == n and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 3 * n
+    # whole-job aggregate: samples per step = prompts x samples x ranks
+    assert out["value"] == pytest.approx(3 * 2 * n / (out["ms_per_step"] / 1000.0), rel=0.02)
