@@ -441,8 +441,10 @@ class SFTConfig(BaseExperimentConfig):
 @dataclass
 class GRPOConfig(BaseExperimentConfig):
     async_training: bool = True
-    rollout_weight_update: str = field(default="nccl", metadata={"choices": ["nccl", "xgmi", "disk"],
-                                                                 "help": "transport to remote rollout servers"})
+    rollout_weight_update: str = field(default="xgmi", metadata={
+        "choices": ["nccl", "xgmi", "disk"],
+        "help": "transport to remote rollout servers: xgmi = collective push with every trainer rank sending a share "
+                "of the parameter chunks, nccl = all chunks broadcast by trainer rank 0, disk = checkpoint files"})
     colocated_kv_cache_gb: Optional[float] = field(default=None, metadata={
         "help": "KV-cache budget of the in-process rollout engine (colocated mode); default: mem_fraction_static"})
     gconfig: GenerationHyperparameters = field(default_factory=GenerationHyperparameters)

@@ -94,6 +94,17 @@ class WeightUpdateMeta:
     nccl_master_port: int = 29500
     nccl_param_specs: List[List[ParamSpec]] = field(default_factory=list)
     nccl_group_name: str = "update_weight_group"
+    # Sharded push: trainer ranks 0 .. n-1 (all hold the full replica under ZeRO-1 data parallelism) each own a
+    # broadcast group with the rollout servers and send every n-th chunk, so an update leaves through n
+    # devices' links at once instead of funnelling through rank 0 (the reference's scheme, n = 1).
+    nccl_n_senders: int = 1
+    nccl_master_ports: List[int] = field(default_factory=list)
+
+    def sender_port(self, s: int) -> int:
+        return self.nccl_master_ports[s] if self.nccl_master_ports else self.nccl_master_port + s
+
+    def sender_group_name(self, s: int) -> str:
+        return self.nccl_group_name if s == 0 else f"{self.nccl_group_name}_{s}"
 
     @classmethod
     def from_disk(cls, experiment_name: str, trial_name: str, file_root: str, name: str = "default"):
@@ -104,17 +115,22 @@ class WeightUpdateMeta:
 
     @classmethod
     def from_fsdp_nccl(cls, allocation_mode: AllocationMode, fsdp_engine: "TrainEngine",
-                       nccl_group_name: str = "update_weight_group", weight_chunked_mem_mb: int = 1024):
+                       nccl_group_name: str = "update_weight_group", weight_chunked_mem_mb: int = 1024,
+                       n_senders: int = 1):
         from ..platforms import current_platform
         from ..utils.network import find_free_ports, gethostip
 
+        n_senders = max(1, min(n_senders, len(fsdp_engine.get_param_specs(weight_chunked_mem_mb))))
+        ports = find_free_ports(n_senders)
         return cls(
             type="nccl",  # on CPU the same broadcast protocol runs over gloo
             alloc_mode=allocation_mode,
             nccl_master_address=gethostip(),
-            nccl_master_port=find_free_ports(1)[0],
+            nccl_master_port=ports[0],
             nccl_param_specs=fsdp_engine.get_param_specs(weight_chunked_mem_mb),
             nccl_group_name=nccl_group_name,
+            nccl_n_senders=max(1, n_senders),
+            nccl_master_ports=list(ports),
         )
 
     from_nccl = from_fsdp_nccl

@@ -226,17 +226,23 @@ def _update_from_distributed(meta: WeightUpdateMeta, addresses, retries, timeout
                 return await asyncio.gather(*[
                     arequest_with_retry(addr=a, session=session, endpoint="/init_weights_update_group", method="POST",
                                         payload=dict(master_address=meta.nccl_master_address,
-                                                     master_port=str(meta.nccl_master_port), rank_offset=1 + i * tp,
+                                                     master_port=str(meta.sender_port(s)), rank_offset=1 + i * tp,
                                                      world_size=world, backend=backend,
-                                                     group_name=meta.nccl_group_name),
-                                        max_retries=retries, timeout=timeout) for i, a in enumerate(addresses)])
+                                                     group_name=meta.sender_group_name(s)),
+                                        max_retries=retries, timeout=timeout)
+                    for s in range(max(1, meta.nccl_n_senders)) for i, a in enumerate(addresses)])
 
         for r in asyncio.run(init_all()):
             assert r.get("success"), r
-    for chunk in meta.nccl_param_specs:
-        payload = dict(names=[s.name for s in chunk], dtypes=[s.dtype for s in chunk],
-                       shapes=[list(s.shape) for s in chunk], group_name=meta.nccl_group_name,
-                       abort_all_requests=True, version=next_version)
+    n = max(1, meta.nccl_n_senders)
+    for lo in range(0, len(meta.nccl_param_specs), n):
+        # one round: chunk lo + s arrives from sender s, all of them concurrently
+        groups = [dict(group_name=meta.sender_group_name(s), names=[p.name for p in chunk],
+                       dtypes=[p.dtype for p in chunk], shapes=[list(p.shape) for p in chunk])
+                  for s, chunk in enumerate(meta.nccl_param_specs[lo:lo + n])]
+        payload = dict(groups[0], abort_all_requests=True, version=next_version)
+        if n > 1:
+            payload["groups"] = groups
         for r in _post_all(addresses, "/update_weights_from_distributed", payload, retries, timeout):
             assert r.get("success"), r
     return True

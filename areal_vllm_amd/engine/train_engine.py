@@ -696,21 +696,27 @@ class NativeTrainEngine(TrainEngine):
     def _init_weight_update_group(self, meta: WeightUpdateMeta):
         from ..utils.distributed import init_custom_process_group
 
-        if self.rank == 0 and self._weight_update_group is None:
+        n = max(1, meta.nccl_n_senders)
+        assert n == 1 or (n <= self.world_size and self.grid.pp == 1), \
+            "every sender needs the full parameter set: n_senders <= trainer ranks, no pipeline stages"
+        if self.rank < n and self._weight_update_group is None:
             ws = meta.alloc_mode.gen.world_size + 1
             self._weight_update_group = init_custom_process_group(
                 backend="nccl" if self.device.type == "cuda" else "gloo",
-                init_method=f"tcp://{meta.nccl_master_address}:{meta.nccl_master_port}", world_size=ws, rank=0,
-                group_name=meta.nccl_group_name)
+                init_method=f"tcp://{meta.nccl_master_address}:{meta.sender_port(self.rank)}", world_size=ws, rank=0,
+                group_name=meta.sender_group_name(self.rank))
 
     def _upload_collective(self, meta: WeightUpdateMeta):
-        """Rank 0 of the trainer broadcasts every (HF-named, full) parameter into the rollout group, chunk
-        by chunk in the order of `meta.nccl_param_specs` (protocol of ``fsdp_engine.py:399-433``)."""
+        """Trainer ranks 0 .. n_senders-1 broadcast the (HF-named, full) parameters into their rollout groups,
+        chunk i by rank i % n_senders, in the order of `meta.nccl_param_specs` (n_senders = 1 is the protocol of
+        ``fsdp_engine.py:399-433``). The chunks of one round (one per sender) travel concurrently."""
         self._init_weight_update_group(meta)
+        n = max(1, meta.nccl_n_senders)
         full = dict(self._iter_full_hf_params())
-        for chunk in meta.nccl_param_specs:
-            if self.rank == 0:
-                for spec in chunk:
+        for lo in range(0, len(meta.nccl_param_specs), n):
+            mine = lo + self.rank
+            if self.rank < n and mine < len(meta.nccl_param_specs):
+                for spec in meta.nccl_param_specs[mine]:
                     t = full[spec.name].contiguous()
                     dist.broadcast(t, src=0, group=self._weight_update_group)
             if dist.is_initialized():

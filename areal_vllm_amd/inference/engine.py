@@ -95,6 +95,7 @@ class NativeInferenceEngine:
         self._stream = None
         self._mm_ids: Dict[str, int] = {}  # request id -> scheduler id of requests that carry images
         self.update_group = None
+        self.update_groups: Dict[str, Any] = {}
         # tensor-parallel serving: rank 0 of the TP group owns the scheduler and tells the other ranks
         # what to run (see inference/tp_worker.py)
         self.is_leader = tp_rank == 0
@@ -259,7 +260,7 @@ class NativeInferenceEngine:
             elif cmd == "init_update_group":
                 self._join_update_group(payload)
             elif cmd == "recv_weights":
-                self._recv_weights(*payload)
+                self._recv_weights(payload)
             elif cmd == "shutdown":
                 return
             elif cmd != "noop":
@@ -491,37 +492,51 @@ class NativeInferenceEngine:
         from ..utils.distributed import init_custom_process_group
 
         rank = int(body["rank_offset"]) + self.tp_rank
-        self.update_group = init_custom_process_group(
+        group = init_custom_process_group(
             backend=body.get("backend", "nccl"), world_size=int(body["world_size"]), rank=rank,
             init_method=f"tcp://{body['master_address']}:{body['master_port']}", group_name=body["group_name"])
+        self.update_groups[body["group_name"]] = group
+        self.update_group = group
 
     def init_weight_update_group(self, body: Dict[str, Any]):
-        """Join the trainer's weight-update group: trainer rank 0 is rank 0, TP rank r of this server is
-        rank ``rank_offset + r`` (``areal/engine/sglang_remote.py:452-480`` in the reference)."""
+        """Join a weight-update group of the trainer: the sending trainer rank is rank 0, TP rank r of this
+        server is rank ``rank_offset + r`` (``areal/engine/sglang_remote.py:452-480`` in the reference). With
+        several senders the trainer opens one group per sender, each under its own name."""
         def f():
             self._tp_bcast("init_update_group", body)
             self._join_update_group(body)
         self._control(f)
 
-    def _recv_weights(self, names, dtypes, shapes):
+    def _recv_weights(self, groups: List[Dict[str, Any]]):
+        """`groups`: [{group_name, names, dtypes, shapes}]: the chunks of one round, one per sender; their
+        broadcasts are all started before the first one is waited for."""
         import torch.distributed as dist
 
-        tensors = {}
-        for n, dt, sh in zip(names, dtypes, shapes):
-            t = torch.empty(sh, dtype=getattr(torch, str(dt).replace("torch.", "")), device=self.device)
-            dist.broadcast(t, src=0, group=self.update_group)
-            tensors[n] = t
+        tensors, works = {}, []
+        for g in groups:
+            group = self.update_groups.get(g.get("group_name")) or self.update_group
+            for n, dt, sh in zip(g["names"], g["dtypes"], g["shapes"]):
+                t = torch.empty(sh, dtype=getattr(torch, str(dt).replace("torch.", "")), device=self.device)
+                works.append(dist.broadcast(t, src=0, group=group, async_op=True))
+                tensors[n] = t
+        for w in works:
+            w.wait()
         assign_hf_named_tensors(self.model, tensors)
 
-    def update_weights_from_distributed(self, names, dtypes, shapes, version: Optional[int] = None,
-                                        abort_running: bool = True):
-        """Receive HF-named full tensors broadcast by trainer rank 0; every TP rank keeps its slices."""
+    def update_weights_from_distributed(self, names=None, dtypes=None, shapes=None, version: Optional[int] = None,
+                                        abort_running: bool = True, group_name: Optional[str] = None,
+                                        groups: Optional[List[Dict[str, Any]]] = None):
+        """Receive HF-named full tensors broadcast by the trainer's sender rank(s); every TP rank keeps its
+        slices."""
+        if groups is None:
+            groups = [dict(group_name=group_name, names=names, dtypes=dtypes, shapes=shapes)]
+
         def f():
             if abort_running:
                 self.sched.abort_all()
                 self._deliver()
-            self._tp_bcast("recv_weights", (names, dtypes, shapes))
-            self._recv_weights(names, dtypes, shapes)
+            self._tp_bcast("recv_weights", groups)
+            self._recv_weights(groups)
             self._after_weight_change(version)
         self._control(f)
 

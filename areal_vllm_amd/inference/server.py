@@ -8,6 +8,8 @@ Speaks the REST verbs the reference's clients use against SGLang (``areal/engine
   POST /pause_generation, /continue_generation, /flush_cache, /abort_request {rid}
   POST /update_weights_from_disk {model_path, abort_all_requests}
   POST /init_weights_update_group {master_address, master_port, rank_offset, world_size, backend, group_name}
+       (once per sending trainer rank; /update_weights_from_distributed then names the group, or lists one
+       chunk per group under "groups" when several senders push concurrently)
   POST /update_weights_from_distributed {names, dtypes, shapes, group_name, abort_all_requests}
   POST /set_version {version}
 
@@ -184,7 +186,7 @@ class InferenceServer:
         abort = bool(body.get("abort_all_requests", True))
         try:
             await self._offload(self.engine.update_weights_from_distributed, body["names"], body["dtypes"],
-                                body["shapes"], body.get("version"), abort)
+                                body["shapes"], body.get("version"), abort, body.get("group_name"), body.get("groups"))
         except Exception as e:
             return web.json_response({"success": False, "message": repr(e)})
         return web.json_response({"success": True, "message": "Succeeded to update parameter online."})

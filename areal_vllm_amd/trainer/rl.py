@@ -54,7 +54,12 @@ def build_rollout_engines(config: GRPOConfig, actor: NativePPOActor, parallel_st
         if config.rollout_weight_update == "disk":
             meta = WeightUpdateMeta.from_disk(config.experiment_name, config.trial_name, config.cluster.fileroot)
         else:
-            box = [WeightUpdateMeta.from_fsdp_nccl(am, actor)]
+            # "xgmi": every data-parallel trainer rank pushes its share of the chunks through its own links;
+            # "nccl": the reference's protocol, everything leaves through rank 0
+            senders = 1
+            if config.rollout_weight_update == "xgmi" and parallel_strategy.pp_size == 1:
+                senders = min(8, dist.get_world_size())
+            box = [WeightUpdateMeta.from_fsdp_nccl(am, actor, n_senders=senders)]
             dist.broadcast_object_list(box, src=0)
             meta = box[0]
         return rollout, eval_rollout, meta, None

@@ -247,3 +247,103 @@ def test_colocated_weight_copy_with_trainer_side_padding():
             pytest.skip("padding did not change the buffer length for this model")
     finally:
         eng.destroy()
+
+
+def _sharded_push_worker(rank, world, port, srv_port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), AREAL_PLATFORM="cpu", GLOO_SOCKET_IFNAME="lo")
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    import torch.distributed as dist
+
+    from areal_vllm_amd.api.alloc_mode import AllocationMode, ParallelStrategy
+    from areal_vllm_amd.api.cli_args import InferenceEngineConfig, MicroBatchSpec, OptimizerConfig, TrainEngineConfig
+    from areal_vllm_amd.api.io_struct import FinetuneSpec, WeightUpdateMeta
+    from areal_vllm_amd.engine.remote_engine import RemoteInferenceEngine
+    from areal_vllm_amd.engine.train_engine import NativeTrainEngine
+
+    cfg = TrainEngineConfig(experiment_name="push", trial_name="t", path="tiny", init_from_scratch=True, dtype="float32",
+                            gradient_checkpointing=False, optimizer=OptimizerConfig(lr=1e-3),
+                            mb_spec=MicroBatchSpec(max_tokens_per_mb=2048))
+    eng = NativeTrainEngine(cfg)
+    eng.create_process_group(ParallelStrategy(data_parallel_size=world))
+    eng.initialize(None, FinetuneSpec(1, 16, 4))
+    client = None
+    try:
+        box = [None]
+        if rank == 0:
+            client = RemoteInferenceEngine(InferenceEngineConfig(experiment_name="push", trial_name="t", setup_timeout=60,
+                                                                 max_concurrent_rollouts=8, consumer_batch_size=4))
+            client.initialize(addr=f"127.0.0.1:{srv_port}", train_data_parallel_size=world)
+            meta = WeightUpdateMeta.from_fsdp_nccl(AllocationMode.from_str("native:d1+native:d2"), eng,
+                                                   weight_chunked_mem_mb=1, n_senders=2)
+            meta.nccl_master_address = "127.0.0.1"
+            assert len(meta.nccl_param_specs) >= 3 and len(set(meta.nccl_master_ports)) == 2
+            box = [meta]
+        dist.broadcast_object_list(box, src=0)
+        meta = box[0]
+        for version, scale in ((1, 1.3), (2, 0.7)):  # the second round reuses both groups
+            eng.model.flat.flat.mul_(scale)  # identical replicas on both ranks
+            fut = None
+            if rank == 0:
+                client.pause()
+                fut = client.update_weights(meta)
+            eng.upload_weights(meta)
+            if rank == 0:
+                assert fut.result(timeout=120)
+                client.set_version(version)
+                client.resume()
+                r = requests.post(f"http://127.0.0.1:{srv_port}/generate", json=dict(
+                    input_ids=[5, 6, 7, 8, 9], sampling_params=dict(max_new_tokens=6, temperature=0.0)), timeout=60).json()
+                toks = [5, 6, 7, 8, 9] + r["output_ids"]
+                ids = torch.tensor(toks)
+                m = eng.model
+                with torch.no_grad():
+                    h = m(ids, torch.arange(len(toks), dtype=torch.int32), torch.tensor([0, len(toks)], dtype=torch.int32),
+                          len(toks))
+                    lp = torch.log_softmax(m.logits(h).float(), -1)
+                want = lp[torch.arange(4, len(toks) - 1), ids[5:]]
+                got = torch.tensor([x[0] for x in r["meta_info"]["output_token_logprobs"]])
+                assert float((got - want).abs().max()) < 1e-3, (got, want)
+                assert (lp[torch.arange(4, len(toks) - 1)].argmax(-1) == ids[5:]).all()  # greedy under the NEW weights
+        if rank == 0:
+            open(os.path.join(out_dir, "ok"), "w").write("ok")
+    finally:
+        if client is not None:
+            client.destroy()
+        eng.destroy()
+
+
+def test_sharded_weight_push_from_two_trainer_ranks(tmp_path):
+    """Two data-parallel trainer ranks each broadcast every other parameter chunk into their own group with
+    the rollout server; the server starts the receives of a round together. Afterwards it decodes greedily
+    with exactly the trainer's new weights (two rounds: the groups are reused)."""
+    import subprocess
+
+    import torch.multiprocessing as mp
+
+    srv_port = _free_port()
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", AREAL_PLATFORM="cpu", GLOO_SOCKET_IFNAME="lo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    srv = subprocess.Popen([sys.executable, "-m", "areal_vllm_amd.inference.server", "--model-path", "tiny", "--dtype",
+                            "float32", "--device", "cpu", "--num-pages", "64", "--context-length", "128",
+                            "--max-running-requests", "8", "--port", str(srv_port)], env=env, cwd=ROOT)
+    try:
+        deadline = time.time() + 120
+        while True:
+            try:
+                if requests.get(f"http://127.0.0.1:{srv_port}/health", timeout=2).status_code == 200:
+                    break
+            except requests.RequestException:
+                pass
+            assert srv.poll() is None and time.time() < deadline
+            time.sleep(0.5)
+        mp.spawn(_sharded_push_worker, args=(2, _free_port(), srv_port, str(tmp_path)), nprocs=2, join=True)
+        assert (tmp_path / "ok").exists()
+    finally:
+        srv.terminate()
+        try:
+            srv.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            srv.kill()
