@@ -25,7 +25,15 @@ def init_custom_process_group(backend: Union[str, Backend, None] = None, init_me
     backend = Backend(backend) if backend else Backend("undefined")
     timeout = timeout or DEFAULT_TIMEOUT
     if store is None:
-        store, rank, world_size = next(iter(rendezvous(init_method, rank, world_size, timeout=timeout)))
+        if init_method.startswith("tcp://"):
+            # Own TCP store, hosted by rank 0 of THIS group. `rendezvous()` would, inside a process started by
+            # torchrun with a static rendezvous (TORCHELASTIC_USE_AGENT_STORE), make every rank - rank 0
+            # included - a client of a store that nobody hosts at this address.
+            host, port = init_method[len("tcp://"):].rsplit(":", 1)
+            assert world_size > 0 and rank >= 0
+            store = dist.TCPStore(host, int(port.split("?")[0]), world_size, rank == 0, timeout, multi_tenant=True)
+        else:
+            store, rank, world_size = next(iter(rendezvous(init_method, rank, world_size, timeout=timeout)))
         store.set_timeout(timeout)
         store = PrefixStore(group_name, store)
     kw = {}
