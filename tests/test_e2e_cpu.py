@@ -14,8 +14,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_launcher(entry, cfg, overrides, timeout=900):
-    env = dict(os.environ, PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+def _run_launcher(entry, cfg, overrides, timeout=900, **extra_env):
+    env = dict(os.environ, PYTHONPATH=ROOT, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="", **extra_env)
     cmd = [sys.executable, "-m", "areal_vllm_amd.launcher.local", os.path.join(ROOT, entry), "--config",
            os.path.join(ROOT, cfg), *overrides]
     return subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
@@ -45,6 +45,26 @@ def test_grpo_learns_through_local_launcher():
     assert len(rewards) >= 16
     assert rewards[0] < 0.3, rewards
     assert rewards[-1] > 0.6, rewards
+
+
+@pytest.mark.parametrize("transport", ["xgmi", "disk"])
+def test_decoupled_allocation_through_local_launcher(transport):
+    """The reference's default deployment: the launcher starts a rollout server process and a two-rank
+    trainer (torchrun); rollouts travel over HTTP, weights over the collective push (every trainer rank a
+    sender, its own group with the server) or over checkpoint files; asynchronous with staleness 2."""
+    root = tempfile.mkdtemp(prefix="areal_e2e_dec_")
+    r = _run_launcher("examples/synthetic/toy_grpo.py", "examples/synthetic/toy_grpo.yaml",
+                      [f"cluster.fileroot={root}", f"cluster.name_resolve.nfs_record_root={root}/nr", "trial_name=dec",
+                       "allocation_mode=native:d1+native:d2", "async_training=true", "total_train_epochs=1",
+                       f"rollout_weight_update={transport}"], timeout=600, GLOO_SOCKET_IFNAME="lo")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    import getpass
+
+    log = os.path.join(root, "logs", getpass.getuser(), "toy-grpo", "dec", "trainer.log")
+    rewards = _rewards(log)
+    assert len(rewards) >= 8, rewards
+    text = open(log).read()
+    assert "Training completes" in text
 
 
 def test_grpo_recover_run_continues(tmp_path):
