@@ -697,8 +697,9 @@ class NativeTrainEngine(TrainEngine):
         from ..utils.distributed import init_custom_process_group
 
         n = max(1, meta.nccl_n_senders)
-        assert n == 1 or (n <= self.world_size and self.grid.pp == 1), \
-            "every sender needs the full parameter set: n_senders <= trainer ranks, no pipeline stages"
+        assert self.grid.pp == 1, ("a pipeline stage holds only its own layers, the collective weight push would be "
+                                   "partial: use the disk transport with pipeline-parallel trainers")
+        assert n <= self.world_size, "more senders than trainer ranks"
         if self.rank < n and self._weight_update_group is None:
             ws = meta.alloc_mode.gen.world_size + 1
             self._weight_update_group = init_custom_process_group(

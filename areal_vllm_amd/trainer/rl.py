@@ -51,13 +51,20 @@ def build_rollout_engines(config: GRPOConfig, actor: NativePPOActor, parallel_st
         eval_rollout = RemoteInferenceEngine(eval_cfg)
         eval_rollout.initialize()
         am = AllocationMode.from_str(config.allocation_mode)
-        if config.rollout_weight_update == "disk":
+        transport = config.rollout_weight_update
+        if transport != "disk" and parallel_strategy.pp_size > 1:
+            # a pipeline stage only holds its own layers: the collective push (whose senders need every
+            # parameter) would update the servers partially; checkpoint files carry all stages
+            logger.warning("trainer has pipeline stages: weights go to the rollout servers through checkpoint "
+                           "files (rollout_weight_update=disk)")
+            transport = "disk"
+        if transport == "disk":
             meta = WeightUpdateMeta.from_disk(config.experiment_name, config.trial_name, config.cluster.fileroot)
         else:
             # "xgmi": every data-parallel trainer rank pushes its share of the chunks through its own links;
             # "nccl": the reference's protocol, everything leaves through rank 0
             senders = 1
-            if config.rollout_weight_update == "xgmi" and parallel_strategy.pp_size == 1:
+            if transport == "xgmi":
                 senders = min(8, dist.get_world_size())
             box = [WeightUpdateMeta.from_fsdp_nccl(am, actor, n_senders=senders)]
             dist.broadcast_object_list(box, src=0)

@@ -63,6 +63,7 @@ def test_decoupled_allocation_through_local_launcher(transport):
     log = os.path.join(root, "logs", getpass.getuser(), "toy-grpo", "dec", "trainer.log")
     rewards = _rewards(log)
     assert len(rewards) >= 8, rewards
+    assert rewards[-1] > 0.6 > rewards[0], rewards  # the servers really generate with the updated weights
     text = open(log).read()
     assert "Training completes" in text
 
