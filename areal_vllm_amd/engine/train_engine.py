@@ -674,10 +674,22 @@ class NativeTrainEngine(TrainEngine):
 
     def upload_weights(self, meta: WeightUpdateMeta):
         if meta.type == "inproc":
-            assert self._local_rollout_engine is not None, "no in-process rollout engine connected"
+            # Colocated: the data-parallel head of every replica hosts a rollout engine with the FULL model.
             eng = self._local_rollout_engine
-            eng.load_weights_from_trainer(self.model, version=None,
-                                          abort_running=getattr(eng, "abort_on_weight_update", True))
+            if self.grid.pp > 1:
+                raise NotImplementedError("a colocated rollout engine needs a trainer without pipeline stages "
+                                          "(use a decoupled allocation such as native:d4+native:d2p2)")
+            if self.grid.tp == 1:
+                if eng is not None:  # same flat layout: one device copy
+                    eng.load_weights_from_trainer(self.model, version=None,
+                                                  abort_running=getattr(eng, "abort_on_weight_update", True))
+            else:  # tensor-parallel trainer: gather the shards (every tp rank takes part), load by name on the head
+                full = dict(self._iter_full_hf_params())
+                if self.device.type == "cuda":
+                    torch.cuda.current_stream().synchronize()  # the engine reads the gathered tensors on its stream
+                if eng is not None:
+                    eng.load_named_tensors(full, version=None,
+                                           abort_running=getattr(eng, "abort_on_weight_update", True))
         elif meta.type == "disk":
             self._upload_disk(meta)
         elif meta.type in ("nccl", "xgmi"):

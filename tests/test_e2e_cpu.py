@@ -68,6 +68,21 @@ def test_decoupled_allocation_through_local_launcher(transport):
     assert "Training completes" in text
 
 
+@pytest.mark.parametrize("layout", ["d2p1t1", "d1p1t2"])
+def test_colocated_allocation_with_parallel_trainers(layout):
+    """Colocated rollout engines under a data-parallel (one engine per rank, flat-buffer copy) and a
+    tensor-parallel trainer (engine on the replica's head, shards gathered and loaded by name)."""
+    root = tempfile.mkdtemp(prefix="areal_e2e_col_")
+    r = _run_launcher("examples/synthetic/toy_grpo.py", "examples/synthetic/toy_grpo.yaml",
+                      [f"cluster.fileroot={root}", f"cluster.name_resolve.nfs_record_root={root}/nr", "trial_name=col",
+                       f"allocation_mode={layout}", "async_training=true", "total_train_epochs=1"], timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    import getpass
+
+    rewards = _rewards(os.path.join(root, "logs", getpass.getuser(), "toy-grpo", "col", "trainer.log"))
+    assert len(rewards) >= 8 and rewards[-1] > 0.6 > rewards[0], rewards
+
+
 def test_grpo_recover_run_continues(tmp_path):
     """Kill-free recover check: run 1 step budget with recover checkpoints, then relaunch with
     AREAL_RECOVER_RUN semantics (`recover.mode=resume`) and see the step counter continue."""
