@@ -12,6 +12,7 @@
 All block tables have the engine-wide maximum width, so graphs only depend on the batch bucket.
 """
 import math
+import os
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -31,7 +32,8 @@ DEFAULT_BUCKETS = [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 320, 
 
 class ModelRunner:
     def __init__(self, model: Transformer, num_pages: int, max_context: int, max_batch: int, decode_steps: int = 1,
-                 use_graph: bool = True, seed: int = 1, buckets: Optional[List[int]] = None):
+                 use_graph: bool = True, seed: int = 1, buckets: Optional[List[int]] = None,
+                 fused_decode: Optional[bool] = None):
         self.model = model
         self.cfg: ModelConfig = model.cfg
         self.device = next(model.parameters()).device
@@ -66,6 +68,13 @@ class ModelRunner:
         # vision-language requests: scheduler request id -> positions / image features (see register_multimodal)
         self.is_vl = cfg.vision is not None
         self.mm: Dict[int, Dict[str, Any]] = {}
+        # Decode batches of FUSED_MIN_BATCH rows and more run the layer as seven launches (ops/decode_gemm.py);
+        # smaller ones, and model variants its epilogues do not cover, take the library GEMMs.
+        fusable = (cfg.n_experts == 0 and not cfg.qk_norm and cfg.hidden_act == "silu" and model.tp_size == 1
+                   and cfg.hidden_size % 64 == 0 and cfg.intermediate_size % 64 == 0 and cfg.head_dim % 16 == 0)
+        if fused_decode is None:
+            fused_decode = self.device.type == "cuda" and os.environ.get("AREAL_FUSED_DECODE", "1") != "0"
+        self.fused_decode = bool(fused_decode) and fusable
 
     # ------------------------------------------------------------------- vision-language requests
     def _placeholder_mask(self, prompt_ids: List[int], grid_thw: torch.Tensor):
@@ -251,11 +260,50 @@ class ModelRunner:
             st["h_bt"] = torch.zeros(Bp, self.max_pages, dtype=torch.int32).pin_memory()
         return st
 
+    FUSED_MIN_BATCH = 48
+    # above this many rows the widest GEMM (gate|up) is faster in the library; the other three stay fused
+    FUSED_GATE_UP_MAX_BATCH = 384
+
+    def _decode_layers_fused(self, st: Dict[str, torch.Tensor], h: torch.Tensor, rope_pos: torch.Tensor):
+        """All decoder layers of one decode step on the fused path -> final-normed hidden states [Bp, H].
+
+        Per layer: qkv GEMM (split-K slabs) -> slab sum + bias + RoPE + KV-cache write -> paged attention ->
+        o GEMM (slabs) -> slab sum + residual + RMSNorm -> gate|up GEMM with SwiGLU epilogue -> down GEMM
+        (slabs) -> slab sum + residual + the NEXT layer's RMSNorm."""
+        from ..ops import decode_gemm as dg
+
+        cfg = self.cfg
+        hq, hkv, D = self.hq, self.hkv, cfg.head_dim
+        Bp, H = h.shape
+        eps, gemma = cfg.rms_norm_eps, cfg.gemma_norm
+        layers = self.model.layers
+        x, residual = ops.rmsnorm(h, layers[0].ln1, eps, None, gemma)
+        for li, blk in enumerate(layers):
+            kc, vc = self.kv[li]
+            slab = dg.dgemm(x, blk.attn.qkv, epilogue=dg.EPI_SLAB)
+            q = dg.splitk_rope_cache_write(slab, slab.shape[0], blk.attn.qkv_bias, rope_pos, st["slots"], self.rope,
+                                           kc, vc, hq, hkv, D, dtype=self.dtype)
+            attn = ops.paged_attention_decode(q, kc, vc, st["block_tables"], st["context_lens"], nsplit=st["nsplit"],
+                                              workspace=st["ws"])
+            slab = dg.dgemm(attn.view(Bp, hq * D), blk.attn.o, epilogue=dg.EPI_SLAB)
+            x, residual = dg.splitk_residual_rmsnorm(slab, slab.shape[0], Bp, H, residual=residual, weight=blk.ln2,
+                                                     eps=eps, gemma=gemma, dtype=self.dtype)
+            if Bp <= self.FUSED_GATE_UP_MAX_BATCH:
+                act = dg.dgemm(x, blk.mlp.gate_up, epilogue=dg.EPI_SWIGLU)
+            else:
+                act = ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)
+            slab = dg.dgemm(act, blk.mlp.down, epilogue=dg.EPI_SLAB)
+            nw = layers[li + 1].ln1 if li + 1 < len(layers) else self.model.norm
+            x, residual = dg.splitk_residual_rmsnorm(slab, slab.shape[0], Bp, H, residual=residual, weight=nw,
+                                                     eps=eps, gemma=gemma, dtype=self.dtype)
+        return x
+
     def _decode_body(self, st: Dict[str, torch.Tensor], filtered: bool):
         """`decode_steps` decode iterations on the static buffers (captured into a graph)."""
         hq, hkv, D = self.hq, self.hkv, self.cfg.head_dim
         Bp = st["input_ids"].numel()
         qkv_stride = (hq + 2 * hkv) * D
+        fused = self.fused_decode and Bp >= self.FUSED_MIN_BATCH
         for s in range(self.decode_steps):
             h = self.model.embed_tokens(st["input_ids"])
             residual = None
@@ -263,18 +311,21 @@ class ModelRunner:
             if self.is_vl:  # generated tokens of a request with images sit `delta` away from their index
                 torch.add(st["positions"], st["rope_delta"], out=st["rope_pos"])
                 rope_pos = st["rope_pos"]
-            for li, blk in enumerate(self.model.layers):
-                kc, vc = self.kv[li]
+            if fused:
+                logits = F.linear(self._decode_layers_fused(st, h, rope_pos), self.model.head_weight)
+            else:
+                for li, blk in enumerate(self.model.layers):
+                    kc, vc = self.kv[li]
 
-                def attn_fn(blk_, qkv2d, kc=kc, vc=vc, rope_pos=rope_pos):
-                    qkv = qkv2d.view(Bp, hq + 2 * hkv, D)
-                    ops.rope_and_cache_write_(qkv, rope_pos, st["slots"], self.rope, kc, vc, hq, hkv)
-                    return ops.paged_attention_decode(qkv[:, :hq], kc, vc, st["block_tables"], st["context_lens"],
-                                                      nsplit=st["nsplit"], workspace=st["ws"],
-                                                      q_row_stride=qkv_stride)
+                    def attn_fn(blk_, qkv2d, kc=kc, vc=vc, rope_pos=rope_pos):
+                        qkv = qkv2d.view(Bp, hq + 2 * hkv, D)
+                        ops.rope_and_cache_write_(qkv, rope_pos, st["slots"], self.rope, kc, vc, hq, hkv)
+                        return ops.paged_attention_decode(qkv[:, :hq], kc, vc, st["block_tables"], st["context_lens"],
+                                                          nsplit=st["nsplit"], workspace=st["ws"],
+                                                          q_row_stride=qkv_stride)
 
-                h, residual = self._layer(blk, h, residual, st["positions"], st["slots"], attn_fn)
-            logits = self._final_logits(h, residual)
+                    h, residual = self._layer(blk, h, residual, st["positions"], st["slots"], attn_fn)
+                logits = self._final_logits(h, residual)
             ops.sample(logits, st["temperature"], st["top_k"] if filtered else None, st["top_p"] if filtered else None,
                        self.seed, self.step_counter, bump_step=True, out_tokens=st["out_tokens"][s],
                        out_logprobs=st["out_logprobs"][s])

@@ -25,4 +25,5 @@ from .rl import gae_1d_packed, gae_2d, gae_padded, merge_intervals, set_interval
 from .sampling import advance_step_, sample  # noqa: F401
 from .skinny import SkinnyWorkspace, embed_rowsumsq, skinny_linear  # noqa: F401
 from .linear import embedding, linear  # noqa: F401
+from .decode_gemm import dgemm, splitk_residual_rmsnorm, splitk_rope_cache_write  # noqa: F401
 from .grouped_gemm import grouped_gemm, grouped_gemm_ref  # noqa: F401

@@ -57,7 +57,7 @@ def build_hip(verbose=True) -> Path:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(_run, jobs))
     lib = OUT_DIR / "libareal_hip.so"
-    if jobs or not lib.exists():
+    if jobs or not lib.exists() or any(o.stat().st_mtime > lib.stat().st_mtime for o in objs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)])
         if verbose:
             print(f"[build_ext] linked {lib}")
