@@ -442,9 +442,11 @@ class SFTConfig(BaseExperimentConfig):
 class GRPOConfig(BaseExperimentConfig):
     async_training: bool = True
     rollout_weight_update: str = field(default="xgmi", metadata={
-        "choices": ["nccl", "xgmi", "disk"],
+        "choices": ["nccl", "xgmi", "ipc", "disk"],
         "help": "transport to remote rollout servers: xgmi = collective push with every trainer rank sending a share "
-                "of the parameter chunks, nccl = all chunks broadcast by trainer rank 0, disk = checkpoint files"})
+                "of the parameter chunks, nccl = all chunks broadcast by trainer rank 0, ipc = servers on the same "
+                "node map the trainer's flat parameter buffer and pull it with one device-to-device copy, "
+                "disk = checkpoint files"})
     colocated_kv_cache_gb: Optional[float] = field(default=None, metadata={
         "help": "KV-cache budget of the in-process rollout engine (colocated mode); default: mem_fraction_static"})
     gconfig: GenerationHyperparameters = field(default_factory=GenerationHyperparameters)

@@ -87,7 +87,7 @@ class ParamSpec:
 
 @dataclass
 class WeightUpdateMeta:
-    type: Literal["disk", "nccl", "xgmi", "inproc"]
+    type: Literal["disk", "nccl", "xgmi", "inproc", "ipc"]
     path: Optional[str] = None
     alloc_mode: Optional[AllocationMode] = None
     nccl_master_address: str = "127.0.0.1"
@@ -99,6 +99,12 @@ class WeightUpdateMeta:
     # devices' links at once instead of funnelling through rank 0 (the reference's scheme, n = 1).
     nccl_n_senders: int = 1
     nccl_master_ports: List[int] = field(default_factory=list)
+
+    # Peer-memory push ("ipc"): one exported flat parameter buffer per data-parallel trainer rank (all of them
+    # hold the full replica); rollout server i pulls from buffer i % n with a device-to-device copy.
+    ipc_buffers: List[Dict[str, Any]] = field(default_factory=list)
+    ipc_layout: str = ""  # fingerprint of the flat parameter layout the buffers use
+    ipc_used_bytes: int = 0  # bytes of parameters at the head of every buffer (the tail is shard padding)
 
     def sender_port(self, s: int) -> int:
         return self.nccl_master_ports[s] if self.nccl_master_ports else self.nccl_master_port + s
@@ -134,6 +140,11 @@ class WeightUpdateMeta:
         )
 
     from_nccl = from_fsdp_nccl
+
+    @classmethod
+    def from_ipc(cls, engine: "TrainEngine"):
+        """Collective over the trainer's world: every rank exports the memory behind its flat parameter buffer."""
+        return cls(type="ipc", **engine.export_weight_buffers())
 
     @classmethod
     def from_inproc(cls):

@@ -28,6 +28,12 @@ from ...utils.functional import (
 from ..train_engine import LogitsProxy, NativeTrainEngine
 
 
+def _pp_share(engine, stats):
+    """Loss statistics are recorded on the last pipeline stage; give every stage the union."""
+    f = getattr(engine, "share_pipeline_stats", None)
+    return f(stats) if f is not None else stats
+
+
 class AdvNorm:
     """Advantage normalisation with independent levels for the mean and the std:
     "batch" (all-reduced over the data-parallel group), "group" (consecutive `group_size` rows), "none"."""
@@ -261,7 +267,7 @@ class PPOActor:
             train_stat = self.engine.train_batch(mb, loss_fn=loss_fn,
                                                  loss_weight_fn=lambda x: x["loss_mask"].count_nonzero())
             stats_tracker.scalar(**train_stat)
-            all_stats.append(stats_tracker.export(reduce_group=dp_group))
+            all_stats.append(_pp_share(self.engine, stats_tracker.export(reduce_group=dp_group)))
         all_stats[0].update(global_stats)
         return all_stats
 

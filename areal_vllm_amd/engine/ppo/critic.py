@@ -22,6 +22,12 @@ from ...utils.functional import ppo_critic_loss_fn
 from ..train_engine import NativeTrainEngine
 
 
+def _pp_share(engine, stats):
+    """Loss statistics are recorded on the last pipeline stage; give every stage the union."""
+    f = getattr(engine, "share_pipeline_stats", None)
+    return f(stats) if f is not None else stats
+
+
 class PPOCritic:
     def __init__(self, config: PPOCriticConfig, engine: TrainEngine):
         self.config = config
@@ -51,7 +57,7 @@ class PPOCritic:
         for mb in mbs.mbs:
             stat = self.engine.train_batch(mb, loss_fn=loss_fn, loss_weight_fn=lambda x: x["loss_mask"].count_nonzero())
             stats_tracker.scalar(**stat)
-            all_stats.append(stats_tracker.export(reduce_group=dp_group))
+            all_stats.append(_pp_share(self.engine, stats_tracker.export(reduce_group=dp_group)))
         all_stats[0].update(global_stats)
         return all_stats
 

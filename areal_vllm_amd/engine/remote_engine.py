@@ -140,9 +140,15 @@ class RemoteInferenceEngine(InferenceEngine):
 
     # ----------------------------------------------------------------------- weight update
     def update_weights(self, meta: WeightUpdateMeta) -> Future:
+        next_version = self._version + 1
+        if meta.type == "ipc":
+            # the servers keep decoding while they pull the new weights into a staging buffer and only stop
+            # for the flip between two engine steps: no pause / continue round trip
+            return self.executor.submit(_update_from_ipc, meta, self.config.experiment_name, self.config.trial_name,
+                                        self._version, self.addresses, self.config.request_retries,
+                                        self.config.request_timeout, next_version)
         for a in self.addresses:
             requests.post(f"http://{a}/pause_generation", timeout=self.config.request_timeout).raise_for_status()
-        next_version = self._version + 1
         if meta.type == "disk":
             fut = self.executor.submit(_update_from_disk, self.config.experiment_name, self.config.trial_name,
                                        self._version, self.addresses, meta.path, self.config.request_retries,
@@ -207,6 +213,32 @@ def _update_from_disk(experiment_name, trial_name, model_version, addresses, pat
     for r in res:
         assert r.get("success"), r
     logger.info(f"Loading weights done in {(time.time_ns() - load_ts) / 1e6:.2f} ms")
+    return True
+
+
+def _update_from_ipc(meta: WeightUpdateMeta, experiment_name, trial_name, model_version, addresses, retries,
+                     timeout, next_version):
+    """Wait until the trainer says its buffers are final, then let every server pull from the buffer of
+    trainer rank i % n (they all hold the full replica; spreading the sources spreads the links)."""
+    key = names.update_weights_from_ipc(experiment_name, trial_name, model_version)
+    name_resolve.wait(key, timeout=600)
+    t0 = time.perf_counter()
+    n = len(meta.ipc_buffers)
+
+    async def go():
+        async with aiohttp.ClientSession(timeout=aiohttp.ClientTimeout(total=timeout),
+                                         connector=get_default_connector()) as session:
+            return await asyncio.gather(*[
+                arequest_with_retry(addr=a, session=session, endpoint="/update_weights_from_ipc", method="POST",
+                                    payload=dict(buffer=meta.ipc_buffers[i % n], layout=meta.ipc_layout,
+                                                 used_bytes=meta.ipc_used_bytes, version=next_version,
+                                                 abort_all_requests=True),
+                                    max_retries=retries, timeout=timeout)
+                for i, a in enumerate(addresses)])
+
+    for r in asyncio.run(go()):
+        assert r.get("success"), r
+    logger.info(f"peer-memory weight update of {len(addresses)} server(s) took {(time.perf_counter() - t0) * 1e3:.1f} ms")
     return True
 
 

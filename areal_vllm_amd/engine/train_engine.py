@@ -333,6 +333,9 @@ class NativeTrainEngine(TrainEngine):
             self._replica_sync(self.model.flat.main_grad, self._partial_grad_ranges(), "sum")
 
     def destroy(self):
+        if getattr(self, "_ipc_export", None) is not None:
+            self._ipc_export.close()
+            self._ipc_export = None
         self.model = None
         self.optimizer = None
         gc.collect()
@@ -542,10 +545,11 @@ class NativeTrainEngine(TrainEngine):
     # ----------------------------------------------------------------------- save / load
     def _save_sharded(self, meta: SaveLoadMeta):
         """Distributed checkpoint: every (pp, tp) shard writes its own slice of the flat buffer - no
-        gather, no conversion - plus a manifest with the parameter offsets; dp replica 0 writes. The
-        optimizer state is per rank as in the HF format. Role of the reference's ``dcp`` /
-        ``naive_distributed`` formats (``areal/experimental/utils/megatron_checkpointer.py``,
-        ``areal/experimental/autotp_engine.py:97``)."""
+        gather, no conversion - plus a manifest with the parameter offsets; dp replica 0 writes the dense
+        buffer, and with expert parallelism every rank of the first expert-data-parallel replica writes the
+        routed experts IT holds under its expert-parallel rank. The optimizer state is per rank as in the HF
+        format. Role of the reference's ``dcp`` / ``naive_distributed`` formats
+        (``areal/experimental/utils/megatron_checkpointer.py``, ``areal/experimental/autotp_engine.py:97``)."""
         import json
 
         from safetensors.torch import save_file
@@ -554,11 +558,8 @@ class NativeTrainEngine(TrainEngine):
         os.makedirs(meta.path, exist_ok=True)
         tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
         if g.coord.dp == 0 and g.coord.cp == 0:
-            tensors = {"flat": self.model.flat.flat.detach().cpu()}
-            if self.model.flat_experts is not None:
-                tensors["flat_experts"] = self.model.flat_experts.flat.detach().cpu()
-            save_file(tensors, os.path.join(meta.path, f"shard-{tag}.safetensors"))
-            manifest = dict(format="areal-sharded-v1", layout=dict(dp=g.dp, tp=g.tp, pp=g.pp, cp=g.cp, ep=g.ep),
+            save_file({"flat": self.model.flat.flat.detach().cpu()}, os.path.join(meta.path, f"shard-{tag}.safetensors"))
+            manifest = dict(format="areal-sharded-v2", layout=dict(dp=g.dp, tp=g.tp, pp=g.pp, cp=g.cp, ep=g.ep),
                             dtype=str(self.model.dtype).replace("torch.", ""),
                             offsets={n: [int(o), int(k)] for n, (o, k) in self.model.flat.offsets.items()},
                             layer_range=list(self.model.layer_range))
@@ -567,6 +568,10 @@ class NativeTrainEngine(TrainEngine):
             if g.coord.pp == 0 and g.coord.tp == 0:
                 with open(os.path.join(meta.path, "config.json"), "w") as f:
                     json.dump(self.model_config.to_hf_dict(), f, indent=2)
+        if self.model.flat_experts is not None and g.coord.dp < g.ep and g.coord.cp == 0:
+            # ep rank = dp % ep: ranks dp = 0 .. ep-1 hold the ep distinct expert sets
+            save_file({"flat_experts": self.model.flat_experts.flat.detach().cpu()},
+                      os.path.join(meta.path, f"experts-{tag}-ep{g.rank_in('ep')}.safetensors"))
         if meta.with_optim and self.optimizer is not None:
             sd = dict(optim=self.optimizer.state_dict(), lr_step=self._lr_step)
             if self.expert_optimizer is not None:
@@ -576,24 +581,60 @@ class NativeTrainEngine(TrainEngine):
             dist.barrier(group=self.grid.group("world"))
 
     def _load_sharded(self, meta: SaveLoadMeta):
+        """Load a sharded checkpoint. Written with the same (tp, pp) it is one file read per rank; written with
+        ANOTHER tensor / pipeline layout, every rank pulls the intervals of the source shards that make up its
+        own flat buffer (the plan of ``parallel/param_realloc.py``, applied to files instead of peers): the
+        resharding load of ``areal/experimental/utils/megatron_checkpointer.py`` /
+        ``areal/experimental/model/hf_load.py``."""
+        import glob
         import json
 
         from safetensors.torch import load_file
 
         g = self.grid
-        tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
-        with open(os.path.join(meta.path, f"manifest-{tag}.json")) as f:
-            man = json.load(f)
-        lay = man["layout"]
-        if (lay["tp"], lay["pp"]) != (g.tp, g.pp):
-            raise ValueError(f"sharded checkpoint was written as tp{lay['tp']} pp{lay['pp']}, this engine is "
-                             f"tp{g.tp} pp{g.pp}; convert through the hf format or parallel/param_realloc.py")
-        mine = {n: [int(o), int(k)] for n, (o, k) in self.model.flat.offsets.items()}
-        assert man["offsets"] == mine, "parameter layout of the checkpoint differs from this model"
-        t = load_file(os.path.join(meta.path, f"shard-{tag}.safetensors"))
-        self.model.flat.flat.copy_(t["flat"].to(self.model.flat.flat.dtype))
+        mans = sorted(glob.glob(os.path.join(meta.path, "manifest-pp*-tp*.json")))
+        if not mans:
+            raise FileNotFoundError(f"no sharded checkpoint manifest under {meta.path}")
+        with open(mans[0]) as f:
+            lay = json.load(f)["layout"]
+        flat = self.model.flat.flat
+        if (lay["tp"], lay["pp"]) == (g.tp, g.pp):
+            tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
+            with open(os.path.join(meta.path, f"manifest-{tag}.json")) as f:
+                man = json.load(f)
+            mine = {n: [int(o), int(k)] for n, (o, k) in self.model.flat.offsets.items()}
+            assert man["offsets"] == mine, "parameter layout of the checkpoint differs from this model"
+            t = load_file(os.path.join(meta.path, f"shard-{tag}.safetensors"))
+            flat.copy_(t["flat"].to(flat.dtype))
+        else:
+            from ..parallel.param_realloc import Layout, derive_realloc_plan
+
+            if self.model.flat_experts is not None:
+                raise NotImplementedError("resharding a mixture-of-experts checkpoint across tp / pp layouts: "
+                                          "convert through the hf format")
+            src, dst = Layout(1, int(lay["tp"]), int(lay["pp"])), Layout(1, g.tp, g.pp)
+            me = dst.index_of(g.coord.pp, 0, g.coord.tp)
+            host = torch.zeros(flat.numel(), dtype=flat.dtype)
+            filled = 0
+            for tr in derive_realloc_plan(self.model_config, src, dst, dtype=flat.dtype):
+                if tr.dst != me:
+                    continue
+                sp, st = divmod(tr.src, src.tp)
+                sflat = load_file(os.path.join(meta.path, f"shard-pp{sp}-tp{st}.safetensors"))["flat"].to(flat.dtype)
+                ops.set_intervals(ops.slice_intervals(sflat, tr.src_intervals), host, tr.dst_intervals)
+                filled += tr.numel
+            used = sum(k for _, k in self.model.flat.offsets.values())
+            assert filled == used, f"resharding load covered {filled} of {used} parameter elements"
+            flat.copy_(host)
+            logger.info(f"resharded checkpoint load: tp{src.tp} pp{src.pp} -> tp{dst.tp} pp{dst.pp}")
         if self.model.flat_experts is not None:
-            self.model.flat_experts.flat.copy_(t["flat_experts"])
+            if int(lay.get("ep", 1)) != g.ep:
+                raise ValueError(f"sharded checkpoint holds ep{lay.get('ep', 1)} expert shards, this engine is ep{g.ep}; "
+                                 "convert through the hf format")
+            tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
+            fe = self.model.flat_experts.flat
+            t = load_file(os.path.join(meta.path, f"experts-{tag}-ep{g.rank_in('ep')}.safetensors"))
+            fe.copy_(t["flat_experts"].to(fe.dtype))
 
     def save(self, meta: SaveLoadMeta):
         if meta.weight_format in ("dcp", "naive_distributed"):
@@ -668,6 +709,18 @@ class NativeTrainEngine(TrainEngine):
         else:
             yield from hf_io.native_to_hf_state(self.model, gather=True)
 
+    def share_pipeline_stats(self, stats: Dict[str, float]) -> Dict[str, float]:
+        """Loss functions run on the last pipeline stage only, so their statistics (actor loss, entropy, clip
+        ratios ...) are recorded there, while the logging sink is global rank 0 = stage 0. Every stage gets
+        the union; values this stage exported itself win. No-op without pipeline parallelism."""
+        if self.grid.pp <= 1 or not dist.is_initialized():
+            return stats
+        group = self.grid.group("pp")
+        ranks = dist.get_process_group_ranks(group)
+        box = [stats if self.grid.coord.pp == self.grid.pp - 1 else None]
+        dist.broadcast_object_list(box, src=ranks[self.grid.pp - 1], group=group)
+        return {**(box[0] or {}), **stats}
+
     def connect_local_engine(self, engine):
         """Register a rollout engine living in this process (colocated mode)."""
         self._local_rollout_engine = engine
@@ -694,8 +747,39 @@ class NativeTrainEngine(TrainEngine):
             self._upload_disk(meta)
         elif meta.type in ("nccl", "xgmi"):
             self._upload_collective(meta)
+        elif meta.type == "ipc":
+            self._upload_ipc(meta)
         else:
             raise NotImplementedError(f"Unknown weight update type {meta.type}")
+
+    def export_weight_buffers(self) -> Dict[str, Any]:
+        """Export the memory behind this rank's flat bf16 parameter buffer for peer-memory weight updates and
+        gather the descriptors of all data-parallel ranks (collective over the world group)."""
+        from ..ops import ipc
+
+        if self.grid.tp > 1 or self.grid.pp > 1 or self.model.flat_experts is not None:
+            raise NotImplementedError("peer-memory weight updates copy the flat buffer of an unsharded replica "
+                                      "(data-parallel trainers); use the collective or disk transport")
+        if getattr(self, "_ipc_export", None) is None:
+            self._ipc_export = ipc.export_buffer(self.model.flat.flat)
+        descs = [self._ipc_export.desc]
+        if dist.is_initialized() and self.world_size > 1:
+            descs = [None] * self.world_size
+            dist.all_gather_object(descs, self._ipc_export.desc, group=self.grid.group("world"))
+        name, off, shape = self.model.flat.specs[-1]
+        used = (off + int(math.prod(shape))) * self.model.flat.flat.element_size()
+        return dict(ipc_buffers=descs, ipc_layout=flat_layout_fingerprint(self.model), ipc_used_bytes=int(used))
+
+    def _upload_ipc(self, meta: WeightUpdateMeta):
+        """Peers pull; this side only has to make the buffer final (finish the optimizer step's stream work,
+        rewrite the host mirror on the CPU platform) and say so: rank 0 posts the update key the client side
+        waits for once every rank is ready."""
+        self._ipc_export.refresh()
+        if dist.is_initialized():
+            dist.barrier(group=self.grid.group("world"))
+        if self.rank == 0:
+            key = names.update_weights_from_ipc(self.config.experiment_name, self.config.trial_name, self._version)
+            name_resolve.add(key, str(time.time_ns()), keepalive_ttl=120, replace=True)
 
     def _upload_disk(self, meta: WeightUpdateMeta):
         self.save(SaveLoadMeta(path=meta.path, weight_format="hf", with_optim=False))
@@ -725,7 +809,16 @@ class NativeTrainEngine(TrainEngine):
         ``fsdp_engine.py:399-433``). The chunks of one round (one per sender) travel concurrently."""
         self._init_weight_update_group(meta)
         n = max(1, meta.nccl_n_senders)
-        full = dict(self._iter_full_hf_params())
+        # Only the tensors of this rank's own chunks are kept: a tensor-parallel rank still takes part in every
+        # gather of the stream, but a full gathered copy of the model never exists on any rank, and ranks that
+        # send nothing from an unsharded replica skip the stream altogether.
+        mine_names = {spec.name for ci, chunk in enumerate(meta.nccl_param_specs) if ci % n == self.rank and self.rank < n
+                      for spec in chunk}
+        full = {}
+        if mine_names or self.grid.tp > 1:
+            for name, t in self._iter_full_hf_params():
+                if name in mine_names:
+                    full[name] = t
         for lo in range(0, len(meta.nccl_param_specs), n):
             mine = lo + self.rank
             if self.rank < n and mine < len(meta.nccl_param_specs):
@@ -736,6 +829,15 @@ class NativeTrainEngine(TrainEngine):
                 dist.barrier(group=self.grid.group("world"))
         if self.device.type == "cuda":
             torch.cuda.synchronize()
+
+
+def flat_layout_fingerprint(model: Transformer) -> str:
+    """Identifies a flat parameter layout (names, offsets, shapes, dtype): two buffers with equal fingerprints
+    can be copied byte for byte."""
+    import hashlib
+
+    text = repr([(n, int(o), tuple(int(x) for x in sh)) for n, o, sh in model.flat.specs]) + str(model.flat.flat.dtype)
+    return hashlib.sha1(text.encode()).hexdigest()
 
 
 # Names used by scripts written against the reference API.

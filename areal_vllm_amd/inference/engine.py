@@ -487,6 +487,58 @@ class NativeInferenceEngine:
                 self._after_weight_change(version)
         self._control(f)
 
+    # ------------------------------------------------------------ weight updates from peer memory
+    def update_weights_from_ipc(self, buffer: Dict[str, Any], layout: str, used_bytes: int,
+                                version: Optional[int] = None, abort_running: bool = True) -> Dict[str, float]:
+        """Pull the trainer's flat parameter buffer out of its (exported) memory.
+
+        Phase 1 runs on the CALLER's thread while the engine loop keeps decoding: a device-to-device copy on a
+        side stream from the peer mapping into a staging buffer (xGMI between two GPUs, a local copy when
+        trainer and server share one). Phase 2 runs between two engine steps: running requests are aborted
+        (their KV cache belongs to the old weights; the client re-issues them), staging -> live parameters
+        (an on-device copy, ~1.5 ms for a 1.5B model), prefix cache flushed, version bumped. Returns timings."""
+        from ..engine.train_engine import flat_layout_fingerprint
+        from ..ops import ipc
+
+        assert self.tp_size == 1, "the flat-buffer pull needs identical layouts; tensor-parallel servers load by name"
+        mine = flat_layout_fingerprint(self.model)
+        if layout and layout != mine:
+            raise ValueError("the trainer's flat parameter layout differs from this server's (model config, dtype "
+                             "or tied-embedding setting)")
+        flat = self.model.flat.flat
+        n = int(used_bytes) or min(int(buffer["nbytes"]), flat.numel() * flat.element_size())
+        assert n <= flat.numel() * flat.element_size(), "trainer buffer holds more parameters than this model"
+        key = buffer.get("handle") or buffer.get("name")
+        peers = self.__dict__.setdefault("_ipc_peers", {})
+        t0 = time.perf_counter()
+        if key not in peers:
+            peers[key] = ipc.PeerBuffer(buffer)
+        if getattr(self, "_ipc_staging", None) is None:
+            self._ipc_staging = torch.empty_like(flat)
+        cuda = self.device.type == "cuda"
+        if cuda:
+            torch.cuda.set_device(self.device)
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._copy_stream):
+                peers[key].copy_into(self._ipc_staging, n)
+            self._copy_stream.synchronize()
+        else:
+            peers[key].copy_into(self._ipc_staging, n)
+        t1 = time.perf_counter()
+
+        def flip():
+            if abort_running:
+                self.sched.abort_all()
+                self._deliver()
+            flat.view(torch.uint8).view(-1)[:n].copy_(self._ipc_staging.view(torch.uint8).view(-1)[:n])
+            if cuda:
+                torch.cuda.current_stream().synchronize()
+            self._after_weight_change(version)
+        self._control(flip)
+        t2 = time.perf_counter()
+        return dict(pull_ms=(t1 - t0) * 1e3, flip_ms=(t2 - t1) * 1e3, bytes=float(n))
+
     # ------------------------------------------------------- weight updates over a collective
     def _join_update_group(self, body: Dict[str, Any]):
         from ..utils.distributed import init_custom_process_group
@@ -554,13 +606,26 @@ class NativeInferenceEngine:
         }
 
 
-def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]):
-    """Copy HF-named FULL tensors into the (possibly tensor-parallel) native parameters."""
+def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor], strict: bool = True):
+    """Copy HF-named FULL tensors into the (possibly tensor-parallel) native parameters. With `strict`, a
+    tensor whose name maps onto no parameter of this model raises instead of being dropped (a silent drop
+    leaves that part of the rollout model on stale weights)."""
     cfg = model.cfg
+    if cfg.family == "gpt2":
+        raise NotImplementedError("named weight updates are implemented for the RMSNorm / rotary / gated-MLP "
+                                  "families; GPT-2 is a training-side family (use the hf checkpoint path)")
     D = cfg.head_dim
     tp, tr = model.tp_size, model.tp_rank
     params = dict(model.named_parameters())
-    lo_layer, _ = model.layer_range
+    lo_layer, hi_layer = model.layer_range
+    given = set(tensors)
+
+    class _Seen(dict):  # records which of the given names were read
+        def __getitem__(self, k):
+            given.discard(k)
+            return dict.__getitem__(self, k)
+
+    tensors = _Seen(tensors)
 
     def rows(t, lo, hi):
         return t[lo:hi]
@@ -610,6 +675,9 @@ def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]
                     dn.data[le].copy_(tensors[dnn][:, tr * f:(tr + 1) * f])
     if model.has_embed and "model.embed_tokens.weight" in tensors:
         params["embed"].data.copy_(tensors["model.embed_tokens.weight"])
+    for n in [k for k in list(given) if k.startswith("visual.")]:  # vision tower: replicated, same names
+        if n in params:
+            params[n].data.copy_(tensors[n])
     if model.has_head:
         if "model.norm.weight" in tensors:
             params["norm"].data.copy_(tensors["model.norm.weight"])
@@ -617,3 +685,20 @@ def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]
             for n in ("lm_head.weight", "score.weight"):
                 if n in tensors:
                     params["head"].data.copy_(tensors[n])
+        elif "lm_head.weight" in tensors:  # tied head: the embedding copy above covers it
+            tensors["lm_head.weight"]
+    if strict and given:
+        import re
+
+        def foreign(n):  # parameters of layers / ends another pipeline stage owns are not ours to consume
+            if ".experts." in n:  # routed experts other expert-parallel ranks hold
+                return True
+            m = re.match(r"model\.layers\.(\d+)\.", n)
+            if m:
+                return not (lo_layer <= int(m.group(1)) < hi_layer)
+            if n == "model.embed_tokens.weight" or n.startswith("visual."):
+                return not model.has_embed
+            return n in ("model.norm.weight", "lm_head.weight", "score.weight") and not model.has_head
+        left = sorted(n for n in given if not foreign(n))
+        if left:
+            raise KeyError(f"{len(left)} received tensor(s) map onto no parameter of this model: {left[:8]}")

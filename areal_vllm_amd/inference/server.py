@@ -67,6 +67,7 @@ class InferenceServer:
         r.add_post("/update_weights_from_disk", self.update_from_disk)
         r.add_post("/init_weights_update_group", self.init_update_group)
         r.add_post("/update_weights_from_distributed", self.update_from_distributed)
+        r.add_post("/update_weights_from_ipc", self.update_from_ipc)
         r.add_post("/set_version", self.set_version)
 
     async def health(self, req):
@@ -190,6 +191,18 @@ class InferenceServer:
         except Exception as e:
             return web.json_response({"success": False, "message": repr(e)})
         return web.json_response({"success": True, "message": "Succeeded to update parameter online."})
+
+
+    async def update_from_ipc(self, req):
+        body = await req.json()
+        t0 = time.perf_counter()
+        try:
+            info = await self._offload(self.engine.update_weights_from_ipc, body["buffer"], body.get("layout", ""),
+                                       int(body.get("used_bytes", 0)), body.get("version"),
+                                       bool(body.get("abort_all_requests", True)))
+        except Exception as e:
+            return web.json_response({"success": False, "message": repr(e)})
+        return web.json_response({"success": True, "message": f"pulled in {time.perf_counter() - t0:.3f}s", **info})
 
 
 def _add_config_args(parser: argparse.ArgumentParser):

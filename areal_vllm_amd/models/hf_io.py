@@ -286,10 +286,11 @@ def native_to_hf_state(model, gather: bool = True, experts_only: bool = False) -
     params = dict(model.named_parameters())
     if model.has_embed:
         yield "model.embed_tokens.weight", params["embed"].data
-        if model.tp_rank == 0 or not gather:  # the tower is replicated over tensor-parallel ranks
-            for n, p in params.items():
-                if n.startswith("visual."):
-                    yield n, p.data
+        # the tower is replicated over tensor-parallel ranks: every rank yields it, so parameter specs and
+        # collective weight pushes agree across the tp group (checkpoint writers are tp rank 0 only)
+        for n, p in params.items():
+            if n.startswith("visual."):
+                yield n, p.data
     lo_layer, _ = model.layer_range
     for li, blk in enumerate(model.layers):
         i = lo_layer + li

@@ -58,8 +58,13 @@ def build_rollout_engines(config: GRPOConfig, actor: NativePPOActor, parallel_st
             logger.warning("trainer has pipeline stages: weights go to the rollout servers through checkpoint "
                            "files (rollout_weight_update=disk)")
             transport = "disk"
+        if transport == "ipc" and (parallel_strategy.tp_size > 1 or am.gen.tp_size > 1):
+            logger.warning("peer-memory weight updates need unsharded replicas on both sides; using the collective push")
+            transport = "xgmi"
         if transport == "disk":
             meta = WeightUpdateMeta.from_disk(config.experiment_name, config.trial_name, config.cluster.fileroot)
+        elif transport == "ipc":
+            meta = WeightUpdateMeta.from_ipc(actor)
         else:
             # "xgmi": every data-parallel trainer rank pushes its share of the chunks through its own links;
             # "nccl": the reference's protocol, everything leaves through rank 0
@@ -263,7 +268,7 @@ def run_grpo(argv, reward_fn: Optional[Callable] = None,
             recover_handler.dump(actor, step_info, saver, evaluator, stats_logger, train_dataloader,
                                  tokenizer=tokenizer)
         sync()
-        stats[0].update(stats_tracker.export_all(reduce_group=actor.data_parallel_group))
+        stats[0].update(actor.share_pipeline_stats(stats_tracker.export_all(reduce_group=actor.data_parallel_group)))
         stats_logger.commit(epoch, step, global_step, stats)
         sync()
         if rollout is not None:

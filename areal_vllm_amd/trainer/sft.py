@@ -103,7 +103,7 @@ def run_sft(argv, config_cls=SFTConfig, processor_needed: bool = False):
             dist.barrier()
         current_platform.synchronize()
         out = dict(stats) if isinstance(stats, dict) else {}
-        out.update(stats_tracker.export_all(reduce_group=engine.data_parallel_group))
+        out.update(engine.share_pipeline_stats(stats_tracker.export_all(reduce_group=engine.data_parallel_group)))
         stats_logger.commit(epoch, step, global_step, out)
         losses.append(out.get("sft/loss/avg", out.get("sft/loss", float("nan"))))
     stats_logger.close()

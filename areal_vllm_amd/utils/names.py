@@ -24,6 +24,10 @@ def update_weights_from_disk(experiment_name, trial_name, model_version):
     return f"{USER_NAMESPACE}/{experiment_name}/{trial_name}/update_weights_from_disk/{model_version}"
 
 
+def update_weights_from_ipc(experiment_name, trial_name, model_version):
+    return f"{USER_NAMESPACE}/{experiment_name}/{trial_name}/update_weights_from_ipc/{model_version}"
+
+
 def worker_status(experiment_name, trial_name, worker_name):
     return f"{USER_NAMESPACE}/{experiment_name}/{trial_name}/status/{worker_name}"
 

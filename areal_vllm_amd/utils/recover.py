@@ -156,19 +156,26 @@ class RecoverHandler:
             e.load(SaveLoadMeta(path=ckpt, weight_format="hf", with_optim=True))
         global_step = info.last_step_info.global_step
         self.last_step_info = info.last_step_info
-        if inference_engine is not None:
+        if weight_update_meta is not None:
+            # Every trainer rank takes part (a tensor-parallel trainer gathers its shards inside
+            # `upload_weights`, and the barrier is a world collective); only the ranks that drive a rollout
+            # engine - the data-parallel heads - talk to it.
             upd = engine[inference_engine_update_from]
-            inference_engine.pause()
             is0 = (not dist.is_initialized()) or dist.get_rank() == 0
-            fut = inference_engine.update_weights(weight_update_meta) if is0 else None
+            fut = None
+            if inference_engine is not None:
+                inference_engine.pause()
+                if is0 or weight_update_meta.type == "inproc":  # every colocated head drives its own engine
+                    fut = inference_engine.update_weights(weight_update_meta)
             upd.upload_weights(weight_update_meta)
             if fut is not None:
                 fut.result()
             if dist.is_initialized():
                 dist.barrier()
-            inference_engine.resume()
             upd.set_version(global_step + 1)
-            inference_engine.set_version(global_step + 1)
+            if inference_engine is not None:
+                inference_engine.resume()
+                inference_engine.set_version(global_step + 1)
         return info
 
 

@@ -1,0 +1,49 @@
+// Peer-memory weight shipping: a trainer process exports the device allocation that holds its flat bf16
+// parameter buffer, a rollout process maps it and pulls the bytes with an asynchronous device-to-device copy
+// on a side stream (over xGMI when the two processes own different GPUs of a node, a local copy when they
+// share one). Host-side wrappers over the HIP IPC API with a C ABI for ctypes.
+//
+// Replaces the reference's weight funnel (every parameter all-gathered on the trainer, then broadcast from
+// trainer rank 0 into every server rank: areal/engine/fsdp_engine.py:399-433) for layouts whose flat buffers
+// match: no collective, no process group between trainer and servers, one copy per server.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#define IPC_RET(expr)                      \
+  do {                                     \
+    hipError_t _e = (expr);                \
+    if (_e != hipSuccess) return (int)_e;  \
+  } while (0)
+
+// handle_out: 64 bytes. offset_out: byte offset of `ptr` inside its allocation (the handle names the
+// allocation's base). alloc_size_out: size of that allocation.
+extern "C" int areal_ipc_export(const void* ptr, unsigned char* handle_out, long* offset_out, long* alloc_size_out) {
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  IPC_RET(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr));
+  hipIpcMemHandle_t h;
+  IPC_RET(hipIpcGetMemHandle(&h, (void*)base));
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  memcpy(handle_out, &h, sizeof(h));
+  *offset_out = (long)((const char*)ptr - (const char*)base);
+  *alloc_size_out = (long)size;
+  return 0;
+}
+
+extern "C" int areal_ipc_open(const unsigned char* handle, void** base_out) {
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  IPC_RET(hipIpcOpenMemHandle(base_out, h, hipIpcMemLazyEnablePeerAccess));
+  return 0;
+}
+
+extern "C" int areal_ipc_close(void* base) {
+  IPC_RET(hipIpcCloseMemHandle(base));
+  return 0;
+}
+
+extern "C" int areal_memcpy_d2d_async(void* dst, const void* src, long bytes, hipStream_t st) {
+  if (bytes <= 0) return 0;
+  IPC_RET(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, st));
+  return 0;
+}

@@ -83,13 +83,17 @@ def test_colocated_allocation_with_parallel_trainers(layout):
     assert len(rewards) >= 8 and rewards[-1] > 0.6 > rewards[0], rewards
 
 
-def test_grpo_recover_run_continues(tmp_path):
+@pytest.mark.parametrize("layout", [None, "d1p1t2"])
+def test_grpo_recover_run_continues(tmp_path, layout):
     """Kill-free recover check: run 1 step budget with recover checkpoints, then relaunch with
-    AREAL_RECOVER_RUN semantics (`recover.mode=resume`) and see the step counter continue."""
+    AREAL_RECOVER_RUN semantics (`recover.mode=resume`) and see the step counter continue. The colocated
+    tensor-parallel layout re-uploads the recovered weights with a gather every trainer rank takes part in."""
     root = str(tmp_path)
     common = [f"cluster.fileroot={root}", f"cluster.name_resolve.nfs_record_root={root}/nr", "trial_name=rec",
               "recover.freq_steps=1", "recover.freq_epochs=null", "recover.freq_secs=null",
               "train_dataset.path=synthetic:low-token:n=32:len=8"]
+    if layout is not None:
+        common += [f"allocation_mode={layout}", "async_training=true"]
     r = _run_launcher("examples/synthetic/toy_grpo.py", "examples/synthetic/toy_grpo.yaml",
                       common + ["recover.mode=auto", "total_train_steps=2"])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

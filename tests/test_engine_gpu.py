@@ -413,11 +413,13 @@ def test_vision_language_rollout_matches_trainer_on_gpu():
         eng.destroy()
 
 
-def test_decoupled_server_process_with_disk_weight_updates(tmp_path):
+@pytest.mark.parametrize("transport", ["disk", "ipc"])
+def test_decoupled_server_process_with_disk_weight_updates(tmp_path, transport):
     """Decoupled deployment on one GPU: the rollout engine runs as its own HTTP server process, the trainer
-    talks to it through the remote client, publishes weights as a HF checkpoint on disk, and after every
-    update the server's behaviour log-probs must agree with the trainer's recomputation (which proves that
-    the new weights arrived)."""
+    talks to it through the remote client and publishes weights either as a HF checkpoint on disk or through
+    peer memory (`ipc`: the server process maps the trainer's flat bf16 buffer with hipIpc and pulls it with an
+    asynchronous device-to-device copy on a side stream); after every update the server's behaviour
+    log-probs must agree with the trainer's recomputation (which proves that the new weights arrived)."""
     import socket
     import subprocess
     import time
@@ -466,7 +468,8 @@ def test_decoupled_server_process_with_disk_weight_updates(tmp_path):
         client = RemoteInferenceEngine(InferenceEngineConfig(experiment_name="dec", trial_name="t", setup_timeout=60,
                                                              max_concurrent_rollouts=16, consumer_batch_size=8))
         client.initialize(addr=f"127.0.0.1:{port}", train_data_parallel_size=1)
-        meta = WeightUpdateMeta.from_disk("dec", "t", str(tmp_path))
+        meta = (WeightUpdateMeta.from_disk("dec", "t", str(tmp_path)) if transport == "disk"
+                else WeightUpdateMeta.from_ipc(actor))
         g = GenerationHyperparameters(n_samples=2, max_new_tokens=48, temperature=1.0, stop_token_ids=[1])
         wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: float(sum(ci) % 2), g, reward_in_process=True)
         gen = torch.Generator().manual_seed(11)

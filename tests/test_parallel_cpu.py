@@ -62,11 +62,19 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
     strategy_kwargs = dict(strategy_kwargs)
     cfg.native.context_parallel_mode = strategy_kwargs.pop("_cp_mode", "ulysses")
     cfg.native.sequence_parallel = strategy_kwargs.pop("_seq_par", False)
+    reshard_from = strategy_kwargs.pop("_reshard_from", None)
     eng = NativeTrainEngine(cfg)
     st = ParallelStrategy(**strategy_kwargs)
     eng.create_process_group(st)
     eng.initialize(None, FinetuneSpec(1, 8, 4))
     if ckpt_in is None:
+        eng.save(SaveLoadMeta(path=ckpt_out, weight_format="hf", with_optim=False))
+        eng.destroy()
+        return
+    if reshard_from is not None:
+        # load a sharded checkpoint written under ANOTHER (tp, pp) layout, write it back as HF
+        eng.model.flat.flat.zero_()
+        eng.load(SaveLoadMeta(path=reshard_from, weight_format="dcp", with_optim=False))
         eng.save(SaveLoadMeta(path=ckpt_out, weight_format="hf", with_optim=False))
         eng.destroy()
         return
@@ -89,10 +97,15 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
     shard_dir = os.path.join(ckpt_out, "sharded")
     eng.save(SaveLoadMeta(path=shard_dir, weight_format="dcp", with_optim=True))
     want_w, want_m = eng.model.flat.flat.clone(), eng.optimizer.m.clone()
+    want_e = eng.model.flat_experts.flat.clone() if eng.model.flat_experts is not None else None
     eng.model.flat.flat.add_(1.0)
     eng.optimizer.m.zero_()
+    if want_e is not None:
+        eng.model.flat_experts.flat.zero_()
     eng.load(SaveLoadMeta(path=shard_dir, weight_format="dcp", with_optim=True))
     assert torch.equal(eng.model.flat.flat, want_w) and torch.equal(eng.optimizer.m, want_m)
+    if want_e is not None:  # every expert-parallel rank gets ITS experts back, not rank 0's
+        assert torch.equal(eng.model.flat_experts.flat, want_e)
     assert torch.equal(eng.optimizer.master, want_w[eng.optimizer.lo:eng.optimizer.hi].float())
     eng.destroy()
 
@@ -168,6 +181,28 @@ def test_layout_matches_single_process(dense_reference, name, world, kw, n_mbs):
         # the last token of a sequence scores its packed neighbour's first token: layout dependent
         for i, n in enumerate([23, 9, 31, 14][: fw.shape[0]]):
             torch.testing.assert_close(fw[i, : n - 1], ref_fw[i, : n - 1], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("src,dst_world,dst_kw", [
+    ("tp2", 1, {}),
+    ("pp2", 2, dict(tensor_parallel_size=2)),
+    ("dp2tp2", 4, dict(tensor_parallel_size=2, pipeline_parallel_size=2)),
+])
+def test_sharded_checkpoint_loads_into_another_layout(dense_reference, src, dst_world, dst_kw):
+    """A sharded checkpoint written as tp2 / pp2 / dp2tp2 is read by an engine laid out differently (every
+    rank pulls the intervals that make up its own flat buffer from the source shard files)."""
+    d, init, ref = dense_reference
+    src_dir = os.path.join(d, src)
+    if not os.path.isdir(os.path.join(src_dir, "sharded")):
+        kw, world, n_mbs = {"tp2": (dict(tensor_parallel_size=2), 2, 2), "pp2": (dict(pipeline_parallel_size=2), 2, 3),
+                            "dp2tp2": (dict(data_parallel_size=2, tensor_parallel_size=2), 4, 1)}[src]
+        _run(world, kw, init, src_dir, n_mbs=n_mbs)
+    out = os.path.join(d, f"reshard_{src}_to_{dst_world}")
+    _run(dst_world, dict(dst_kw, _reshard_from=os.path.join(src_dir, "sharded")), init, out)
+    a, b = _load_ckpt(src_dir), _load_ckpt(out)
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 def test_expert_parallel_matches_single_process():

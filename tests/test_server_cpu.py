@@ -141,8 +141,10 @@ def test_interrupted_generation_spans_versions(server):
     client.destroy()
 
 
-def test_collective_weight_update_into_server_process(tmp_path):
-    """Default weight path of the decoupled allocation: trainer rank 0 and the rollout server join a second
+@pytest.mark.parametrize("transport", ["collective", "ipc"])
+def test_collective_weight_update_into_server_process(tmp_path, transport):
+    """`ipc`: the server maps the trainer's exported flat buffer (POSIX shared memory on the CPU platform,
+    hipIpc device memory on GPUs) and pulls it while it keeps serving. `collective`: default weight path of the decoupled allocation: trainer rank 0 and the rollout server join a second
     process group and the trainer broadcasts every HF-named parameter chunk by chunk (gloo on CPU, RCCL on
     GPUs). Afterwards the server scores its own samples like the trainer does."""
     import subprocess
@@ -184,10 +186,14 @@ def test_collective_weight_update_into_server_process(tmp_path):
         client = RemoteInferenceEngine(InferenceEngineConfig(experiment_name="col", trial_name="t", setup_timeout=60,
                                                              max_concurrent_rollouts=8, consumer_batch_size=4))
         client.initialize(addr=f"127.0.0.1:{port}", train_data_parallel_size=1)
-        meta = WeightUpdateMeta.from_fsdp_nccl(AllocationMode.from_str("native:d1+native:d1"), actor,
-                                               weight_chunked_mem_mb=1)
-        meta.nccl_master_address = "127.0.0.1"
-        assert len(meta.nccl_param_specs) > 1  # several chunks
+        if transport == "ipc":
+            meta = WeightUpdateMeta.from_ipc(actor)
+            assert meta.ipc_buffers and meta.ipc_used_bytes > 0
+        else:
+            meta = WeightUpdateMeta.from_fsdp_nccl(AllocationMode.from_str("native:d1+native:d1"), actor,
+                                                   weight_chunked_mem_mb=1)
+            meta.nccl_master_address = "127.0.0.1"
+            assert len(meta.nccl_param_specs) > 1  # several chunks
         wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: 1.0, GenerationHyperparameters(n_samples=2, max_new_tokens=10),
                           reward_in_process=True)
         prompts = [dict(input_ids=[5, 6, 7, 8]), dict(input_ids=[9, 10, 11])]
@@ -206,6 +212,7 @@ def test_collective_weight_update_into_server_process(tmp_path):
             fut = client.update_weights(meta)
             actor.upload_weights(meta)
             assert fut.result(timeout=120)
+            actor.set_version(version)
             client.set_version(version)
             client.resume()
             g, b = gap()

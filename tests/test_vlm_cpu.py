@@ -101,3 +101,32 @@ def test_vl_rollout_matches_trainer_and_trains():
     finally:
         roll.destroy()
         eng.destroy()
+
+
+def test_named_weight_update_reaches_the_vision_tower():
+    """Weight updates that travel by name (collective push, tensor-parallel colocated load) must update the
+    vision tower too, and must not drop a tensor silently."""
+    import pytest
+
+    from areal_vllm_amd.inference.engine import assign_hf_named_tensors
+    from areal_vllm_amd.models import hf_io
+    from areal_vllm_amd.models.config import preset
+    from areal_vllm_amd.models.transformer import Transformer
+
+    cfg = preset("tiny-vl")
+    src = Transformer(cfg, dtype=torch.float32, device="cpu")
+    src.flatten()
+    src.init_weights(seed=11)
+    dst = Transformer(cfg, dtype=torch.float32, device="cpu")
+    dst.flatten()
+    dst.init_weights(seed=12)
+    state = dict(hf_io.native_to_hf_state(src, gather=False))
+    assert any(n.startswith("visual.") for n in state)
+    assign_hf_named_tensors(dst, state)
+    for (n, a), (_, b) in zip(src.named_parameters(), dst.named_parameters()):
+        assert torch.equal(a, b), n
+    with pytest.raises(KeyError):
+        assign_hf_named_tensors(dst, dict(state, **{"model.layers.0.mlp.not_a_weight": torch.zeros(1)}))
+    g = Transformer(preset("tiny-gpt2"), dtype=torch.float32, device="cpu")
+    with pytest.raises(NotImplementedError):
+        assign_hf_named_tensors(g, {})
