@@ -18,6 +18,13 @@ the synchronous schedule. Before the W warm-up steps the rollout pipeline is pri
 steps so that the timed steps see the steady state (staggered batches), not the start-up transient in
 which eta+1 batches finish together.
 
+``--mode decoupled`` (needs an even N >= 2) is the reference's own allocation (``sglang.d4p1t1+d4p1t1`` at
+N = 8, ``examples/math/gsm8k_grpo.yaml:3``): ranks 0 .. N/2-1 form the data-parallel trainer, ranks N/2 .. N-1
+each run a rollout server process-in-rank (HTTP verbs of ``inference/server.py``) on their own GPU; the trainer
+ranks reach them through the remote client, and after every step each server pulls the new weights out of a
+trainer rank's exported flat buffer (peer memory, device-to-device over xGMI) while it keeps decoding.
+``--seq-len S`` sets max_new_tokens = S - prompt_len_max (the 4k / 24k configurations).
+
 Launch: ``python bench.py`` (1 GPU) or
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W``.
 Rank 0 prints ONE JSON line. `value` = RL samples (trajectories) per second over the whole job.
@@ -62,7 +69,85 @@ def parse_args():
                    help="take proximal log-probs from the training forward (valid for ppo_n_minibatches=1) instead of "
                         "a separate recompute pass; off by default to keep the reference's per-step work")
     p.add_argument("--profile-phases", action="store_true", help="print per-phase timings on rank 0 (stderr)")
-    return p.parse_args()
+    p.add_argument("--mode", default="colocated", choices=["colocated", "decoupled"],
+                   help="colocated: every rank trains AND generates on its GPU; decoupled: first half of the ranks "
+                        "train, second half serve rollouts (the reference's sglang.dXp1t1+dXp1t1 allocation)")
+    p.add_argument("--seq-len", type=int, default=0,
+                   help="total sequence budget: sets max_new_tokens = seq_len - prompt_len_max (0: keep --max-new-tokens)")
+    p.add_argument("--weight-update", default="ipc", choices=["ipc", "disk"],
+                   help="decoupled mode: how the rollout servers get new weights (ipc falls back to disk if the "
+                        "peer mapping cannot be opened)")
+    p.add_argument("--share-gpu", action="store_true",
+                   help="decoupled rehearsal on a single GPU: every rank uses device 0 (not a benchmark of N GPUs)")
+    a = p.parse_args()
+    if a.seq_len:
+        a.max_new_tokens = a.seq_len - a.prompt_len_max
+        assert a.max_new_tokens > 0, "--seq-len must exceed --prompt-len-max"
+    return a
+
+
+def _store(args, rank):
+    """Host-side rendezvous shared by trainer and rollout ranks (they are in no common process group)."""
+    import datetime
+
+    import torch.distributed as dist
+
+    port = int(os.environ.get("MASTER_PORT", "29533")) + 2
+    return dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), port, world_size=args.gpus, is_master=rank == 0,
+                         timeout=datetime.timedelta(seconds=1800), wait_for_workers=False)
+
+
+def serve_rollouts(args, rank, local_rank, store):
+    """Body of a rollout rank in decoupled mode: one native engine behind the HTTP server, until the trainer
+    side says the run is over."""
+    import asyncio
+    import socket
+    import threading
+
+    import torch
+    from aiohttp import web
+
+    from areal_vllm_amd.api.cli_args import InferenceServerConfig
+    from areal_vllm_amd.inference.engine import NativeInferenceEngine
+    from areal_vllm_amd.inference.server import InferenceServer
+    from areal_vllm_amd.models.config import preset
+
+    on_gpu = args.device == "cuda"
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    n_train = args.gpus // 2
+    # every trainer rank feeds prompts_per_gpu x n_samples sequences per step and may run eta+1 steps ahead
+    n_seqs = args.prompts_per_gpu * args.n_samples
+    srv = InferenceServerConfig(model_path=args.model, random_seed=1 + rank, dtype="bfloat16" if on_gpu else "float32",
+                                context_length=args.prompt_len_max + args.max_new_tokens + 64,
+                                max_running_requests=n_seqs * (args.eta + 1), max_prefill_tokens=32768,
+                                num_continuous_decode_steps=args.decode_steps, disable_cuda_graph=args.no_graph,
+                                schedule_policy="fcfs")
+    mc = preset(args.model)
+    engine = NativeInferenceEngine(srv, model_config=mc, device=dev, kv_cache_gb=args.kv_cache_gb if on_gpu else None,
+                                   num_pages=None if on_gpu else 2048)
+    engine.initialize(load_weights=False)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    server = InferenceServer(engine)
+    loop = asyncio.new_event_loop()
+    runner = web.AppRunner(server.app, access_log=None)
+
+    def run():
+        asyncio.set_event_loop(loop)
+        loop.run_until_complete(runner.setup())
+        loop.run_until_complete(web.TCPSite(runner, "127.0.0.1", port).start())
+        loop.run_forever()
+
+    threading.Thread(target=run, daemon=True, name="rollout-http").start()
+    store.set(f"server_addr_{rank - n_train}", f"127.0.0.1:{port}")
+    store.wait(["bench_done"])
+    m = engine.metrics()
+    store.set(f"server_stats_{rank - n_train}", json.dumps(dict(gen_tokens=m["gen_tokens_total"], aborted=m["aborted"],
+                                                                 prefill_time=m["prefill_time"],
+                                                                 decode_time=m["decode_time"])))
+    loop.call_soon_threadsafe(loop.stop)
+    engine.destroy()
 
 
 def main():
@@ -86,14 +171,39 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("AREAL_LOG_LEVEL", "WARNING")
     on_gpu = args.device == "cuda"
+    decoupled = args.mode == "decoupled"
+    if args.share_gpu:
+        local_rank = 0
+        os.environ["LOCAL_RANK"] = "0"
     if on_gpu:
         assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        if not args.share_gpu:
+            assert torch.cuda.device_count() > local_rank, (
+                f"rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     else:
         os.environ["HIP_VISIBLE_DEVICES"] = os.environ["CUDA_VISIBLE_DEVICES"] = ""
         os.environ["AREAL_PLATFORM"] = "cpu"
         dev = torch.device("cpu")
+    store = None
+    n_gen = 0
+    if decoupled:
+        assert world >= 2 and world % 2 == 0, "--mode decoupled splits the ranks in two halves: needs an even --gpus >= 2"
+        n_gen = world // 2
+        store = _store(args, rank)
+        if rank >= world - n_gen:
+            serve_rollouts(args, rank, local_rank, store)
+            return
+        # the trainer half forms its own process group: ranks 0 .. n_train-1 on the next port
+        world = world - n_gen
+        os.environ["WORLD_SIZE"] = str(world)
+        os.environ["MASTER_PORT"] = str(int(os.environ["MASTER_PORT"]) + 1)
+        # torchrun's agent store lives on the original port and counts N ranks: the trainer group rendezvouses
+        # on a store of its own (rank 0 hosts it)
+        os.environ["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+        addrs = [store.get(f"server_addr_{i}").decode() for i in range(n_gen)]
+        os.environ["AREAL_LLM_SERVER_ADDRS"] = ",".join(addrs)
 
     def dev_sync(all_streams=False):
         if on_gpu:
@@ -130,27 +240,105 @@ def main():
     actor.initialize(None, FinetuneSpec(total_train_epochs=1, dataset_size=10**6,
                                         train_batch_size=args.prompts_per_gpu * world))
 
+    engine = None
+    if decoupled:
+        from areal_vllm_amd.engine.remote_engine import RemoteInferenceEngine
+
+        rollout = RemoteInferenceEngine(
+            InferenceEngineConfig(experiment_name="bench", trial_name="bench",
+                                  max_concurrent_rollouts=args.prompts_per_gpu * world * (args.eta + 1),
+                                  consumer_batch_size=args.prompts_per_gpu * world, max_head_offpolicyness=args.eta,
+                                  queue_size=args.prompts_per_gpu * 64, setup_timeout=600, request_timeout=3600))
+        rollout.initialize(train_data_parallel_size=world)
+        transport = args.weight_update
+        meta = None
+        if transport == "ipc":
+            try:
+                meta = WeightUpdateMeta.from_ipc(actor)
+            except Exception as e:  # e.g. a platform without device IPC
+                print(f"[bench] peer-memory export failed ({e!r}); weights go through checkpoint files", file=sys.stderr)
+                transport = "disk"
+        if meta is None:
+            import tempfile
+
+            box = [tempfile.mkdtemp(prefix="areal_bench_wu_") if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            meta = WeightUpdateMeta.from_disk("bench", "bench", box[0])
     # ---- rollout engine on the same GPU
-    srv = InferenceServerConfig(model_path=args.model, random_seed=1 + rank, dtype="bfloat16" if on_gpu else "float32",
+    srv = None if decoupled else InferenceServerConfig(model_path=args.model, random_seed=1 + rank, dtype="bfloat16" if on_gpu else "float32",
                                 context_length=args.prompt_len_max + args.max_new_tokens + 64,
                                 max_running_requests=n_seqs_per_gpu * (args.eta + 1), max_prefill_tokens=32768,
                                 num_continuous_decode_steps=args.decode_steps, disable_cuda_graph=args.no_graph,
                                 schedule_policy="fcfs")
-    engine = NativeInferenceEngine(srv, model_config=actor.model_config, device=dev,
-                                   kv_cache_gb=args.kv_cache_gb if on_gpu else None,
-                                   num_pages=None if on_gpu else 2048)
-    engine.initialize(load_weights=False)
-    actor.connect_local_engine(engine)
-    rollout = LocalInferenceEngine(
-        InferenceEngineConfig(experiment_name="bench", trial_name="bench",
-                              max_concurrent_rollouts=args.prompts_per_gpu * world * (args.eta + 1),
-                              consumer_batch_size=args.prompts_per_gpu * world, max_head_offpolicyness=args.eta,
-                              queue_size=args.prompts_per_gpu * 64), engine)
-    engine.abort_on_weight_update = not args.retain_kv
-    rollout.initialize(train_data_parallel_size=world)
-    meta = WeightUpdateMeta.from_inproc()
-    actor.upload_weights(meta)  # trainer weights -> engine (both start from the same values)
-    engine.set_version(0)
+    if not decoupled:
+        engine = NativeInferenceEngine(srv, model_config=actor.model_config, device=dev,
+                                       kv_cache_gb=args.kv_cache_gb if on_gpu else None,
+                                       num_pages=None if on_gpu else 2048)
+        engine.initialize(load_weights=False)
+        actor.connect_local_engine(engine)
+        rollout = LocalInferenceEngine(
+            InferenceEngineConfig(experiment_name="bench", trial_name="bench",
+                                  max_concurrent_rollouts=args.prompts_per_gpu * world * (args.eta + 1),
+                                  consumer_batch_size=args.prompts_per_gpu * world, max_head_offpolicyness=args.eta,
+                                  queue_size=args.prompts_per_gpu * 64), engine)
+        engine.abort_on_weight_update = not args.retain_kv
+        rollout.initialize(train_data_parallel_size=world)
+        meta = WeightUpdateMeta.from_inproc()
+        actor.upload_weights(meta)  # trainer weights -> engine (both start from the same values)
+        engine.set_version(0)
+
+    wu = dict(transport="inproc" if not decoupled else meta.type, fallback=None)
+
+    def push_weights(version):
+        """Trainer weights -> rollout side, then the version bump both sides agree on."""
+        nonlocal meta
+        if not decoupled:
+            rollout.pause()
+            actor.upload_weights(meta)
+            actor.set_version(version)
+            rollout.set_version(version)
+            rollout.resume()
+            return
+        try:
+            fut = rollout.update_weights(meta) if rank == 0 else None
+            actor.upload_weights(meta)
+            ok = True
+            if fut is not None:
+                try:
+                    fut.result(timeout=1800)
+                except Exception as e:
+                    ok = False
+                    print(f"[bench] weight update over {meta.type} failed: {e!r}", file=sys.stderr)
+            flag = torch.tensor([1 if ok else 0], device=dev)
+            if world > 1:
+                dist.broadcast(flag, src=0)
+            if not int(flag.item()):
+                raise RuntimeError("rollout servers could not take the weights")
+        except RuntimeError:
+            if meta.type != "ipc":
+                raise
+            import tempfile
+
+            wu["fallback"] = "ipc -> disk"
+            box = [tempfile.mkdtemp(prefix="areal_bench_wu_") if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            meta = WeightUpdateMeta.from_disk("bench", "bench", box[0])
+            wu["transport"] = "disk"
+            rollout.pause()
+            fut = rollout.update_weights(meta) if rank == 0 else None
+            actor.upload_weights(meta)
+            if fut is not None:
+                fut.result(timeout=1800)
+            rollout.resume()
+        if world > 1:
+            dist.barrier()
+        actor.set_version(version)
+        rollout.set_version(version)
+
+    if decoupled:
+        push_weights(0)  # the servers start from their own random init: give them the trainer's weights
 
     mc = actor.model_config
     gconfig = GenerationHyperparameters(n_samples=args.n_samples, max_new_tokens=args.max_new_tokens, temperature=1.0,
@@ -188,13 +376,14 @@ def main():
             def __enter__(s):
                 dev_sync()
                 s.t = time.perf_counter()
-                s.d, s.p = engine.runner.n_decode_tokens, engine.runner.n_prefill_tokens
+                if engine is not None:
+                    s.d, s.p = engine.runner.n_decode_tokens, engine.runner.n_prefill_tokens
 
             def __exit__(s, *a):
                 dev_sync()
                 dt = time.perf_counter() - s.t
                 phase[name] = phase.get(name, 0.0) + dt
-                if args.profile_phases:
+                if args.profile_phases and engine is not None:
                     trace.append((name, round(dt, 3), engine.runner.n_decode_tokens - s.d,
                                   engine.runner.n_prefill_tokens - s.p))
         return _T()
@@ -223,11 +412,7 @@ def main():
             stats = actor.ppo_update(batch)
             actor.step_lr_scheduler()
         with timed("update_weights"):
-            rollout.pause()
-            actor.upload_weights(meta)
-            actor.set_version(step + 1)
-            rollout.set_version(step + 1)
-            rollout.resume()
+            push_weights(step + 1)
         stats_tracker.export_all(reduce_group=actor.data_parallel_group)
         return stats
 
@@ -258,14 +443,21 @@ def main():
         mean_len = all_tok / max(1.0, samples)
         tok_s = all_tok / elapsed
         per_gpu = BASELINE_TOK_S_PER_GPU.get(args.model)
-        baseline_tok_s = per_gpu * world if per_gpu else None
+        baseline_tok_s = per_gpu * args.gpus if per_gpu else None
         label = MODEL_LABEL.get(args.model, args.model)
+        server_stats = None
+        if decoupled:
+            store.set("bench_done", "1")
+            server_stats = [json.loads(store.get(f"server_stats_{i}").decode()) for i in range(n_gen)]
+        layout = (f"decoupled: {n_gen} rollout server rank(s) + dp{world} trainer" + (" sharing ONE GPU" if args.share_gpu else "")
+                  if decoupled else f"dp{world} colocated rollout+train")
         out = {
             "metric": f"RL samples/sec (whole node), {label} GRPO end-to-end (rollout + train + weight update)",
-            "value": round(value, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 4), "unit": "samples/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(tok_s / baseline_tok_s, 4) if baseline_tok_s else None, "dtype": "bf16",
+            # the reference publishes no samples/s figure for this configuration (nor any MI355X number)
+            "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic prompts, random-init weights",
             "gen_tokens_per_s": round(gen_tok / elapsed, 1), "e2e_tokens_per_s": round(tok_s, 1),
             "mean_seq_len": round(mean_len, 1), "mean_gen_len": round(gen_tok / max(1.0, samples), 1),
@@ -273,12 +465,16 @@ def main():
             "grad_norm_last": stats[-1].get("grad_norm"),
             "mean_token_staleness_rank0": round(tot.get("stale_sum", 0.0) / args.steps, 3),
             "pipeline_prime_steps": prime,
-            "baseline_note": "vs_baseline = end-to-end tokens/s over the reference's published per-GPU figure x n_gpus "
-                             "(1.5B: 20k tok/s on one 8xH800 node, 7B: 26k tok/s on 32 H800; blog/AReaL_v0_2.md:54); "
-                             "it publishes no samples/s number",
+            "mode": args.mode, "weight_update": wu,
+            "rollout_servers": server_stats,
+            "other_hardware_context": {
+                "note": "NOT the same configuration: the reference's closest published figure is end-to-end tokens/s "
+                        "of synchronous long-generation RL (1.5B: ~20k tok/s on one 8xH800 node, 7B: ~26k tok/s on "
+                        "32 H800; blog/AReaL_v0_2.md:54); scaled per GPU for orientation only",
+                "e2e_tokens_per_s_over_that_figure_per_gpu": round(tok_s / baseline_tok_s, 3) if baseline_tok_s else None},
             "config": {"model": f"{label} (random init)", "global_batch": int(args.prompts_per_gpu * world),
                        "n_samples": args.n_samples, "seq_len": args.prompt_len_max + args.max_new_tokens,
-                       "max_new_tokens": args.max_new_tokens, "parallelism": f"dp{world} colocated rollout+train",
+                       "max_new_tokens": args.max_new_tokens, "parallelism": layout,
                        "async_training": args.eta > 0, "max_head_offpolicyness": args.eta,
                        "interrupt_on_weight_update": "retain-kv" if args.retain_kv else "abort+recompute",
                        "algo": "GRPO, decoupled PPO loss, recompute_logprob, ppo_n_minibatches=1"
@@ -294,7 +490,10 @@ def main():
             for row in trace:
                 print("phase %-15s %7.3fs  decoded %7d  prefilled %7d" % row, file=sys.stderr)
     rollout.destroy()
-    engine.destroy()
+    if engine is not None:
+        engine.destroy()
+    if getattr(actor, "_ipc_export", None) is not None:
+        actor._ipc_export.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

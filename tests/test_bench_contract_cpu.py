@@ -21,17 +21,18 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("n", [1, 4])
-def test_bench_prints_one_json_line(n):
+@pytest.mark.parametrize("n,mode", [(1, "colocated"), (4, "colocated"), (2, "decoupled"), (4, "decoupled"),
+                                    (8, "decoupled")])
+def test_bench_prints_one_json_line(n, mode):
     env = dict(os.environ, AREAL_PLATFORM="cpu", OMP_NUM_THREADS="1")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AREAL_LLM_SERVER_ADDRS"):
         env.pop(k, None)
     if n == 1:
         cmd = [sys.executable, "bench.py", *ARGS]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), *ARGS]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), "--mode", mode, *ARGS]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout
@@ -40,6 +41,20 @@ def test_bench_prints_one_json_line(n):
                 "vs_baseline", "dtype", "data", "config"):
         assert key in out, key
     assert out["n_gpus"] == n and out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
-    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 3 * n
-    # whole-job aggregate: samples per step = prompts x samples x ranks
-    assert out["value"] == pytest.approx(3 * 2 * n / (out["ms_per_step"] / 1000.0), rel=0.02)
+    n_train = n if mode == "colocated" else n // 2
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 3 * n_train
+    assert out["vs_baseline"] is None  # the reference publishes no number for this metric / configuration
+    # whole-job aggregate: samples per step = prompts x samples x trainer ranks
+    assert out["value"] == pytest.approx(3 * 2 * n_train / (out["ms_per_step"] / 1000.0), rel=0.02)
+    if mode == "decoupled":
+        assert out["weight_update"]["transport"] == "ipc" and out["weight_update"]["fallback"] is None
+        assert len(out["rollout_servers"]) == n // 2 and all(sv["gen_tokens"] > 0 for sv in out["rollout_servers"])
+
+
+def test_decoupled_mode_refuses_an_odd_rank_count():
+    env = dict(os.environ, AREAL_PLATFORM="cpu", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--mode", "decoupled", *ARGS], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "even --gpus" in p.stderr
