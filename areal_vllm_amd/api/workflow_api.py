@@ -1,25 +1,29 @@
-"""Rollout workflow interface and the asynchronous rollout executor with staleness control.
+"""Rollout workflows and the asynchronous executor that runs them under staleness control.
 
-Semantics follow ``areal/api/workflow_api.py:31-323`` in the reference:
+Contract (what trainers and engines rely on; same as ``areal/api/workflow_api.py:31-323`` of the reference):
 
-* ``capacity = min(max(1, max_concurrent_rollouts // dp) - running,
-                   (eta + version + 1) * max(1, consumer_batch_size // dp) - (accepted + running))``
-* ``wait`` pops finished trajectories, rejected ones release their slot, accepted ones are returned oldest
-  first (then shuffled) and concatenated; ``prepare_batch`` keeps at least one extra batch in flight.
+* ``RolloutWorkflow.arun_episode(engine, data)`` produces one trajectory batch (or ``None`` to drop it).
+* At most ``max_concurrent_rollouts // dp`` episodes run at once, and the number of trajectories that exist
+  (running + finished and not rejected) never exceeds ``(eta + version + 1) * (consumer_batch_size // dp)``:
+  with ``eta = max_head_offpolicyness`` no sample is more than ``eta`` weight versions old when it is trained on.
+* ``wait(count)`` hands out the ``count`` OLDEST accepted trajectories (in shuffled order) as one padded batch;
+  a trajectory that ``should_accept`` refuses gives its slot back. ``prepare_batch`` keeps the pipeline fed from
+  a dataloader, ``rollout_batch`` is the synchronous submit-all / wait-all form, ``pause`` stops NEW episodes.
 
-The executor is event-driven (the reference sleeps one second per loop iteration): the rollout thread
-blocks on ``asyncio.wait`` with a short timeout only while tasks are in flight, is woken by submissions,
-and results are handed to ``wait`` through a condition variable.
+Design: nothing polls. One thread owns an asyncio loop; every change that can open capacity (a submission, an
+episode ending, a rejection, ``resume``, a version bump) schedules ``_admit`` on that loop, which starts as many
+queued episodes as the two limits allow. Each episode task carries a done-callback that books the result and
+notifies the condition variable ``wait`` sleeps on. The reference loops with fixed sleeps instead
+(``workflow_api.py:122-210``).
 """
 import asyncio
+import collections
 import itertools
-import queue
 import random
 import threading
 import time
 import traceback
-from dataclasses import dataclass
-from typing import TYPE_CHECKING, Any, Callable, Dict, List, Optional
+from typing import TYPE_CHECKING, Any, Callable, Deque, Dict, List, Optional, Tuple
 
 import torch.distributed as dist
 
@@ -31,18 +35,6 @@ from .io_struct import RolloutStat
 if TYPE_CHECKING:
     from .engine_api import InferenceEngine
 
-ROLLOUT_POLL_WAIT_TIME = 0.05
-
-
-def _as_batch(traj):
-    """Episodes may return {completion_id: CompletionWithTokenLogpReward} (OpenAI-style agent
-    workflows): flatten them into one padded batch, one row per stored completion."""
-    if isinstance(traj, dict) and traj and all(hasattr(v, "to_tensor_dict") for v in traj.values()):
-        from ..utils.data import concat_padded_tensors
-
-        return concat_padded_tensors([v.to_tensor_dict() for v in traj.values()])
-    return traj
-
 
 class RolloutWorkflow:
     async def arun_episode(self, engine: "InferenceEngine", data: Dict[str, Any]) -> Optional[Dict[str, Any]]:
@@ -50,169 +42,184 @@ class RolloutWorkflow:
         raise NotImplementedError()
 
 
-@dataclass
-class _TimedResult:
-    t: int
-    data: Optional[Dict[str, Any]]
+def _to_padded_batch(result):
+    """Agent-style workflows return {completion_id: completion-with-reward}: one padded row per completion."""
+    if isinstance(result, dict) and result and all(hasattr(v, "to_tensor_dict") for v in result.values()):
+        return concat_padded_tensors([v.to_tensor_dict() for v in result.values()])
+    return result
 
 
 class WorkflowExecutor:
     def __init__(self, config: InferenceEngineConfig, inference_engine: "InferenceEngine"):
         config.max_concurrent_rollouts = config.max_concurrent_rollouts or config.consumer_batch_size
         self.config = config
-        self.exiting = threading.Event()
-        self.paused = threading.Event()
-        self.lock = threading.Lock()
         self.inference_engine = inference_engine
-        qsize = config.queue_size or config.max_concurrent_rollouts * 16
-        self.input_queue: "queue.Queue" = queue.Queue(maxsize=qsize)
-        self.output_queue: "queue.Queue" = queue.Queue(maxsize=qsize)
-        self.result_cache: List[_TimedResult] = []
+        self.paused = threading.Event()  # read by the engines' generate loops as well
+        self.exiting = threading.Event()
         self.rollout_stat = RolloutStat()
-        self._out_cv = threading.Condition()
-        self._wake = threading.Event()
-        self.rollout_tasks: Dict[str, asyncio.Task] = {}
-        self.rollout_thread: Optional[threading.Thread] = None
         self.dp_world_size = 1
+        self._limit = config.queue_size or config.max_concurrent_rollouts * 16
+        self._mutex = threading.Lock()  # guards the counters and both containers below
+        self._backlog: Deque[Tuple[Dict[str, Any], RolloutWorkflow]] = collections.deque()
+        self._finished: List[Tuple[int, Optional[Dict[str, Any]]]] = []  # (start time, trajectory)
+        self._ready = threading.Condition(self._mutex)  # signalled whenever `_finished` grows
+        self._kept: List[Tuple[int, Dict[str, Any]]] = []  # accepted, not yet handed out (consumer side only)
+        self._loop: Optional[asyncio.AbstractEventLoop] = None
+        self._thread: Optional[threading.Thread] = None
+        self._started = threading.Event()
+        self._live: Dict[int, asyncio.Task] = {}
+        self._serial = itertools.count()
+        self._feed = None
 
+    # ------------------------------------------------------------------------------ life cycle
     def initialize(self, logger=None, train_data_parallel_size: Optional[int] = None):
         self.logger = logger or logging.getLogger("WorkflowExecutor")
         if train_data_parallel_size is not None:
             self.dp_world_size = train_data_parallel_size
-        elif dist.is_initialized():
-            self.dp_world_size = dist.get_world_size()
         else:
-            self.dp_world_size = 1
-        self.rollout_thread = threading.Thread(target=self._rollout_thread, daemon=True)
-        self.rollout_thread.start()
+            self.dp_world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self._thread = threading.Thread(target=self._serve, daemon=True, name="rollout-executor")
+        self._thread.start()
+        self._started.wait()
 
-    def destroy(self):
-        self.exiting.set()
-        self._wake.set()
-        if self.rollout_thread is not None:
-            self.rollout_thread.join(timeout=10)
-
-    # ------------------------------------------------------------------ staleness control
-    def get_capacity(self) -> int:
-        with self.lock:
-            max_concurrent = max(1, self.config.max_concurrent_rollouts // self.dp_world_size)
-            capacity = max_concurrent - len(self.rollout_tasks)
-            version = self.inference_engine.get_version()
-            ofp = self.config.max_head_offpolicyness
-            sample_cnt = self.rollout_stat.accepted + self.rollout_stat.running
-            consumer_bs = max(1, self.config.consumer_batch_size // self.dp_world_size)
-            capacity = min(capacity, (ofp + version + 1) * consumer_bs - sample_cnt)
-        return capacity
-
-    # ------------------------------------------------------------------ rollout thread
-    def _rollout_thread(self):
+    def _serve(self):
+        self._loop = asyncio.new_event_loop()
+        asyncio.set_event_loop(self._loop)
+        self._started.set()
         try:
-            asyncio.run(self._rollout_thread_async())
-        except Exception:
-            traceback.print_exc()
-
-    async def _rollout_thread_async(self):
-        rollout_tasks = self.rollout_tasks
-        create_time: Dict[str, int] = {}
-        rid = 0
-        try:
-            while not self.exiting.is_set():
-                capacity = self.get_capacity()
-                with self.lock:
-                    while capacity > 0 and not self.paused.is_set() and self.input_queue.qsize() > 0:
-                        data, workflow = self.input_queue.get_nowait()
-                        task = asyncio.create_task(workflow.arun_episode(self.inference_engine, data), name=str(rid))
-                        rollout_tasks[str(rid)] = task
-                        create_time[str(rid)] = time.monotonic_ns()
-                        self.rollout_stat.submitted += 1
-                        self.rollout_stat.running += 1
-                        if self.config.enable_rollout_tracing:
-                            self.logger.info(f"Submit rollout rid {rid}. Submit: {self.rollout_stat.submitted}, "
-                                             f"running: {self.rollout_stat.running}, "
-                                             f"accepted: {self.rollout_stat.accepted}.")
-                        capacity -= 1
-                        rid += 1
-                    tasks = list(rollout_tasks.values())
-                done = []
-                if tasks:
-                    done, _ = await asyncio.wait(tasks, timeout=ROLLOUT_POLL_WAIT_TIME,
-                                                 return_when=asyncio.FIRST_COMPLETED)
-                else:
-                    # idle: sleep until a submission / resume / version bump wakes us (bounded)
-                    self._wake.clear()
-                    await asyncio.get_running_loop().run_in_executor(None, self._wake.wait, ROLLOUT_POLL_WAIT_TIME)
-                for task in done:
-                    try:
-                        traj = _as_batch(await task)
-                    except Exception:
-                        traceback.print_exc()
-                        traj = None
-                    task_rid = task.get_name()
-                    with self.lock:
-                        rollout_tasks.pop(task_rid)
-                        ct = create_time.pop(task_rid)
-                        self.rollout_stat.accepted += 1
-                        self.rollout_stat.running -= 1
-                        if self.config.enable_rollout_tracing:
-                            self.logger.info(f"Finish rollout {task_rid}. Submit: {self.rollout_stat.submitted}, "
-                                             f"running: {self.rollout_stat.running}, "
-                                             f"accepted: {self.rollout_stat.accepted}.")
-                    try:
-                        self.output_queue.put_nowait(_TimedResult(ct, traj))
-                    except queue.Full:
-                        raise RuntimeError("Output queue full. Please increase queue_size.")
-                    with self._out_cv:
-                        self._out_cv.notify_all()
+            self._loop.run_forever()
+            pending = [t for t in self._live.values() if not t.done()]
+            for t in pending:
+                t.cancel()
+            if pending:
+                self._loop.run_until_complete(asyncio.gather(*pending, return_exceptions=True))
         except Exception:
             traceback.print_exc()
         finally:
-            for task in list(rollout_tasks.values()):
-                if not task.done():
-                    task.cancel()
-                    try:
-                        await task
-                    except (asyncio.CancelledError, Exception):
-                        pass
+            self._loop.close()
 
-    # ------------------------------------------------------------------ public API
+    def destroy(self):
+        self.exiting.set()
+        with self._ready:
+            self._ready.notify_all()
+        if self._loop is not None and self._thread is not None and self._thread.is_alive():
+            self._loop.call_soon_threadsafe(self._loop.stop)
+            self._thread.join(timeout=10)
+
+    def _poke(self):
+        """Ask the loop thread to re-evaluate admission (safe from any thread)."""
+        if self._loop is not None and not self.exiting.is_set():
+            try:
+                self._loop.call_soon_threadsafe(self._admit)
+            except RuntimeError:  # loop already closed
+                pass
+
+    # ------------------------------------------------------------------------ staleness control
+    def _room(self) -> int:
+        """Episodes that may start now. Caller holds `_mutex`."""
+        dp = self.dp_world_size
+        by_concurrency = max(1, self.config.max_concurrent_rollouts // dp) - len(self._live)
+        per_version = max(1, self.config.consumer_batch_size // dp)
+        allowed = (self.config.max_head_offpolicyness + self.inference_engine.get_version() + 1) * per_version
+        by_staleness = allowed - (self.rollout_stat.accepted + self.rollout_stat.running)
+        return min(by_concurrency, by_staleness)
+
+    def get_capacity(self) -> int:
+        with self._mutex:
+            return self._room()
+
+    # ------------------------------------------------------------------- loop-thread callbacks
+    def _admit(self):
+        if self.exiting.is_set() or self.paused.is_set():
+            return
+        started = []
+        with self._mutex:
+            room = self._room()
+            while room > 0 and self._backlog:
+                data, workflow = self._backlog.popleft()
+                sid = next(self._serial)
+                task = self._loop.create_task(workflow.arun_episode(self.inference_engine, data), name=f"episode-{sid}")
+                self._live[sid] = task
+                self.rollout_stat.submitted += 1
+                self.rollout_stat.running += 1
+                room -= 1
+                started.append((sid, task))
+        for sid, task in started:
+            t_start = time.monotonic_ns()
+            task.add_done_callback(lambda t, sid=sid, t_start=t_start: self._episode_ended(sid, t_start, t))
+            if self.config.enable_rollout_tracing:
+                self.logger.info(f"episode {sid} started ({self._stat_line()})")
+
+    def _episode_ended(self, sid: int, t_start: int, task: asyncio.Task):
+        traj = None
+        if not task.cancelled():
+            err = task.exception()
+            if err is None:
+                try:
+                    traj = _to_padded_batch(task.result())
+                except Exception:
+                    traceback.print_exc()
+            else:
+                traceback.print_exception(type(err), err, err.__traceback__)
+        with self._ready:
+            self._live.pop(sid, None)
+            self.rollout_stat.running -= 1
+            self.rollout_stat.accepted += 1  # provisional: `wait` takes it back if the trajectory is refused
+            if len(self._finished) >= self._limit:
+                self.exiting.set()
+                self._ready.notify_all()
+                raise RuntimeError("Output queue full. Please increase queue_size.")
+            self._finished.append((t_start, traj))
+            self._ready.notify_all()
+        if self.config.enable_rollout_tracing:
+            self.logger.info(f"episode {sid} finished ({self._stat_line()})")
+        self._admit()
+
+    def _stat_line(self) -> str:
+        s = self.rollout_stat
+        return f"submitted {s.submitted}, running {s.running}, accepted {s.accepted}"
+
+    # ------------------------------------------------------------------------------- public API
     def submit(self, data: Dict[str, Any], workflow: Optional[RolloutWorkflow] = None,
                workflow_builder: Optional[Callable] = None) -> None:
-        try:
-            if workflow is None:
-                workflow = workflow_builder()
-            self.input_queue.put_nowait((data, workflow))
-            self._wake.set()
-        except queue.Full:
-            raise RuntimeError("Input queue full. Please increase queue_size.")
+        if workflow is None:
+            workflow = workflow_builder()
+        with self._mutex:
+            if len(self._backlog) >= self._limit:
+                raise RuntimeError("Input queue full. Please increase queue_size.")
+            self._backlog.append((data, workflow))
+        self._poke()
 
     def wait(self, count: int, timeout: Optional[float] = None, should_accept: Optional[Callable] = None):
-        tik = time.perf_counter()
-        timeout = timeout or float(7 * 24 * 3600)
-        while not self.exiting.is_set() and time.perf_counter() - tik < timeout:
-            while True:
-                try:
-                    r = self.output_queue.get_nowait()
-                except queue.Empty:
-                    break
-                if r.data is not None and (should_accept is None or should_accept(r.data)):
-                    self.result_cache.append(r)
+        deadline = time.monotonic() + (timeout if timeout else 7 * 24 * 3600.0)
+        while True:
+            with self._ready:
+                fresh, self._finished = self._finished, []
+            refused = 0
+            for t_start, traj in fresh:
+                if traj is not None and (should_accept is None or should_accept(traj)):
+                    self._kept.append((t_start, traj))
                 else:
-                    with self.lock:
-                        self.rollout_stat.accepted -= 1
-                    self._wake.set()
-            if len(self.result_cache) >= count:
+                    refused += 1
+            if refused:
+                with self._mutex:
+                    self.rollout_stat.accepted -= refused
+                self._poke()
+            if len(self._kept) >= count:
                 break
-            with self._out_cv:
-                remaining = timeout - (time.perf_counter() - tik)
-                self._out_cv.wait(timeout=max(0.0, min(ROLLOUT_POLL_WAIT_TIME, remaining)))
-        if self.exiting.is_set():
-            raise RuntimeError("Rollout engine is exiting, cannot wait for results.")
-        if len(self.result_cache) < count:
-            raise TimeoutError(f"Timed out waiting for {count} rollouts, only received {len(self.result_cache)}.")
-        self.result_cache.sort(key=lambda x: x.t)
-        results, self.result_cache = self.result_cache[:count], self.result_cache[count:]
-        random.shuffle(results)
-        return concat_padded_tensors([r.data for r in results])
+            with self._ready:
+                if self.exiting.is_set():
+                    raise RuntimeError("Rollout engine is exiting, cannot wait for results.")
+                if not self._finished:
+                    left = deadline - time.monotonic()
+                    if left <= 0 or not self._ready.wait(timeout=left):
+                        if not self._finished:
+                            raise TimeoutError(
+                                f"Timed out waiting for {count} rollouts, only received {len(self._kept)}.")
+        self._kept.sort(key=lambda item: item[0])
+        picked, self._kept = self._kept[:count], self._kept[count:]
+        random.shuffle(picked)
+        return concat_padded_tensors([traj for _, traj in picked])
 
     def rollout_batch(self, data: List[Dict[str, Any]], workflow: Optional[RolloutWorkflow] = None,
                       workflow_builder: Optional[Callable] = None, should_accept: Optional[Callable] = None):
@@ -222,26 +229,30 @@ class WorkflowExecutor:
 
     def prepare_batch(self, dataloader, workflow: Optional[RolloutWorkflow] = None,
                       workflow_builder: Optional[Callable] = None, should_accept: Optional[Callable] = None):
-        if not hasattr(self, "data_generator"):
-            self.data_generator = itertools.cycle(dataloader)
+        """One training batch; before waiting, another dataloader batch is queued whenever the limits would let
+        part of it start and the backlog has room, so generation never idles behind the trainer."""
+        if self._feed is None:
+            self._feed = itertools.cycle(dataloader)
         bs = dataloader.batch_size
         assert bs is not None
         while True:
-            if self.get_capacity() + bs > 0 and self.input_queue.qsize() + bs < self.input_queue.maxsize:
-                for item in next(self.data_generator):
+            with self._mutex:
+                refill = self._room() + bs > 0 and len(self._backlog) + bs < self._limit
+            if refill:
+                for item in next(self._feed):
                     self.submit(item, workflow=workflow, workflow_builder=workflow_builder)
             try:
                 return self.wait(bs, timeout=1, should_accept=should_accept)
             except TimeoutError:
-                pass
+                continue
 
     def pause(self):
         self.paused.set()
 
     def resume(self):
         self.paused.clear()
-        self._wake.set()
+        self._poke()
 
     def notify_version_changed(self):
-        """Wake the rollout thread after a weight-version bump (capacity may have grown)."""
-        self._wake.set()
+        """A weight-version bump raises the staleness allowance: re-evaluate admission."""
+        self._poke()

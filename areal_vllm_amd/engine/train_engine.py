@@ -771,9 +771,9 @@ class NativeTrainEngine(TrainEngine):
         return dict(ipc_buffers=descs, ipc_layout=flat_layout_fingerprint(self.model), ipc_used_bytes=int(used))
 
     def _upload_ipc(self, meta: WeightUpdateMeta):
-        """Peers pull; this side only has to make the buffer final (finish the optimizer step's stream work,
-        rewrite the host mirror on the CPU platform) and say so: rank 0 posts the update key the client side
-        waits for once every rank is ready."""
+        """Peers pull; this side takes a snapshot of the flat buffer into the exported area (after the optimizer
+        step's stream work; the trainer may then go on while the servers read) and says so: rank 0 posts the
+        update key the client side waits for once every rank is ready."""
         self._ipc_export.refresh()
         if dist.is_initialized():
             dist.barrier(group=self.grid.group("world"))

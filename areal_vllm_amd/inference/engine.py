@@ -199,6 +199,7 @@ class NativeInferenceEngine:
         try:
             while not self._stop.is_set():
                 self._drain_control()
+                self._poll_pull()
                 self._drain_requests()
                 if self._paused or not self.sched.has_work():
                     self._deliver()
@@ -490,54 +491,76 @@ class NativeInferenceEngine:
     # ------------------------------------------------------------ weight updates from peer memory
     def update_weights_from_ipc(self, buffer: Dict[str, Any], layout: str, used_bytes: int,
                                 version: Optional[int] = None, abort_running: bool = True) -> Dict[str, float]:
-        """Pull the trainer's flat parameter buffer out of its (exported) memory.
+        """Pull the trainer's flat parameter buffer out of its exported snapshot.
 
-        Phase 1 runs on the CALLER's thread while the engine loop keeps decoding: a device-to-device copy on a
-        side stream from the peer mapping into a staging buffer (xGMI between two GPUs, a local copy when
-        trainer and server share one). Phase 2 runs between two engine steps: running requests are aborted
-        (their KV cache belongs to the old weights; the client re-issues them), staging -> live parameters
-        (an on-device copy, ~1.5 ms for a 1.5B model), prefix cache flushed, version bumped. Returns timings."""
+        All device work is issued by the engine's loop thread. Phase 1: between two engine steps the loop maps
+        the snapshot (first time) and starts a device-to-device copy into a staging buffer on a side stream
+        (xGMI between two GPUs, a local copy when trainer and server share one) - decoding goes on while it
+        runs. Phase 2: the loop polls the copy's event between steps; once it has fired, running requests are
+        aborted (their KV cache belongs to the old weights; the client re-issues them), staging -> live
+        parameters (an on-device copy, ~2 ms for a 1.5B model), prefix cache flushed, version bumped.
+        Blocks the caller until the flip is done; returns timings."""
         from ..engine.train_engine import flat_layout_fingerprint
-        from ..ops import ipc
 
         assert self.tp_size == 1, "the flat-buffer pull needs identical layouts; tensor-parallel servers load by name"
-        mine = flat_layout_fingerprint(self.model)
-        if layout and layout != mine:
+        if layout and layout != flat_layout_fingerprint(self.model):
             raise ValueError("the trainer's flat parameter layout differs from this server's (model config, dtype "
                              "or tied-embedding setting)")
         flat = self.model.flat.flat
         n = int(used_bytes) or min(int(buffer["nbytes"]), flat.numel() * flat.element_size())
         assert n <= flat.numel() * flat.element_size(), "trainer buffer holds more parameters than this model"
-        key = buffer.get("handle") or buffer.get("name")
-        peers = self.__dict__.setdefault("_ipc_peers", {})
+        done: "queue.Queue" = queue.Queue()
         t0 = time.perf_counter()
-        if key not in peers:
-            peers[key] = ipc.PeerBuffer(buffer)
-        if getattr(self, "_ipc_staging", None) is None:
-            self._ipc_staging = torch.empty_like(flat)
-        cuda = self.device.type == "cuda"
-        if cuda:
-            torch.cuda.set_device(self.device)
-            if self._copy_stream is None:
-                self._copy_stream = torch.cuda.Stream(device=self.device)
-            with torch.cuda.stream(self._copy_stream):
-                peers[key].copy_into(self._ipc_staging, n)
-            self._copy_stream.synchronize()
-        else:
-            peers[key].copy_into(self._ipc_staging, n)
-        t1 = time.perf_counter()
 
-        def flip():
-            if abort_running:
+        def start():
+            from ..ops import ipc
+
+            peers = self.__dict__.setdefault("_ipc_peers", {})
+            if buffer["key"] not in peers:
+                peers[buffer["key"]] = ipc.PeerBuffer(buffer)
+            if getattr(self, "_ipc_staging", None) is None:
+                self._ipc_staging = torch.empty_like(flat)
+            event = None
+            if self.device.type == "cuda":
+                if self._copy_stream is None:
+                    self._copy_stream = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(self._copy_stream):
+                    peers[buffer["key"]].copy_into(self._ipc_staging, n)
+                    event = torch.cuda.Event()
+                    event.record(self._copy_stream)
+            else:
+                peers[buffer["key"]].copy_into(self._ipc_staging, n)
+            self._pending_pull = dict(event=event, n=n, version=version, abort=abort_running, done=done, t0=t0,
+                                      t_issue=time.perf_counter())
+
+        self._control(start)
+        ok, info = done.get(timeout=600)
+        if not ok:
+            raise info
+        return info
+
+    def _poll_pull(self):
+        """Loop thread, between steps: finish a peer-memory weight pull whose copy has completed."""
+        p = getattr(self, "_pending_pull", None)
+        if p is None or (p["event"] is not None and not p["event"].query()):
+            return
+        self._pending_pull = None
+        try:
+            t1 = time.perf_counter()
+            if p["abort"]:
                 self.sched.abort_all()
                 self._deliver()
+            flat, n = self.model.flat.flat, p["n"]
             flat.view(torch.uint8).view(-1)[:n].copy_(self._ipc_staging.view(torch.uint8).view(-1)[:n])
-            if cuda:
+            if self.device.type == "cuda":
                 torch.cuda.current_stream().synchronize()
-            self._after_weight_change(version)
-        self._control(flip)
-        t2 = time.perf_counter()
-        return dict(pull_ms=(t1 - t0) * 1e3, flip_ms=(t2 - t1) * 1e3, bytes=float(n))
+            self._after_weight_change(p["version"])
+            t2 = time.perf_counter()
+            p["done"].put((True, dict(pull_ms=(t1 - p["t_issue"]) * 1e3, flip_ms=(t2 - t1) * 1e3,
+                                      total_ms=(t2 - p["t0"]) * 1e3, bytes=float(n))))
+        except Exception as e:  # surfaced to the caller
+            traceback.print_exc()
+            p["done"].put((False, e))
 
     # ------------------------------------------------------- weight updates over a collective
     def _join_update_group(self, body: Dict[str, Any]):

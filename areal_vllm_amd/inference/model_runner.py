@@ -343,6 +343,7 @@ class ModelRunner:
         if not self.use_graph:
             self.graphs[key] = None
             return None, st
+        logger.info(f"capturing decode graph: batch bucket {Bp}, filtered={filtered}")
         # warm up eagerly on a side stream (allocator + hipBLASLt workspaces), then capture
         saved = {k: st[k].clone() for k in ("input_ids", "positions", "context_lens", "slots")}
         step_saved = self.step_counter.clone()

@@ -19,35 +19,62 @@ import torch
 from . import _lib as L
 
 
+CHUNK_BYTES = 1 << 30  # exported pieces stay well below 2 GiB: mapping a larger allocation hangs (see ipc.hip)
+
+
 class ExportedBuffer:
-    """Exporter side. Keep it alive as long as peers may read."""
+    """Exporter side: a SNAPSHOT area other processes can map, refreshed from the tensor on demand.
+
+    Device tensors: the snapshot is a list of dedicated device allocations of at most `CHUNK_BYTES` each
+    (allocated outside the framework's caching allocator so that a handle never names a multi-GiB segment);
+    ``refresh()`` copies the tensor into them on the current stream (an on-device copy, ~1.4 TB/s) and waits.
+    Peers then read a consistent image while the owner goes on mutating the tensor. Host tensors: the
+    snapshot is one POSIX shared-memory segment. Keep the object alive as long as peers may read."""
 
     def __init__(self, t: torch.Tensor):
         assert t.is_contiguous()
         self.tensor = t
         self.nbytes = t.numel() * t.element_size()
         self._shm: Optional[shared_memory.SharedMemory] = None
+        self._chunks = []  # (device pointer, nbytes)
         if t.is_cuda:
-            L.lib()
-            handle = (ctypes.c_ubyte * 64)()
-            off, size = ctypes.c_long(0), ctypes.c_long(0)
-            L.check(L.lib().areal_ipc_export(L.ptr(t), handle, ctypes.byref(off), ctypes.byref(size)), "ipc_export")
-            self.desc: Dict[str, Any] = dict(kind="hip", handle=bytes(handle).hex(), offset=int(off.value),
-                                             nbytes=self.nbytes, device=int(t.device.index or 0))
+            lib = L.lib()
+            pieces = []
+            for lo in range(0, self.nbytes, CHUNK_BYTES):
+                n = min(CHUNK_BYTES, self.nbytes - lo)
+                p = ctypes.c_void_p(0)
+                L.check(lib.areal_ipc_alloc(ctypes.c_long(n), ctypes.byref(p)), "ipc_alloc")
+                handle = (ctypes.c_ubyte * 64)()
+                off, size = ctypes.c_long(0), ctypes.c_long(0)
+                L.check(lib.areal_ipc_export(p, handle, ctypes.byref(off), ctypes.byref(size)), "ipc_export")
+                assert off.value == 0 and size.value < (1 << 31)
+                self._chunks.append((p.value, n))
+                pieces.append(dict(handle=bytes(handle).hex(), nbytes=n))
+            self.desc: Dict[str, Any] = dict(kind="hip", chunks=pieces, nbytes=self.nbytes,
+                                             device=int(t.device.index or 0), key=pieces[0]["handle"] if pieces else "")
         else:
             self._shm = shared_memory.SharedMemory(create=True, size=max(1, self.nbytes))
-            self.desc = dict(kind="shm", name=self._shm.name, offset=0, nbytes=self.nbytes, device=-1)
+            self.desc = dict(kind="shm", name=self._shm.name, nbytes=self.nbytes, device=-1, key=self._shm.name)
 
     def refresh(self):
-        """Make the current contents visible to peers: device buffers are live (the caller synchronises its
-        stream), the host mirror is rewritten."""
+        """Take a new snapshot of the tensor (returns when it is complete)."""
         if self._shm is not None:
             src = self.tensor.detach().contiguous().view(torch.uint8).numpy()
             self._shm.buf[: self.nbytes] = src.tobytes()
-        elif self.tensor.is_cuda:
-            torch.cuda.current_stream(self.tensor.device).synchronize()
+            return
+        base = self.tensor.data_ptr()
+        lo = 0
+        with torch.cuda.device(self.tensor.device):
+            for p, n in self._chunks:
+                L.check(L.lib().areal_memcpy_d2d_async(ctypes.c_void_p(p), ctypes.c_void_p(base + lo), ctypes.c_long(n),
+                                                       L.stream_ptr()), "memcpy_d2d_async")
+                lo += n
+            torch.cuda.current_stream().synchronize()
 
     def close(self):
+        for p, _ in self._chunks:
+            L.lib().areal_ipc_free(ctypes.c_void_p(p))
+        self._chunks = []
         if self._shm is not None:
             try:
                 self._shm.close()
@@ -62,27 +89,26 @@ def export_buffer(t: torch.Tensor) -> ExportedBuffer:
 
 
 class PeerBuffer:
-    """Importer side: a mapping of another process's exported buffer."""
+    """Importer side: a mapping of another process's exported snapshot."""
 
     def __init__(self, desc: Dict[str, Any]):
         self.desc = dict(desc)
         self.nbytes = int(desc["nbytes"])
-        self._base = None
+        self._maps = []  # (mapped base pointer, nbytes)
         self._shm = None
         if desc["kind"] == "hip":
-            raw = bytes.fromhex(desc["handle"])
-            assert len(raw) == 64
-            handle = (ctypes.c_ubyte * 64).from_buffer_copy(raw)
-            base = ctypes.c_void_p(0)
-            L.check(L.lib().areal_ipc_open(handle, ctypes.byref(base)), "ipc_open")
-            self._base = base.value
-            self.ptr = self._base + int(desc["offset"])
+            for piece in desc["chunks"]:
+                raw = bytes.fromhex(piece["handle"])
+                assert len(raw) == 64
+                handle = (ctypes.c_ubyte * 64).from_buffer_copy(raw)
+                base = ctypes.c_void_p(0)
+                L.check(L.lib().areal_ipc_open(handle, ctypes.byref(base)), "ipc_open")
+                self._maps.append((base.value, int(piece["nbytes"])))
         else:
             self._shm = shared_memory.SharedMemory(name=desc["name"])
-            self.ptr = None
 
     def copy_into(self, dst: torch.Tensor, nbytes: Optional[int] = None):
-        """Asynchronous copy of the first `nbytes` bytes into `dst` on the current stream (device buffers);
+        """Asynchronous copy of the first `nbytes` bytes into `dst` on the current stream (device snapshots);
         a plain memcpy for the shared-memory backing."""
         n = self.nbytes if nbytes is None else int(nbytes)
         assert n <= self.nbytes and n <= dst.numel() * dst.element_size() and dst.is_contiguous()
@@ -91,13 +117,19 @@ class PeerBuffer:
             dst.view(torch.uint8).view(-1)[:n].copy_(src)
             return
         assert dst.is_cuda
-        L.check(L.lib().areal_memcpy_d2d_async(L.ptr(dst), ctypes.c_void_p(self.ptr), ctypes.c_long(n), L.stream_ptr()),
-                "memcpy_d2d_async")
+        lo = 0
+        for base, size in self._maps:
+            take = min(size, n - lo)
+            if take <= 0:
+                break
+            L.check(L.lib().areal_memcpy_d2d_async(ctypes.c_void_p(dst.data_ptr() + lo), ctypes.c_void_p(base),
+                                                   ctypes.c_long(take), L.stream_ptr()), "memcpy_d2d_async")
+            lo += take
 
     def close(self):
-        if self._base is not None:
-            L.lib().areal_ipc_close(ctypes.c_void_p(self._base))
-            self._base = None
+        for base, _ in self._maps:
+            L.lib().areal_ipc_close(ctypes.c_void_p(base))
+        self._maps = []
         if self._shm is not None:
             self._shm.close()
             self._shm = None

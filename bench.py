@@ -152,6 +152,12 @@ def serve_rollouts(args, rank, local_rank, store):
 
 def main():
     args = parse_args()
+    if os.environ.get("AREAL_BENCH_HANG_DUMP"):  # debugging aid: stack of every thread after that many seconds
+        import faulthandler
+
+        os.makedirs("gpurun_out", exist_ok=True)
+        _dump = open(f"gpurun_out/hang_dump_rank{os.environ.get('RANK', '0')}.txt", "w")
+        faulthandler.dump_traceback_later(float(os.environ["AREAL_BENCH_HANG_DUMP"]), repeat=False, file=_dump)
     # the result line is the only thing that may reach stdout: libraries (gloo's connection banner) print
     # there too, so everything before the result goes to stderr
     sys.stdout.flush()

@@ -30,6 +30,19 @@ extern "C" int areal_ipc_export(const void* ptr, unsigned char* handle_out, long
   return 0;
 }
 
+// A device allocation of its own (not carved out of a framework's caching allocator), so that the handle
+// names exactly `bytes` bytes: mapping an exported allocation of 2 GiB or more does not return on this
+// platform (ROCm 7.2, dmabuf IPC), so shipping buffers are exported in pieces below that size.
+extern "C" int areal_ipc_alloc(long bytes, void** out) {
+  IPC_RET(hipMalloc(out, (size_t)bytes));
+  return 0;
+}
+
+extern "C" int areal_ipc_free(void* p) {
+  IPC_RET(hipFree(p));
+  return 0;
+}
+
 extern "C" int areal_ipc_open(const unsigned char* handle, void** base_out) {
   hipIpcMemHandle_t h;
   memcpy(&h, handle, sizeof(h));
