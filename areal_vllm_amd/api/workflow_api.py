@@ -49,6 +49,21 @@ def _to_padded_batch(result):
     return result
 
 
+class StalenessGate:
+    """The two admission limits. `room` says how many more episodes may start given the number running now,
+    the trajectories that already count against the allowance and the current weight version."""
+
+    def __init__(self, config: InferenceEngineConfig):
+        self.config = config
+        self.dp = 1
+
+    def room(self, live: int, counted: int, version: int) -> int:
+        c = self.config
+        slots = max(1, c.max_concurrent_rollouts // self.dp) - live
+        allowance = (c.max_head_offpolicyness + version + 1) * max(1, c.consumer_batch_size // self.dp)
+        return min(slots, allowance - counted)
+
+
 class WorkflowExecutor:
     def __init__(self, config: InferenceEngineConfig, inference_engine: "InferenceEngine"):
         config.max_concurrent_rollouts = config.max_concurrent_rollouts or config.consumer_batch_size
@@ -57,7 +72,7 @@ class WorkflowExecutor:
         self.paused = threading.Event()  # read by the engines' generate loops as well
         self.exiting = threading.Event()
         self.rollout_stat = RolloutStat()
-        self.dp_world_size = 1
+        self.gate = StalenessGate(config)
         self._limit = config.queue_size or config.max_concurrent_rollouts * 16
         self._mutex = threading.Lock()  # guards the counters and both containers below
         self._backlog: Deque[Tuple[Dict[str, Any], RolloutWorkflow]] = collections.deque()
@@ -75,9 +90,9 @@ class WorkflowExecutor:
     def initialize(self, logger=None, train_data_parallel_size: Optional[int] = None):
         self.logger = logger or logging.getLogger("WorkflowExecutor")
         if train_data_parallel_size is not None:
-            self.dp_world_size = train_data_parallel_size
+            self.gate.dp = train_data_parallel_size
         else:
-            self.dp_world_size = dist.get_world_size() if dist.is_initialized() else 1
+            self.gate.dp = dist.get_world_size() if dist.is_initialized() else 1
         self._thread = threading.Thread(target=self._serve, daemon=True, name="rollout-executor")
         self._thread.start()
         self._started.wait()
@@ -117,12 +132,12 @@ class WorkflowExecutor:
     # ------------------------------------------------------------------------ staleness control
     def _room(self) -> int:
         """Episodes that may start now. Caller holds `_mutex`."""
-        dp = self.dp_world_size
-        by_concurrency = max(1, self.config.max_concurrent_rollouts // dp) - len(self._live)
-        per_version = max(1, self.config.consumer_batch_size // dp)
-        allowed = (self.config.max_head_offpolicyness + self.inference_engine.get_version() + 1) * per_version
-        by_staleness = allowed - (self.rollout_stat.accepted + self.rollout_stat.running)
-        return min(by_concurrency, by_staleness)
+        stat = self.rollout_stat
+        return self.gate.room(len(self._live), stat.accepted + stat.running, self.inference_engine.get_version())
+
+    @property
+    def dp_world_size(self) -> int:
+        return self.gate.dp
 
     def get_capacity(self) -> int:
         with self._mutex:

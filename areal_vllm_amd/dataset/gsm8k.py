@@ -1,38 +1,43 @@
-"""GSM8K: SFT rows (question+answer token ids with a loss mask over the answer) and RL rows (a chat
-message asking for a boxed answer, plus the reference answer). Reference: ``areal/dataset/gsm8k.py:7-69``."""
-from typing import Optional
+"""GSM8K in the two shapes the trainers read.
+
+* supervised: one row per problem, ``input_ids`` = tokens of question + worked answer + EOS and a
+  ``loss_mask`` that is 1 exactly on the answer (and EOS) tokens;
+* RL: one row per problem with a single-turn chat ``messages`` prompt that asks for a boxed final answer;
+  the ``answer`` column stays for the reward function.
+
+Rows are sharded by data-parallel rank with `datasets`' node splitter. Role of ``areal/dataset/gsm8k.py``.
+"""
+from typing import Any, Dict, Optional
 
 from . import load_raw_dataset
 
 BOXED_SUFFIX = "\nPlease put your final answer within \\boxed{}."
 
 
-def _shard(ds, rank: int, world_size: int):
+def _finish(ds, keep_if, max_length: Optional[int], rank: int, world_size: int):
     from datasets.distributed import split_dataset_by_node
 
+    if max_length is not None:
+        ds = ds.filter(lambda row: keep_if(row) <= max_length)
     return split_dataset_by_node(ds, rank=rank, world_size=world_size)
 
 
 def get_gsm8k_sft_dataset(path: str, split: str, tokenizer, rank: int, world_size: int,
                           max_length: Optional[int] = None):
-    ds = load_raw_dataset(path, split, name="main")
+    def tokenize(row: Dict[str, Any]) -> Dict[str, Any]:
+        question = tokenizer.encode(row["question"])
+        full = tokenizer.encode(row["question"] + row["answer"] + tokenizer.eos_token)
+        n_answer = len(full) - len(question)
+        return dict(input_ids=full, loss_mask=[0] * len(question) + [1] * n_answer)
 
-    def process(sample):
-        seq = tokenizer.encode(sample["question"] + sample["answer"] + tokenizer.eos_token)
-        n_prompt = len(tokenizer.encode(sample["question"]))
-        return {"input_ids": seq, "loss_mask": [0] * n_prompt + [1] * (len(seq) - n_prompt)}
-
-    ds = ds.map(process).remove_columns(["question", "answer"])
-    if max_length is not None:
-        ds = ds.filter(lambda x: len(x["input_ids"]) <= max_length)
-    return _shard(ds, rank, world_size)
+    ds = load_raw_dataset(path, split, name="main").map(tokenize, remove_columns=["question", "answer"])
+    return _finish(ds, lambda row: len(row["input_ids"]), max_length, rank, world_size)
 
 
 def get_gsm8k_rl_dataset(path: str, split: str, tokenizer, rank: int, world_size: int,
                          max_length: Optional[int] = None):
-    ds = load_raw_dataset(path, split, name="main")
-    ds = ds.map(lambda s: {"messages": [{"role": "user", "content": s["question"] + BOXED_SUFFIX}]})
-    ds = ds.remove_columns(["question"])
-    if max_length is not None:
-        ds = ds.filter(lambda s: len(tokenizer.encode(s["messages"][0]["content"])) <= max_length)
-    return _shard(ds, rank, world_size)
+    def as_chat(row: Dict[str, Any]) -> Dict[str, Any]:
+        return dict(messages=[dict(role="user", content=row["question"] + BOXED_SUFFIX)])
+
+    ds = load_raw_dataset(path, split, name="main").map(as_chat, remove_columns=["question"])
+    return _finish(ds, lambda row: len(tokenizer.encode(row["messages"][0]["content"])), max_length, rank, world_size)

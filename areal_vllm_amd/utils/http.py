@@ -1,5 +1,11 @@
-"""Async HTTP helpers with retry (``areal/utils/http.py`` in the reference)."""
+"""HTTP client helpers for the control plane (trainer -> rollout servers, workers -> managers).
+
+``arequest_with_retry`` issues one JSON request and retries transport failures and time-outs; HTTP error
+statuses count as failures too. It opens a session of its own when the caller has none to share. Role of
+``areal/utils/http.py`` in the reference.
+"""
 import asyncio
+import contextlib
 from typing import Any, Dict, Optional
 
 import aiohttp
@@ -9,55 +15,60 @@ from . import logging
 logger = logging.getLogger("http")
 DEFAULT_RETRIES = 3
 DEFAULT_REQUEST_TIMEOUT = 3600
+_VERBS_WITH_BODY = {"POST", "PUT"}
+_VERBS = _VERBS_WITH_BODY | {"GET", "DELETE"}
+_RETRYABLE_STATUS = frozenset({408, 429, 500, 502, 503, 504})
 
 
-def get_default_connector():
+def get_default_connector() -> aiohttp.TCPConnector:
+    # unlimited connections, no keep-alive: servers restart under us during recover runs
     return aiohttp.TCPConnector(limit=0, use_dns_cache=False, force_close=True)
+
+
+@contextlib.asynccontextmanager
+async def _session_for(shared: Optional[aiohttp.ClientSession], timeout: float):
+    if shared is not None:
+        yield shared
+        return
+    async with aiohttp.ClientSession(timeout=aiohttp.ClientTimeout(total=timeout, sock_connect=timeout),
+                                     read_bufsize=10 << 20, connector=get_default_connector()) as own:
+        yield own
+
+
+async def _body(resp: aiohttp.ClientResponse) -> Any:
+    resp.raise_for_status()
+    if "json" in resp.headers.get("Content-Type", ""):
+        return await resp.json()
+    return await resp.text()
 
 
 async def arequest_with_retry(addr: str, endpoint: str, payload: Optional[Dict[str, Any]] = None,
                               session: Optional[aiohttp.ClientSession] = None, method: str = "POST",
                               max_retries: Optional[int] = None, timeout: Optional[float] = None,
                               retry_delay: float = 1.0, verbose: bool = False) -> Any:
-    timeout = timeout or DEFAULT_REQUEST_TIMEOUT
-    max_retries = max_retries or DEFAULT_RETRIES
+    verb = method.upper()
+    if verb not in _VERBS:
+        raise ValueError(f"Unsupported HTTP method: {method}")
+    budget = timeout or DEFAULT_REQUEST_TIMEOUT
+    attempts = max_retries or DEFAULT_RETRIES
     url = f"http://{addr}{endpoint}"
-    last_exc = None
-    own = session is None
-    if own:
-        session = aiohttp.ClientSession(timeout=aiohttp.ClientTimeout(total=timeout, sock_connect=timeout),
-                                        read_bufsize=1024 * 1024 * 10, connector=get_default_connector())
-    try:
-        for attempt in range(max_retries):
+    kwargs: Dict[str, Any] = dict(timeout=aiohttp.ClientTimeout(total=budget))
+    if verb in _VERBS_WITH_BODY:
+        kwargs["json"] = payload
+    failure: Optional[BaseException] = None
+    async with _session_for(session, budget) as s:
+        for n in range(1, attempts + 1):
             try:
-                ctx_timeout = aiohttp.ClientTimeout(total=timeout)
-                if method.upper() == "GET":
-                    ctx = session.get(url, timeout=ctx_timeout)
-                elif method.upper() == "POST":
-                    ctx = session.post(url, json=payload, timeout=ctx_timeout)
-                elif method.upper() == "PUT":
-                    ctx = session.put(url, json=payload, timeout=ctx_timeout)
-                elif method.upper() == "DELETE":
-                    ctx = session.delete(url, timeout=ctx_timeout)
-                else:
-                    raise ValueError(f"Unsupported HTTP method: {method}")
-                async with ctx as resp:
-                    resp.raise_for_status()
-                    ctype = resp.headers.get("Content-Type", "")
-                    if "json" in ctype:
-                        return await resp.json()
-                    return await resp.text()
+                async with s.request(verb, url, **kwargs) as resp:
+                    return await _body(resp)
             except (aiohttp.ClientError, asyncio.TimeoutError) as e:
-                last_exc = e
+                failure = e
                 if verbose:
-                    logger.warning(f"request to {url} failed ({type(e).__name__}: {e}), attempt {attempt + 1}")
-                if attempt < max_retries - 1:
-                    await asyncio.sleep(retry_delay)
-        raise RuntimeError(f"Failed after {max_retries} retries. Endpoint: {url}. Payload: "
-                           f"{str(payload)[:200]}. Last error: {repr(last_exc)}")
-    finally:
-        if own:
-            await session.close()
+                    logger.warning(f"{verb} {url}: {type(e).__name__}: {e} (attempt {n} of {attempts})")
+            if n < attempts:
+                await asyncio.sleep(retry_delay)
+    raise RuntimeError(f"Failed after {attempts} retries. Endpoint: {url}. Payload: {str(payload)[:200]}. "
+                       f"Last error: {failure!r}")
 
 
 def response_ok(http_code: int) -> bool:
@@ -65,4 +76,4 @@ def response_ok(http_code: int) -> bool:
 
 
 def response_retryable(http_code: int) -> bool:
-    return http_code in (408, 429, 500, 502, 503, 504)
+    return http_code in _RETRYABLE_STATUS
