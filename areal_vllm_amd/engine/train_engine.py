@@ -218,6 +218,7 @@ class NativeTrainEngine(TrainEngine):
             ep_size=g.ep, ep_rank=g.rank_in("ep"), ep_group=g.group("ep"),
             gradient_checkpointing=cfg.gradient_checkpointing,
             sequence_parallel=cfg.native.sequence_parallel and g.tp > 1,
+            vocab_parallel=g.tp > 1,
         )
         assert not (self.model.seq_par and g.cp > 1), "choose tensor-parallel sequence parallelism or cp, not both"
         if g.cp > 1:
@@ -277,9 +278,14 @@ class NativeTrainEngine(TrainEngine):
     def _tp_replicated_ranges(self) -> List[Tuple[int, int, int]]:
         """(lo, hi, replication) flat ranges of parameters that more than one tp rank holds."""
         rep = []
+        names = {"ln1", "ln2", "norm", "q_norm", "k_norm", "router", "ln1_bias", "ln2_bias", "norm_bias", "pos_embed",
+                 "o_bias", "proj_bias"}
+        if not self.model.vocab_parallel:
+            names |= {"embed", "head"}
+        elif self.model_config.is_critic:
+            names.add("head")  # the value head [1, H] is not a vocabulary tensor
         for n, (o, numel) in self.model.flat.offsets.items():
-            if n.split(".")[-1] in ("ln1", "ln2", "norm", "q_norm", "k_norm", "embed", "head", "router", "ln1_bias",
-                                    "ln2_bias", "norm_bias", "pos_embed", "o_bias", "proj_bias"):
+            if n.split(".")[-1] in names:
                 rep.append((o, o + numel, self.grid.tp))
         if self._kv_replication() > 1:
             rep += self._kv_ranges()

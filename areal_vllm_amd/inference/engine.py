@@ -696,8 +696,9 @@ def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]
                     gu.data[le, f:].copy_(tensors[un][tr * f:(tr + 1) * f])
                 if dnn in tensors:
                     dn.data[le].copy_(tensors[dnn][:, tr * f:(tr + 1) * f])
+    v_lo, v_hi = model.vocab_range  # the whole vocabulary unless the model shards it over tp
     if model.has_embed and "model.embed_tokens.weight" in tensors:
-        params["embed"].data.copy_(tensors["model.embed_tokens.weight"])
+        params["embed"].data.copy_(tensors["model.embed_tokens.weight"][v_lo:v_hi])
     for n in [k for k in list(given) if k.startswith("visual.")]:  # vision tower: replicated, same names
         if n in params:
             params[n].data.copy_(tensors[n])
@@ -705,9 +706,10 @@ def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]
         if "model.norm.weight" in tensors:
             params["norm"].data.copy_(tensors["model.norm.weight"])
         if "head" in params:
-            for n in ("lm_head.weight", "score.weight"):
-                if n in tensors:
-                    params["head"].data.copy_(tensors[n])
+            if "lm_head.weight" in tensors:
+                params["head"].data.copy_(tensors["lm_head.weight"][v_lo:v_hi])
+            if "score.weight" in tensors:
+                params["head"].data.copy_(tensors["score.weight"])
         elif "lm_head.weight" in tensors:  # tied head: the embedding copy above covers it
             tensors["lm_head.weight"]
     if strict and given:

@@ -111,6 +111,30 @@ def _tp_range(n: int, tp_size: int, tp_rank: int) -> Tuple[int, int]:
     return tp_rank * s, (tp_rank + 1) * s
 
 
+def _vocab_rows(model, rd: "_ShardReader", name: str) -> torch.Tensor:
+    """A [vocab, H] checkpoint tensor, or this rank's rows of it when the model shards the vocabulary."""
+    if getattr(model, "vocab_parallel", False):
+        lo, hi = model.vocab_range
+        return rd.get_rows(name, lo, hi)
+    return rd.get(name)
+
+
+def _gather_vocab(model, t: torch.Tensor, group) -> torch.Tensor:
+    """Inverse of `_vocab_rows`: the full [vocab, H] tensor from the tp ranks' row shards (the last shard
+    may be shorter, so shards travel padded to the longest)."""
+    if not getattr(model, "vocab_parallel", False) or group is None or dist.get_world_size(group) == 1:
+        return t
+    from ..ops import vocab_shard_range
+
+    n = dist.get_world_size(group)
+    rows = [hi - lo for lo, hi in (vocab_shard_range(model.cfg.vocab_size, n, i) for i in range(n))]
+    pad = max(rows) - t.shape[0]
+    padded = torch.cat([t, t.new_zeros(pad, t.shape[1])], 0) if pad else t.contiguous()
+    parts = [torch.empty_like(padded) for _ in range(n)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([p[:r] for p, r in zip(parts, rows)], 0)
+
+
 def load_hf_weights(model, path: str, strict: bool = True) -> None:
     """Fill `model` (a ``Transformer``, possibly a TP shard / pipeline stage) from a HF checkpoint."""
     cfg: ModelConfig = model.cfg
@@ -131,7 +155,7 @@ def load_hf_weights(model, path: str, strict: bool = True) -> None:
     if cfg.family == "gpt2":
         return _load_gpt2(model, rd, put)
     if model.has_embed:
-        put("embed", rd.get("model.embed_tokens.weight"))
+        put("embed", _vocab_rows(model, rd, "model.embed_tokens.weight"))
         for n in params:  # vision tower: parameter names are the checkpoint names
             if n.startswith("visual."):
                 put(n, rd.get(n))
@@ -147,9 +171,9 @@ def load_hf_weights(model, path: str, strict: bool = True) -> None:
                     if strict:
                         raise KeyError("critic checkpoint has no score/v_head weight")
             elif rd.has("lm_head.weight"):
-                put("head", rd.get("lm_head.weight"))
+                put("head", _vocab_rows(model, rd, "lm_head.weight"))
             else:  # tied checkpoint loaded into an untied stage (last pipeline stage)
-                put("head", rd.get("model.embed_tokens.weight"))
+                put("head", _vocab_rows(model, rd, "model.embed_tokens.weight"))
     lo_layer, hi_layer = model.layer_range
     hq_lo, hq_hi = _tp_range(cfg.n_q_heads, tp, tr)
     if cfg.n_kv_heads >= tp:
@@ -202,7 +226,7 @@ def _load_gpt2(model, rd: "_ShardReader", put) -> None:
     D, H = cfg.head_dim, cfg.hidden_size
     pre_hf = "transformer." if rd.has("transformer.wte.weight") or rd.has("transformer.h.0.ln_1.weight") else ""
     if model.has_embed:
-        put("embed", rd.get(pre_hf + "wte.weight"))
+        put("embed", _vocab_rows(model, rd, pre_hf + "wte.weight"))
         put("pos_embed", rd.get(pre_hf + "wpe.weight"))
     if model.has_head:
         put("norm", rd.get(pre_hf + "ln_f.weight"))
@@ -211,7 +235,7 @@ def _load_gpt2(model, rd: "_ShardReader", put) -> None:
             if cfg.is_critic:
                 put("head", rd.get("score.weight"))
             else:
-                put("head", rd.get("lm_head.weight" if rd.has("lm_head.weight") else pre_hf + "wte.weight"))
+                put("head", _vocab_rows(model, rd, "lm_head.weight" if rd.has("lm_head.weight") else pre_hf + "wte.weight"))
     q_lo, q_hi = (x * D for x in _tp_range(cfg.n_q_heads, tp, tr))
     f_lo, f_hi = _tp_range(cfg.intermediate_size, tp, tr)
     lo_layer, hi_layer = model.layer_range
@@ -234,7 +258,7 @@ def _gpt2_state(model, g) -> Iterable[Tuple[str, torch.Tensor]]:
     cfg: ModelConfig = model.cfg
     params = dict(model.named_parameters())
     if model.has_embed:
-        yield "transformer.wte.weight", params["embed"].data
+        yield "transformer.wte.weight", _gather_vocab(model, params["embed"].data, g)
         yield "transformer.wpe.weight", params["pos_embed"].data
     lo_layer, _ = model.layer_range
     for li, blk in enumerate(model.layers):
@@ -256,7 +280,10 @@ def _gpt2_state(model, g) -> Iterable[Tuple[str, torch.Tensor]]:
         yield "transformer.ln_f.bias", params["norm_bias"].data
         tied_copy = cfg.tie_word_embeddings and not cfg.is_critic and not model.has_embed
         if "head" in params and not tied_copy:
-            yield ("score.weight" if cfg.is_critic else "lm_head.weight"), params["head"].data
+            if cfg.is_critic:
+                yield "score.weight", params["head"].data
+            else:
+                yield "lm_head.weight", _gather_vocab(model, params["head"].data, g)
 
 
 # -------------------------------------------------------------------------------------- save
@@ -285,7 +312,7 @@ def native_to_hf_state(model, gather: bool = True, experts_only: bool = False) -
     D = cfg.head_dim
     params = dict(model.named_parameters())
     if model.has_embed:
-        yield "model.embed_tokens.weight", params["embed"].data
+        yield "model.embed_tokens.weight", _gather_vocab(model, params["embed"].data, g)
         # the tower is replicated over tensor-parallel ranks: every rank yields it, so parameter specs and
         # collective weight pushes agree across the tp group (checkpoint writers are tp rank 0 only)
         for n, p in params.items():
@@ -342,7 +369,10 @@ def native_to_hf_state(model, gather: bool = True, experts_only: bool = False) -
         yield "model.norm.weight", params["norm"].data
         tied_copy = cfg.tie_word_embeddings and not cfg.is_critic and not model.has_embed
         if "head" in params and not tied_copy:  # a tied LM head on the last pipeline stage is not a checkpoint tensor
-            yield ("score.weight" if cfg.is_critic else "lm_head.weight"), params["head"].data
+            if cfg.is_critic:
+                yield "score.weight", params["head"].data
+            else:
+                yield "lm_head.weight", _gather_vocab(model, params["head"].data, g)
 
 
 def save_hf_checkpoint(model, path: str, tokenizer=None, stage_tag: str = "", write: bool = True,

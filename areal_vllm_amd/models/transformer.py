@@ -307,8 +307,14 @@ class Transformer(nn.Module):
     def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cpu", tp_size: int = 1, tp_rank: int = 0,
                  tp_group=None, layer_range: Optional[Tuple[int, int]] = None, has_embed: bool = True,
                  has_head: bool = True, ep_size: int = 1, ep_rank: int = 0, ep_group=None,
-                 gradient_checkpointing: bool = False, sequence_parallel: bool = False):
+                 gradient_checkpointing: bool = False, sequence_parallel: bool = False,
+                 vocab_parallel: bool = False):
         super().__init__()
+        # vocab-parallel: the token embedding and the LM head hold only this tp rank's vocabulary rows
+        # (`vocab_range`); lookups are summed over the group and the loss merges per-shard softmax statistics
+        self.vocab_parallel = bool(vocab_parallel) and tp_size > 1
+        self.vocab_range = ops.vocab_shard_range(cfg.vocab_size, tp_size if self.vocab_parallel else 1, tp_rank)
+        v_rows = self.vocab_range[1] - self.vocab_range[0]
         # Megatron-style sequence parallelism: between the tensor-parallel regions the residual stream,
         # norms and their activations hold only T/tp tokens per rank (all-gather before a column-parallel
         # GEMM, reduce-scatter after a row-parallel one: the same bytes over xGMI as the all-reduce pair)
@@ -324,7 +330,7 @@ class Transformer(nn.Module):
         self.gradient_checkpointing = gradient_checkpointing
         self.sp = None  # Ulysses sequence-parallel context (parallel/ulysses.py)
         if has_embed:
-            self.embed = nn.Parameter(torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device))
+            self.embed = nn.Parameter(torch.empty(v_rows, cfg.hidden_size, dtype=dtype, device=device))
             if cfg.pos_embed == "learned":
                 self.pos_embed = nn.Parameter(torch.empty(cfg.max_position_embeddings, cfg.hidden_size, dtype=dtype,
                                                           device=device))
@@ -338,7 +344,7 @@ class Transformer(nn.Module):
             if cfg.is_critic:
                 self.head = nn.Parameter(torch.empty(1, cfg.hidden_size, dtype=dtype, device=device))
             elif not (cfg.tie_word_embeddings and has_embed):
-                self.head = nn.Parameter(torch.empty(cfg.vocab_size, cfg.hidden_size, dtype=dtype, device=device))
+                self.head = nn.Parameter(torch.empty(v_rows, cfg.hidden_size, dtype=dtype, device=device))
         if cfg.vision is not None and has_embed:
             from .vision import VisionConfig, VisionTower
 
@@ -393,8 +399,23 @@ class Transformer(nn.Module):
         return self.embed
 
     # --------------------------------------------------------------------------- forward
-    def embed_tokens(self, input_ids, positions=None):
-        h = ops.embedding(input_ids, self.embed)
+    def embed_tokens(self, input_ids, positions=None, scatter: bool = False):
+        """Token (+ learned position) embeddings [T, H]; with `scatter` (sequence parallelism) this rank's
+        token slice [T/tp, H]. Vocab-parallel shards look up their own rows (zero for foreign ids) and the
+        partial results are summed: an all-reduce, or a reduce-scatter when the result is token-sharded
+        anyway (reference ``realhf/impl/model/parallelism/tensor_parallel/modules.py:57-139``)."""
+        from ..parallel import tensor_parallel as tpar
+
+        if self.vocab_parallel:
+            lo, hi = self.vocab_range
+            foreign = (input_ids < lo) | (input_ids >= hi)
+            h = ops.embedding((input_ids - lo).masked_fill(foreign, 0), self.embed)
+            h = h.masked_fill(foreign.unsqueeze(-1), 0.0)
+            h = (tpar.ReduceScatterToSP if scatter else tpar.ReduceFromTP).apply(h, self.tp_group)
+        else:
+            h = ops.embedding(input_ids, self.embed)
+            if scatter:
+                h = tpar.ScatterToSP.apply(h, self.tp_group)
         if self.cfg.gemma_norm:
             h = h * math.sqrt(self.cfg.hidden_size)
         if self.cfg.pos_embed == "learned":
@@ -434,11 +455,7 @@ class Transformer(nn.Module):
                 residual_in: Optional[torch.Tensor] = None):
         """Returns the final-norm hidden states [T, H] on the last stage, else (h, residual)."""
         if self.has_embed and hidden_in is None:
-            h = self.embed_tokens(input_ids, positions)
-            if self.seq_par:
-                from ..parallel.tensor_parallel import ScatterToSP
-
-                h = ScatterToSP.apply(h, self.tp_group)
+            h = self.embed_tokens(input_ids, positions, scatter=self.seq_par)
         else:
             h = hidden_in
         residual = residual_in
@@ -462,13 +479,23 @@ class Transformer(nn.Module):
             return h, residual
         x, _ = add_norm(self.cfg, h, self.norm, getattr(self, "norm_bias", None), residual)
         if self.seq_par:  # the LM head / value head sees all tokens again
-            from ..parallel.tensor_parallel import GatherForReplicatedUse
+            from ..parallel.tensor_parallel import GatherForReplicatedUse, GatherFromSP
 
-            x = GatherForReplicatedUse.apply(x, self.tp_group)
+            # a vocab-sharded LM head returns a partial d(hidden) per rank: the gather's backward sums them
+            # (reduce-scatter); a replicated head returns the same gradient everywhere: keep the own slice
+            sharded_head = self.vocab_parallel and not self.cfg.is_critic
+            x = (GatherFromSP if sharded_head else GatherForReplicatedUse).apply(x, self.tp_group)
         return x
 
     def logits(self, hidden: torch.Tensor) -> torch.Tensor:
-        return F.linear(hidden, self.head_weight)
+        """Full-vocabulary logits [T, V] (vocab shards are all-gathered along the vocabulary)."""
+        if not self.vocab_parallel:
+            return F.linear(hidden, self.head_weight)
+        from ..parallel import tensor_parallel as tpar
+
+        if not self.seq_par:
+            hidden = tpar.CopyToTP.apply(hidden, self.tp_group)
+        return tpar.GatherVocab.apply(F.linear(hidden, self.head_weight), self.tp_group, self.cfg.vocab_size)
 
     def values(self, hidden: torch.Tensor) -> torch.Tensor:
         assert self.cfg.is_critic
@@ -476,6 +503,10 @@ class Transformer(nn.Module):
 
     def logprobs(self, hidden, labels, temperature=1.0, chunk=8192, keep_logits=True):
         """Fused LM head + log-prob + entropy; never materialises fp32 [T, V]."""
+        if self.vocab_parallel:
+            return ops.lm_head_logprobs(hidden, self.head_weight, labels, temperature, chunk, keep_logits,
+                                        vocab_start=self.vocab_range[0], group=self.tp_group,
+                                        reduce_dh=not self.seq_par)
         return ops.lm_head_logprobs(hidden, self.head_weight, labels, temperature, chunk, keep_logits)
 
     def moe_aux_loss(self):

@@ -17,7 +17,8 @@ from .logprob import (  # noqa: F401
     gather_logprobs_entropy,
     lm_head_logprobs,
     logprob_stats,
-    vocab_parallel_logprobs,
+    merge_shard_stats,
+    vocab_shard_range,
 )
 from .norm_act import RotaryTable, apply_rope, rmsnorm, rope_inplace_, swiglu  # noqa: F401
 from .optim import adam_prepare_, adamw_, scale_, sumsq_  # noqa: F401

@@ -8,7 +8,7 @@ chunk are produced by hipBLASLt, reduced by the kernel and (for training) kept i
 whose gradient kernel overwrites them in place with d(logits).
 
 Tensor-parallel vocab shards (reference: ``realhf/impl/model/parallelism/tensor_parallel/modules.py:
-1060-1177``, 3 all-reduces) exchange one [T, 4] tensor instead: see ``vocab_parallel_logprobs``.
+1060-1177``, 3 all-reduces) exchange one [4, T] tensor instead: ``lm_head_logprobs(..., vocab_start, group)``.
 """
 from typing import Optional, Tuple
 
@@ -31,15 +31,27 @@ def _stats_ref(logits, labels, inv_temp, vocab_start=0):
     return m, s, w, tgt
 
 
-def logprob_stats(logits: torch.Tensor, labels: torch.Tensor, temperature: float = 1.0, vocab_start: int = 0):
-    """Per-row (m, s, w, tgt) over this vocab shard; z = logits / temperature."""
+def logprob_stats(logits: torch.Tensor, labels: torch.Tensor, temperature: float = 1.0, vocab_start: int = 0,
+                  out: Optional[torch.Tensor] = None):
+    """Per-row (m, s, w, tgt) over this vocab shard; z = logits / temperature. `labels` are global token
+    ids: rows whose label lies outside [vocab_start, vocab_start + V) get tgt = 0. `out`: fp32 [4, T]
+    (rows may be column slices of a larger buffer) that receives the four vectors."""
     assert logits.dim() == 2
     T, V = logits.shape
     inv_temp = 1.0 / temperature
     if not L.use_hip(logits):
-        return _stats_ref(logits, labels, inv_temp, vocab_start)
+        res = _stats_ref(logits, labels, inv_temp, vocab_start)
+        if out is not None:
+            for i in range(4):
+                out[i].copy_(res[i])
+            return tuple(out[i] for i in range(4))
+        return res
     assert logits.stride(1) == 1 and labels.dtype == torch.int64
-    outs = [torch.empty(T, dtype=torch.float32, device=logits.device) for _ in range(4)]
+    if out is not None:
+        assert out.dtype == torch.float32 and out.shape == (4, T) and out.stride(1) == 1
+        outs = [out[i] for i in range(4)]
+    else:
+        outs = [torch.empty(T, dtype=torch.float32, device=logits.device) for _ in range(4)]
     L.check(
         L.lib().areal_logprob_stats(
             L.ptr(logits), L.c_int(L.dtype_flag(logits)), L.c_int64(T), L.c_int(V), L.c_int64(logits.stride(0)),
@@ -153,8 +165,54 @@ def gather_logprobs(logits: torch.Tensor, labels: torch.Tensor, temperature: flo
 
 
 # ------------------------------------------------------------------------ fused LM head + logprob
+def vocab_shard_range(vocab: int, tp: int, rank: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of the vocabulary held by tensor-parallel rank `rank`: equal shards of a multiple of 8
+    rows (16-byte aligned bf16 logit rows), the last one takes what is left."""
+    if tp <= 1:
+        return 0, vocab
+    per = (-(-vocab // tp) + 7) // 8 * 8
+    lo = min(vocab, rank * per)
+    hi = min(vocab, lo + per)
+    assert hi > lo, f"vocabulary of {vocab} rows leaves tensor-parallel rank {rank} of {tp} without a shard"
+    return lo, hi
+
+
+def _group_size(group) -> int:
+    return dist.get_world_size(group) if group is not None and dist.is_initialized() else 1
+
+
+def _chunk_logits(hidden: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    lg = torch.matmul(hidden, weight.t())
+    if lg.is_cuda and not _is_aligned(lg):  # odd vocabulary (shard): rows must start on 16-byte boundaries
+        lg = _aligned_copy(lg)
+    return lg
+
+
+def merge_shard_stats(stats: torch.Tensor, group) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """stats [4, T] = this shard's (max, sum exp, sum exp*z, target) rows -> the same four over the whole
+    vocabulary. ONE all-gather of 16 bytes per token replaces the reference's three all-reduces
+    (``realhf/impl/model/parallelism/tensor_parallel/modules.py:1060-1177``)."""
+    n = _group_size(group)
+    if n == 1:
+        return stats[0], stats[1], stats[2], stats[3]
+    allst = torch.empty((n,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)
+    if stats.is_cuda:
+        dist.all_gather_into_tensor(allst, stats.contiguous(), group=group)
+    else:
+        dist.all_gather(list(allst.unbind(0)), stats.contiguous(), group=group)
+    m = allst[:, 0].max(0).values
+    f = torch.exp(allst[:, 0] - m)
+    return m, (allst[:, 1] * f).sum(0), (allst[:, 2] * f).sum(0), allst[:, 3].sum(0)
+
+
 class _LMHeadLogprobFn(torch.autograd.Function):
-    """hidden [T, H] x weight [V, H]^T -> (logp [T], entropy [T]) in row chunks.
+    """hidden [T, H] x weight [V_local, H]^T -> (logp [T], entropy [T]) in row chunks.
+
+    `weight` is the whole LM head or, with a tensor-parallel `group`, this rank's vocabulary rows starting
+    at `vocab_start`: every rank reduces its own logits shard to four numbers per token, one all-gather
+    merges them, and the backward forms d(logits) of the shard from the global log-sum-exp. d(hidden) is
+    then a partial sum over shards: it is all-reduced here when `reduce_dh`, or left to the caller's
+    reduce-scatter (sequence parallelism).
 
     The bf16 logits of every chunk are kept for the backward (288 GB of HBM makes keeping them cheaper
     than recomputing the LM-head GEMM); the backward turns them into d(logits) in place and feeds two
@@ -162,29 +220,26 @@ class _LMHeadLogprobFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, hidden, weight, labels, temperature, chunk, keep_logits):
+    def forward(ctx, hidden, weight, labels, temperature, chunk, keep_logits, vocab_start, group, reduce_dh):
         T = hidden.shape[0]
-        logp = torch.empty(T, dtype=torch.float32, device=hidden.device)
-        ent = torch.empty_like(logp)
-        lse = torch.empty_like(logp)
-        ez = torch.empty_like(logp)
+        stats = torch.empty(4, T, dtype=torch.float32, device=hidden.device)
         need_grad = hidden.requires_grad or weight.requires_grad
         kept = []
         for s in range(0, T, chunk):
             e = min(T, s + chunk)
-            lg = torch.matmul(hidden[s:e], weight.t())
-            a, b, c, d = _fwd(lg, labels[s:e], temperature)
-            logp[s:e], ent[s:e], lse[s:e], ez[s:e] = a, b, c, d
+            lg = _chunk_logits(hidden[s:e], weight)
+            logprob_stats(lg, labels[s:e], temperature, vocab_start, out=stats[:, s:e])
             if need_grad and keep_logits:
                 kept.append(lg)
+        logp, ent, lse, ez = _finalize(*merge_shard_stats(stats, group))
         ctx.save_for_backward(hidden, weight, labels, lse, ez, *kept)
-        ctx.meta = (temperature, chunk, keep_logits)
+        ctx.meta = (temperature, chunk, keep_logits, vocab_start, group, reduce_dh)
         return logp, ent
 
     @staticmethod
     def backward(ctx, dlogp, dent):
         hidden, weight, labels, lse, ez, *kept = ctx.saved_tensors
-        temperature, chunk, keep_logits = ctx.meta
+        temperature, chunk, keep_logits, vocab_start, group, reduce_dh = ctx.meta
         T = hidden.shape[0]
         dlogp = dlogp.contiguous().float() if dlogp is not None else None
         dent = dent.contiguous().float() if dent is not None else None
@@ -192,34 +247,23 @@ class _LMHeadLogprobFn(torch.autograd.Function):
         dw = torch.zeros_like(weight) if ctx.needs_input_grad[1] else None
         for i, s in enumerate(range(0, T, chunk)):
             e = min(T, s + chunk)
-            lg = kept[i] if keep_logits else torch.matmul(hidden[s:e], weight.t())
+            lg = kept[i] if keep_logits else _chunk_logits(hidden[s:e], weight)
             _bwd_inplace(lg, labels[s:e], temperature, lse[s:e], ez[s:e],
-                         dlogp[s:e] if dlogp is not None else None, dent[s:e] if dent is not None else None)
+                         dlogp[s:e] if dlogp is not None else None, dent[s:e] if dent is not None else None,
+                         vocab_start)
             torch.matmul(lg, weight, out=dh[s:e])
             if dw is not None:
                 dw.addmm_(lg.t(), hidden[s:e])
-        return dh, dw, None, None, None, None
+        if reduce_dh and _group_size(group) > 1:
+            dist.all_reduce(dh, group=group)
+        return dh, dw, None, None, None, None, None, None, None
 
 
 def lm_head_logprobs(hidden: torch.Tensor, weight: torch.Tensor, labels: torch.Tensor, temperature: float = 1.0,
-                     chunk: int = 8192, keep_logits: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Fused LM head + log-prob + entropy. hidden [T, H] (bf16), weight [V, H]; labels int64 [T]."""
-    return _LMHeadLogprobFn.apply(hidden, weight, labels.long(), float(temperature), int(chunk), keep_logits)
-
-
-def vocab_parallel_logprobs(local_logits: torch.Tensor, labels: torch.Tensor, vocab_start: int,
-                            group: Optional["dist.ProcessGroup"], temperature: float = 1.0):
-    """Forward-only log-prob / entropy from a vocab shard [T, V/tp]: one all-gather of [T, 4] stats."""
-    m, s, w, tgt = logprob_stats(local_logits, labels, temperature, vocab_start)
-    st = torch.stack([m, s, w, tgt], -1)
-    if group is not None and dist.get_world_size(group) > 1:
-        allst = [torch.empty_like(st) for _ in range(dist.get_world_size(group))]
-        dist.all_gather(allst, st, group=group)
-        allst = torch.stack(allst, 0)  # [tp, T, 4]
-        mm = allst[..., 0].max(0).values
-        f = torch.exp(allst[..., 0] - mm)
-        s = (allst[..., 1] * f).sum(0)
-        w = (allst[..., 2] * f).sum(0)
-        tgt = allst[..., 3].sum(0)
-        m = mm
-    return _finalize(m, s, w, tgt)
+                     chunk: int = 8192, keep_logits: bool = True, vocab_start: int = 0, group=None,
+                     reduce_dh: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fused LM head + log-prob + entropy. hidden [T, H] (bf16), labels int64 [T] (global token ids);
+    weight [V, H], or the vocabulary rows [vocab_start, vocab_start + V_local) of a tensor-parallel shard
+    whose peers are the ranks of `group`."""
+    return _LMHeadLogprobFn.apply(hidden, weight, labels.long(), float(temperature), int(chunk), keep_logits,
+                                  int(vocab_start), group, bool(reduce_dh))

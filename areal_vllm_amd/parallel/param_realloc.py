@@ -11,7 +11,7 @@ How it works here:
 * Every shard's flat parameter buffer is described by *pieces* ``(local_offset, full_offset, length)``:
   a contiguous run of the local buffer that is a contiguous run of the full (unsharded) parameter.
   Row-partitioned weights (fused qkv, gate|up) contribute one piece per section, column-partitioned
-  weights (o, down) one piece per row, replicated weights a single piece. The layout of ANY shard can be
+  weights (o, down) one piece per row, vocabulary shards and replicated weights a single piece. The layout of ANY shard can be
   computed by any process from the model config alone (the module is built on the meta device).
 * Intersecting destination pieces with the (de-duplicated) source pieces of a parameter gives transfer
   segments. Segments of one (source shard, destination shard) pair are packed with the interval-gather
@@ -39,6 +39,7 @@ class Layout:
     dp: int = 1
     tp: int = 1
     pp: int = 1
+    vocab_parallel: bool = True  # embedding / LM head rows split over tp (the trainer's layout under tp > 1)
 
     @property
     def world(self) -> int:
@@ -52,7 +53,7 @@ class Layout:
 def _meta_shard(cfg: ModelConfig, lay: Layout, tp_rank: int, pp_rank: int, dtype=torch.bfloat16) -> Transformer:
     lr = stage_layer_range(cfg.n_layers, lay.pp, pp_rank)
     m = Transformer(cfg, dtype=dtype, device="meta", tp_size=lay.tp, tp_rank=tp_rank, layer_range=lr,
-                    has_embed=pp_rank == 0, has_head=pp_rank == lay.pp - 1)
+                    has_embed=pp_rank == 0, has_head=pp_rank == lay.pp - 1, vocab_parallel=lay.vocab_parallel)
     m.flatten()
     return m
 
@@ -115,7 +116,10 @@ def shard_pieces(model: Transformer) -> Dict[str, np.ndarray]:
             e0 = blk.mlp.ep_rank * blk.mlp.n_local
             out[gname] = np.concatenate([cols(off + e * H * f, H, f, F_, tr * f) + np.array([0, (e0 + e) * H * F_, 0])
                                          for e in range(E)])
-        else:  # replicated over tp: norms, embeddings, value / LM head, router
+        elif model.vocab_parallel and (leaf == "embed" or (leaf == "head" and not cfg.is_critic)):
+            v_lo, v_hi = model.vocab_range
+            out[gname] = np.asarray(rows(off, v_lo, v_hi - v_lo, H), dtype=np.int64)
+        else:  # replicated over tp: norms, position embeddings, value head, router (and unsharded vocabularies)
             out[gname] = np.asarray([(off, 0, numel)], dtype=np.int64)
     return out
 

@@ -132,6 +132,33 @@ class ScatterToSP(torch.autograd.Function):
         return comm.all_gather_cat(g, ctx.group), None
 
 
+class GatherVocab(torch.autograd.Function):
+    """Vocabulary-sharded logits [T, V_r] -> [T, V]: shards may differ in width (the last one takes what an
+    even split leaves), so they travel padded to the widest. Backward keeps this rank's columns."""
+
+    @staticmethod
+    def forward(ctx, x, group, vocab):
+        n = _size(group)
+        if n == 1:
+            return x
+        from ..ops import vocab_shard_range
+
+        bounds = [vocab_shard_range(vocab, n, i) for i in range(n)]
+        widths = [hi - lo for lo, hi in bounds]
+        assert x.shape[1] == widths[dist.get_rank(group)]
+        wmax = max(widths)
+        padded = x if x.shape[1] == wmax else F.pad(x, (0, wmax - x.shape[1]))
+        parts = comm.all_gather_cat(padded.contiguous().unsqueeze(0), group)
+        ctx.lo, ctx.hi = bounds[dist.get_rank(group)]
+        return torch.cat([parts[i, :, :w] for i, w in enumerate(widths)], 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        if not hasattr(ctx, "lo"):
+            return g, None, None
+        return g[:, ctx.lo:ctx.hi].contiguous(), None, None
+
+
 def column_parallel_linear(x, weight, bias=None, group=None, sequence_parallel: bool = False):
     """y_shard = x @ W_shard^T. `x` is replicated (or token-sharded when sequence_parallel)."""
     x = GatherFromSP.apply(x, group) if sequence_parallel else CopyToTP.apply(x, group)
@@ -145,15 +172,17 @@ def row_parallel_linear(x_shard, weight, bias=None, group=None, sequence_paralle
     return y if bias is None else y + bias
 
 
-def vocab_parallel_embedding(ids: torch.Tensor, weight_shard: torch.Tensor, group=None) -> torch.Tensor:
+def vocab_parallel_embedding(ids: torch.Tensor, weight_shard: torch.Tensor, group=None,
+                             vocab_start: Optional[int] = None) -> torch.Tensor:
     """Embedding with the vocabulary split over the tp group: out-of-shard ids contribute zero and the
-    partial results are summed (reference ``modules.py:57-139``)."""
+    partial results are summed (reference ``modules.py:57-139``). `vocab_start`: first row of this shard
+    (default: equal shards)."""
     n = _size(group)
     if n == 1:
         return F.embedding(ids, weight_shard)
     r = dist.get_rank(group)
     per = weight_shard.shape[0]
-    lo = r * per
+    lo = r * per if vocab_start is None else vocab_start
     mask = (ids < lo) | (ids >= lo + per)
     local = (ids - lo).masked_fill(mask, 0)
     out = F.embedding(local, weight_shard)

@@ -280,6 +280,42 @@ def test_lm_head_logprobs_matches_unfused():
     _close(w.grad, wf.grad, 2e-2 * wf.grad.abs().max().item(), 5e-2, "dw")
 
 
+@pytest.mark.parametrize("V,tp", [(151936, 4), (4096, 2), (1000, 3)])
+def test_vocab_shard_kernels_merge_to_full_vocab(V, tp):
+    """The tensor-parallel loss path on one device: every vocabulary shard (vocab_start != 0, uneven last
+    shard) goes through the stats kernel, the [4, T] statistics are merged as the all-gather would, and
+    the gradient kernel forms each shard's d(logits) from the GLOBAL log-sum-exp. Compared with an fp32
+    log-softmax over the whole vocabulary, forward and backward."""
+    from areal_vllm_amd.ops import logprob as LP
+
+    torch.manual_seed(16)
+    T, temp = 53, 0.8
+    full = (3 * torch.randn(T, V, device=DEV)).bfloat16()
+    labels = torch.randint(0, V, (T,), device=DEV)
+    labels[0], labels[1] = 0, V - 1
+    gl, ge = torch.randn(T, device=DEV), torch.randn(T, device=DEV)
+    lf = full.float().requires_grad_(True)
+    ls = torch.log_softmax(lf / temp, -1)
+    ref_lp = ls.gather(-1, labels.unsqueeze(-1)).squeeze(-1)
+    ref_ent = -(ls.exp() * ls).sum(-1)
+    ((ref_lp * gl).sum() + (ref_ent * ge).sum()).backward()
+
+    bounds = [ops.vocab_shard_range(V, tp, r) for r in range(tp)]
+    shards = [LP._aligned_copy(full[:, lo:hi]) for lo, hi in bounds]
+    stats = torch.empty(tp, 4, T, dtype=torch.float32, device=DEV)
+    for r, (lo, hi) in enumerate(bounds):
+        ops.logprob_stats(shards[r], labels, temp, lo, out=stats[r])
+    m = stats[:, 0].max(0).values
+    f = torch.exp(stats[:, 0] - m)
+    logp, ent, lse, ez = LP._finalize(m, (stats[:, 1] * f).sum(0), (stats[:, 2] * f).sum(0), stats[:, 3].sum(0))
+    _close(logp, ref_lp, 1e-3, 1e-4, "merged logp")
+    _close(ent, ref_ent, 1e-3, 1e-3, "merged entropy")
+    for r, (lo, hi) in enumerate(bounds):
+        LP._bwd_inplace(shards[r], labels, temp, lse, ez, gl, ge, lo)
+        want = lf.grad[:, lo:hi]
+        _close(shards[r], want, 2e-2 * lf.grad.abs().max().item(), 2e-2, f"dlogits of shard {r}")
+
+
 @pytest.mark.parametrize("max_seqlen", [32, 128, 512, 5000])
 @pytest.mark.parametrize("bs", [2, 4, 33])
 @pytest.mark.parametrize("gamma,lam", [(0.9, 0.5), (1.0, 1.0), (0.99, 0.95)])

@@ -23,7 +23,7 @@ def _cfg(**kw):
 def _shard(cfg, lay, tp, pp):
     m = Transformer(cfg, dtype=torch.float32, device="cpu", tp_size=lay.tp, tp_rank=tp,
                     layer_range=stage_layer_range(cfg.n_layers, lay.pp, pp), has_embed=pp == 0,
-                    has_head=pp == lay.pp - 1)
+                    has_head=pp == lay.pp - 1, vocab_parallel=lay.vocab_parallel)
     m.flatten()
     return m
 
@@ -45,13 +45,15 @@ def _reference_shards(cfg, full, lay):
             m = _shard(cfg, lay, tp, pp)
             assign_hf_named_tensors(m, tensors)
             if cfg.tie_word_embeddings and "head" in dict(m.named_parameters()):
-                m.head.data.copy_(tensors["model.embed_tokens.weight"])
+                v_lo, v_hi = m.vocab_range
+                m.head.data.copy_(tensors["model.embed_tokens.weight"][v_lo:v_hi])
             out[(pp, tp)] = m
     return out
 
 
 @pytest.mark.parametrize("tied", [True, False])
-@pytest.mark.parametrize("dst", [Layout(1, 2, 1), Layout(1, 4, 1), Layout(2, 1, 3), Layout(1, 2, 2)])
+@pytest.mark.parametrize("dst", [Layout(1, 2, 1), Layout(1, 4, 1), Layout(2, 1, 3), Layout(1, 2, 2),
+                                 Layout(1, 2, 2, vocab_parallel=False)])
 def test_plan_matches_hf_sharding_and_round_trips(dst, tied):
     cfg = _cfg(tie_word_embeddings=tied)
     full = _shard(cfg, Layout(), 0, 0)
