@@ -89,11 +89,15 @@ class LocalInferenceEngine(InferenceEngine):
     async def agenerate(self, req: ModelRequest) -> ModelResponse:
         g = req.gconfig
         mm = (req.metadata or {}).get("multi_modal_input")
+        if g.stop and req.tokenizer is None:
+            raise ValueError("stop strings need a tokenizer on the request")
+        stop_seqs = [list(req.tokenizer.encode(s_, add_special_tokens=False)) for s_ in (g.stop or [])]
 
         async def gen_once(rid, ids, max_new, min_new):
             r = await self.engine.agenerate_once(
                 rid, ids, max_new_tokens=max_new, min_new_tokens=min_new, temperature=g.temperature, top_p=g.top_p,
-                top_k=g.top_k, stop_token_ids=g.stop_token_ids, greedy=g.greedy, multimodal=mm)
+                top_k=g.top_k, stop_token_ids=g.stop_token_ids, greedy=g.greedy, multimodal=mm,
+                stop_sequences=stop_seqs, frequency_penalty=g.frequency_penalty)
             return dict(output_tokens=r.output_tokens, output_logprobs=r.output_logprobs,
                         output_versions=r.output_versions, finish_reason=r.finish_reason, itl=r.itl)
 

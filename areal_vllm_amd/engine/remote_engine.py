@@ -117,12 +117,16 @@ class RemoteInferenceEngine(InferenceEngine):
             raise ValueError("stop strings need a tokenizer on the request")
         addr = self._server_for(req.rid)
 
+        # stop strings travel as token-id sequences: the server matches them against the generated tokens
+        stop_seqs = [list(req.tokenizer.encode(s_, add_special_tokens=False)) for s_ in (g.stop or [])]
+
         async def gen_once(rid, ids, max_new, min_new):
             payload = {
                 "rid": rid, "input_ids": ids, "return_logprob": True, "stream": False,
                 "sampling_params": {"top_p": g.top_p, "top_k": g.top_k, "max_new_tokens": max_new,
                                     "min_new_tokens": min_new, "temperature": 0.0 if g.greedy else g.temperature,
-                                    "stop_token_ids": g.stop_token_ids, "frequency_penalty": g.frequency_penalty},
+                                    "stop_token_ids": g.stop_token_ids, "stop_sequences": stop_seqs,
+                                    "frequency_penalty": g.frequency_penalty},
             }
             if req.image_data:  # base64 images; the server runs its own image processor on them
                 payload["image_data"] = list(req.image_data)

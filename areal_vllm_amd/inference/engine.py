@@ -90,9 +90,14 @@ class NativeInferenceEngine:
         self._version = 0
         self._paused = False
         self.stats = dict(prefill_steps=0, decode_steps=0, prefill_time=0.0, decode_time=0.0, gen_tokens=0,
-                          prompt_tokens=0, aborted=0)
+                          prompt_tokens=0, aborted=0, pipelined_plans=0)
         self._copy_stream = None
         self._stream = None
+        self._inflight: Optional[Dict[str, Any]] = None  # decode plan running on the device, not booked yet
+        self._last_decode_done = 0.0
+        self.pipeline_decode = os.environ.get("AREAL_PIPELINE_DECODE", "1") != "0"
+        self._free_penalty_slots: List[int] = []
+        self._slots_to_clear: List[int] = []
         self._mm_ids: Dict[str, int] = {}  # request id -> scheduler id of requests that carry images
         self.update_group = None
         self.update_groups: Dict[str, Any] = {}
@@ -157,6 +162,7 @@ class NativeInferenceEngine:
                                   use_graph=not cfg.disable_cuda_graph, seed=int(cfg.random_seed),
                                   buckets=cfg.cuda_graph_bs)
         self.num_pages = num_pages
+        self._free_penalty_slots = list(range(max_running - 1, -1, -1))
         if not self.is_leader:
             return self  # followers execute the leader's plans in `run_follower`
         sc = _runtime.SchedulerConfig()
@@ -186,6 +192,11 @@ class NativeInferenceEngine:
 
     # -------------------------------------------------------------------------- step loop
     def _loop(self):
+        """One thread drives the scheduler and the device. Decode plans are pipelined: while plan n runs, its
+        continuation n+1 (same rows, device state carried over) is scheduled and launched, and only then the
+        tokens of plan n are awaited and booked - the device goes from one graph replay straight into the next.
+        Anything that changes the batch (a prefill that is due, a pause, an abort, new weights) first lets the
+        plan in flight finish."""
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
             # the engine owns a stream: decode graphs overlap with whatever the trainer thread runs on
@@ -201,6 +212,9 @@ class NativeInferenceEngine:
                 self._drain_control()
                 self._poll_pull()
                 self._drain_requests()
+                if self._inflight is not None:
+                    self._advance_pipeline()
+                    continue
                 if self._paused or not self.sched.has_work():
                     self._deliver()
                     if self.tp_size > 1 and time.monotonic() - self._last_bcast > 30.0:
@@ -215,20 +229,18 @@ class NativeInferenceEngine:
                     self._wake.wait(timeout=0.002)
                     self._wake.clear()
                     continue
-                t0 = time.perf_counter()
-                if self.tp_size > 1:
-                    self._tp_bcast("prefill" if kind == 1 else "decode", plan)
                 if kind == 1:
+                    t0 = time.perf_counter()
+                    self._attach_slot_clears(plan)
+                    self._tp_bcast("prefill", plan)
+                    self.runner.clear_penalty_slots(plan["clear_penalty_slots"])
                     toks, lps = self.runner.prefill(plan)
-                    self.sched.process_prefill(toks, lps)
+                    self.sched.process_prefill(toks, lps, plan["plan_id"])
                     self.stats["prefill_steps"] += 1
                     self.stats["prefill_time"] += time.perf_counter() - t0
+                    self._deliver()
                 else:
-                    toks, lps = self.runner.decode(plan)
-                    self.sched.process_decode(toks, lps)
-                    self.stats["decode_steps"] += 1
-                    self.stats["decode_time"] += time.perf_counter() - t0
-                self._deliver()
+                    self._launch_decode(plan)
         except Exception:
             traceback.print_exc()
             self._fail_all("engine loop crashed")
@@ -238,6 +250,47 @@ class NativeInferenceEngine:
                     self._tp_bcast("shutdown")
                 except Exception:  # the group may already be gone at interpreter exit
                     pass
+
+    def _attach_slot_clears(self, plan):
+        """Count-table rows handed to new requests since the last plan: every rank zeroes them before it runs
+        the plan."""
+        plan["clear_penalty_slots"] = self._slots_to_clear
+        self._slots_to_clear = []
+
+    def _launch_decode(self, plan):
+        self._attach_slot_clears(plan)
+        self._tp_bcast("decode", plan)
+        self.runner.clear_penalty_slots(plan["clear_penalty_slots"])
+        self._inflight = dict(plan=plan, handle=self.runner.decode_launch(plan), t0=time.perf_counter())
+
+    def _advance_pipeline(self, allow_successor: bool = True):
+        """Book the plan in flight. Unless something needs the batch to change, its continuation is launched
+        FIRST, so the device has work queued while the host waits for, and processes, this plan's tokens."""
+        cur, nxt = self._inflight, None
+        if (allow_successor and self.pipeline_decode and not self._paused and self._ctrl_q.empty()
+                and getattr(self, "_pending_pull", None) is None):
+            # live rows must still fill more than the next smaller batch bucket, or re-packing pays
+            live_floor = self.runner.smaller_bucket(len(cur["plan"]["req_ids"])) + 1
+            cont = self.sched.schedule_continuation(cur["plan"]["plan_id"], live_floor)
+            if cont["kind"] == 2:
+                self._attach_slot_clears(cont)
+                self._tp_bcast("decode", cont)
+                nxt = dict(plan=cont, handle=self.runner.decode_launch(cont), t0=time.perf_counter())
+                self.stats["pipelined_plans"] += 1
+        toks, lps = self.runner.decode_wait(cur["handle"])
+        self.sched.process_decode(toks, lps, cur["plan"]["plan_id"], nxt is not None)
+        self.stats["decode_steps"] += 1
+        now = time.perf_counter()
+        # device time is shared between overlapping plans: count from the later of launch / previous completion
+        self.stats["decode_time"] += now - max(cur["t0"], self._last_decode_done)
+        self._last_decode_done = now
+        self._inflight = nxt
+        self._deliver()
+
+    def _finish_inflight(self):
+        """Wait for and book whatever is running on the device (no successor is launched)."""
+        while self._inflight is not None:
+            self._advance_pipeline(allow_successor=False)
 
     def run_follower(self):
         """Loop of TP ranks > 0: receive the leader's commands and run them on this rank's shard. Sampling
@@ -253,9 +306,13 @@ class NativeInferenceEngine:
             dist.broadcast_object_list(box, src=self._tp_src, group=self.tp_group)
             cmd, payload = box[0]
             if cmd == "prefill":
+                self.runner.clear_penalty_slots(payload.get("clear_penalty_slots", []))
                 self.runner.prefill(payload)
             elif cmd == "decode":
-                self.runner.decode(payload)
+                # launched, never awaited: the leader may send the continuation before this plan has finished
+                # (its tokens arrive through the per-step broadcast inside the plan, not through the host)
+                self.runner.clear_penalty_slots(payload.get("clear_penalty_slots", []))
+                self.runner.decode_launch(payload)
             elif cmd == "load_disk":
                 hf_io.load_hf_weights(self.model, payload)
             elif cmd == "init_update_group":
@@ -277,8 +334,16 @@ class NativeInferenceEngine:
             if mm is not None and self.runner.is_vl:
                 assert self.tp_size == 1, "vision-language serving is single-rank"
                 sched_prompt = self.runner.salted_prompt(prompt, mm["pixel_values"], mm["image_grid_thw"])
+            slot = -1
+            if sp["frequency_penalty"] != 0.0 or sp["presence_penalty"] != 0.0:
+                if not self._free_penalty_slots:  # more penalised requests than batch rows: wait for a free row
+                    self._req_q.put((rid, prompt, sp, mm))
+                    return
+                slot = self._free_penalty_slots.pop()
+                self._slots_to_clear.append(slot)
             req_id = self.sched.add_request(rid, sched_prompt, sp["max_new_tokens"], sp["min_new_tokens"],
-                                            sp["temperature"], sp["top_p"], sp["top_k"], sp["stop_token_ids"])
+                                            sp["temperature"], sp["top_p"], sp["top_k"], sp["stop_token_ids"],
+                                            sp["stop_sequences"], sp["frequency_penalty"], sp["presence_penalty"], slot)
             if mm is not None and self.runner.is_vl:
                 self.runner.register_multimodal(req_id, prompt, mm["pixel_values"], mm["image_grid_thw"])
                 self._mm_ids[rid] = req_id
@@ -289,6 +354,7 @@ class NativeInferenceEngine:
                 fn, done = self._ctrl_q.get_nowait()
             except queue.Empty:
                 return
+            self._finish_inflight()  # control verbs act on a quiescent device and a fully booked scheduler
             try:
                 res = fn()
                 done.put((True, res))
@@ -303,6 +369,8 @@ class NativeInferenceEngine:
                                    output_versions=list(f["output_versions"]), finish_reason=f["finish_reason"],
                                    prompt_len=f["prompt_len"], latency=f["latency"], ttft=f["ttft"], itl=list(f["itl"]))
             self.stats["gen_tokens"] += len(res.output_tokens)
+            if f["penalty_slot"] >= 0:
+                self._free_penalty_slots.append(int(f["penalty_slot"]))
             if res.rid in self._mm_ids:
                 self.runner.release_multimodal(self._mm_ids.pop(res.rid))
             if res.finish_reason == "abort":
@@ -337,12 +405,19 @@ class NativeInferenceEngine:
                temperature: float = 1.0, top_p: float = 1.0, top_k: int = 1 << 30,
                stop_token_ids: Optional[List[int]] = None, greedy: bool = False,
                callback: Optional[Callable[[GenerationResult], None]] = None,
-               multimodal: Optional[Dict[str, torch.Tensor]] = None):
+               multimodal: Optional[Dict[str, torch.Tensor]] = None,
+               stop_sequences: Optional[List[List[int]]] = None, frequency_penalty: float = 0.0,
+               presence_penalty: float = 0.0):
         """`multimodal`: {"pixel_values" [n_patches, C*tp*P*P], "image_grid_thw" [n_images, 3]} for prompts
-        whose `input_ids` contain image placeholder tokens (vision-language models)."""
+        whose `input_ids` contain image placeholder tokens (vision-language models). `stop_sequences`: token-id
+        sequences; generation stops (reason "stop") when the generated tokens end with one of them.
+        `frequency_penalty` / `presence_penalty`: logit - f * count - p * (count > 0) over the tokens this
+        request has generated so far (OpenAI / SGLang semantics)."""
         sp = dict(max_new_tokens=int(max_new_tokens), min_new_tokens=int(min_new_tokens),
                   temperature=0.0 if greedy else float(temperature), top_p=float(top_p),
-                  top_k=int(min(top_k, 1 << 30)), stop_token_ids=[int(x) for x in (stop_token_ids or [])])
+                  top_k=int(min(top_k, 1 << 30)), stop_token_ids=[int(x) for x in (stop_token_ids or [])],
+                  stop_sequences=[[int(t) for t in seq] for seq in (stop_sequences or []) if len(seq)],
+                  frequency_penalty=float(frequency_penalty), presence_penalty=float(presence_penalty))
         with self._lock:
             if rid in self._waiters:
                 raise ValueError(f"duplicate request id {rid}")
@@ -544,6 +619,7 @@ class NativeInferenceEngine:
         p = getattr(self, "_pending_pull", None)
         if p is None or (p["event"] is not None and not p["event"].query()):
             return
+        self._finish_inflight()
         self._pending_pull = None
         try:
             t1 = time.perf_counter()
@@ -624,7 +700,8 @@ class NativeInferenceEngine:
             "token_usage": 1.0 - s.num_free_pages() / total, "num_used_pages": total - s.num_free_pages(),
             "cached_pages": s.num_cached_pages(), "gen_tokens_total": s.total_generated(),
             "prompt_tokens_total": s.total_prompt_tokens(), "cached_tokens_total": s.total_cached_tokens(),
-            "preemptions_total": s.num_preemptions(), "weight_version": self._version,
+            "preemptions_total": s.num_preemptions(), "prefix_cache_collisions": s.num_prefix_collisions(),
+            "weight_version": self._version,
             **{k: float(v) for k, v in self.stats.items()},
         }
 

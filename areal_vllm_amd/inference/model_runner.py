@@ -4,10 +4,16 @@
   the first token of every request;
 * decode: `n_steps` tokens per plan; one step = embedding -> L x (RMSNorm, fused qkv GEMM, fused
   RoPE + cache write, paged-KV MFMA attention, o GEMM, RMSNorm, gate|up GEMM, SwiGLU, down GEMM) ->
-  final norm -> LM head -> fused sampler -> device-side `advance_step`. The whole multi-step body is
-  captured once per batch-size bucket into a hipGraph (``torch.cuda.CUDAGraph``) and replayed, so a
-  decode plan costs one host launch (the reference relies on SGLang's CUDA-graph decode and on
-  ``realhf/impl/model/utils/cuda_graph.py:69-220`` for its own generator).
+  final norm -> LM head -> fused sampler (penalties from the token-count table) -> device-side
+  bookkeeping with early exit (`decode_advance_`: rows that used up their budget or drew a stop id
+  retire inside the plan). The whole multi-step body is captured once per batch-size bucket into a
+  hipGraph (``torch.cuda.CUDAGraph``) and replayed, so a decode plan costs one host launch (the
+  reference relies on SGLang's CUDA-graph decode and on ``realhf/impl/model/utils/cuda_graph.py:69-220``
+  for its own generator).
+* decode plans are issued in two halves, `decode_launch` (uploads + graph replay + copy of the results
+  into pinned memory + event) and `decode_wait`: the engine launches the CONTINUATION of a plan - same
+  rows, device state carried over, only page tables and the kill mask uploaded - before it waits for
+  the plan's own tokens, so the device never idles between two replays.
 
 All block tables have the engine-wide maximum width, so graphs only depend on the batch bucket.
 """
@@ -33,7 +39,7 @@ DEFAULT_BUCKETS = [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 320, 
 class ModelRunner:
     def __init__(self, model: Transformer, num_pages: int, max_context: int, max_batch: int, decode_steps: int = 1,
                  use_graph: bool = True, seed: int = 1, buckets: Optional[List[int]] = None,
-                 fused_decode: Optional[bool] = None):
+                 fused_decode: Optional[bool] = None, n_stop_ids: int = 8):
         self.model = model
         self.cfg: ModelConfig = model.cfg
         self.device = next(model.parameters()).device
@@ -65,6 +71,9 @@ class ModelRunner:
         self.V = cfg.vocab_size
         self.n_prefill_tokens = 0
         self.n_decode_tokens = 0
+        self.n_stop_ids = n_stop_ids  # stop ids per row checked on the device (the scheduler checks all of them)
+        self.counts: Optional[ops.TokenCounts] = None  # frequency / presence penalties: allocated on first use
+        self._launches = 0
         # vision-language requests: scheduler request id -> positions / image features (see register_multimodal)
         self.is_vl = cfg.vision is not None
         self.mm: Dict[int, Dict[str, Any]] = {}
@@ -220,10 +229,26 @@ class ModelRunner:
         top_p = torch.from_numpy(plan["top_p"]).to(dev)
         top_k = torch.from_numpy(np.minimum(plan["top_k"], self.V).astype(np.int32)).to(dev)
         filt = bool((plan["top_k"] < self.V).any() or (plan["top_p"] < 1.0).any())
+        pen = {}
+        if "penalty_slot" in plan and (plan["penalty_slot"] >= 0).any():  # chunks that do not sample carry slot -1
+            pen = dict(counts=self.token_counts(), count_slot=torch.from_numpy(plan["penalty_slot"]).to(dev),
+                       freq_pen=torch.from_numpy(plan["frequency_penalty"]).to(dev),
+                       pres_pen=torch.from_numpy(plan["presence_penalty"]).to(dev))
         tok, lp = ops.sample(logits, temp, top_k if filt else None, top_p if filt else None, self.seed,
-                             self.step_counter)
+                             self.step_counter, **pen)
         self._sync_tokens(tok, lp)
         return tok.cpu().numpy(), lp.cpu().numpy()
+
+    # ------------------------------------------------------------------ penalty count table
+    def token_counts(self) -> "ops.TokenCounts":
+        if self.counts is None:
+            self.counts = ops.TokenCounts(self.max_batch, self.V, self.device)
+        return self.counts
+
+    def clear_penalty_slots(self, slots: List[int]):
+        """Zero the count rows of slots that were just handed to new requests."""
+        if slots:
+            self.token_counts().clear(slots)
 
     # ------------------------------------------------------------------------------ decode
     def _bucket(self, b: int) -> int:
@@ -231,6 +256,12 @@ class ModelRunner:
             if x >= b:
                 return x
         raise RuntimeError(f"decode batch {b} exceeds the largest bucket {self.buckets[-1]}")
+
+    def smaller_bucket(self, b: int) -> int:
+        """Largest batch bucket below the one `b` rows run in (0 when there is none)."""
+        cur = self._bucket(b)
+        below = [x for x in self.buckets if x < cur]
+        return below[-1] if below else 0
 
     def _alloc_static(self, Bp: int) -> Dict[str, torch.Tensor]:
         dev = self.device
@@ -249,15 +280,28 @@ class ModelRunner:
             rope_pos=torch.zeros(Bp, dtype=torch.int32, device=dev),
             out_tokens=torch.zeros(k, Bp, dtype=torch.int64, device=dev),
             out_logprobs=torch.zeros(k, Bp, dtype=torch.float32, device=dev),
+            active=torch.zeros(Bp, dtype=torch.int32, device=dev),
+            remaining=torch.ones(Bp, dtype=torch.int32, device=dev),
+            min_remaining=torch.zeros(Bp, dtype=torch.int32, device=dev),
+            stop_ids=torch.full((Bp, self.n_stop_ids), -1, dtype=torch.int32, device=dev),
+            kill=torch.zeros(Bp, dtype=torch.int32, device=dev),
+            penalty_slot=torch.full((Bp,), -1, dtype=torch.int32, device=dev),
+            freq_pen=torch.zeros(Bp, dtype=torch.float32, device=dev),
+            pres_pen=torch.zeros(Bp, dtype=torch.float32, device=dev),
         )
         st["nsplit"] = nsplit
         st["ws"] = ops.DecodeWorkspace(Bp, self.hq, self.cfg.head_dim, nsplit, dev) if nsplit > 1 else None
-        # pinned host mirrors for one-shot uploads
+        # Pinned host memory, two sets used alternately: uploads of plan n+1 are written while the copies of
+        # plan n may still be queued, and plan n's results are read while plan n+1 fills the other set.
         if dev.type == "cuda":
-            st["h_i64"] = torch.zeros(2, Bp, dtype=torch.int64).pin_memory()
-            st["h_i32"] = torch.zeros(4, Bp, dtype=torch.int32).pin_memory()
-            st["h_f32"] = torch.zeros(2, Bp, dtype=torch.float32).pin_memory()
-            st["h_bt"] = torch.zeros(Bp, self.max_pages, dtype=torch.int32).pin_memory()
+            st["host"] = [dict(i64=torch.zeros(2, Bp, dtype=torch.int64).pin_memory(),
+                               i32=torch.zeros(8, Bp, dtype=torch.int32).pin_memory(),
+                               f32=torch.zeros(4, Bp, dtype=torch.float32).pin_memory(),
+                               stop=torch.zeros(Bp, self.n_stop_ids, dtype=torch.int32).pin_memory(),
+                               bt=torch.zeros(Bp, self.max_pages, dtype=torch.int32).pin_memory(),
+                               out_tokens=torch.zeros(k, Bp, dtype=torch.int64).pin_memory(),
+                               out_logprobs=torch.zeros(k, Bp, dtype=torch.float32).pin_memory(),
+                               done=torch.cuda.Event()) for _ in range(2)]
         return st
 
     FUSED_MIN_BATCH = 48
@@ -298,12 +342,19 @@ class ModelRunner:
                                                      eps=eps, gemma=gemma, dtype=self.dtype)
         return x
 
-    def _decode_body(self, st: Dict[str, torch.Tensor], filtered: bool):
+    def _decode_body(self, st: Dict[str, torch.Tensor], filtered: bool, penalized: bool = False):
         """`decode_steps` decode iterations on the static buffers (captured into a graph)."""
         hq, hkv, D = self.hq, self.hkv, self.cfg.head_dim
         Bp = st["input_ids"].numel()
         qkv_stride = (hq + 2 * hkv) * D
         fused = self.fused_decode and Bp >= self.FUSED_MIN_BATCH
+        pen = {}
+        if penalized:
+            pen = dict(counts=self.token_counts(), count_slot=st["penalty_slot"], freq_pen=st["freq_pen"],
+                       pres_pen=st["pres_pen"])
+        # rows the host has given up on retire; live rows take their KV slot from the (refreshed) page table
+        ops.decode_begin_(st["kill"], st["active"], st["positions"], st["context_lens"], st["slots"],
+                          st["block_tables"])
         for s in range(self.decode_steps):
             h = self.model.embed_tokens(st["input_ids"])
             residual = None
@@ -328,13 +379,16 @@ class ModelRunner:
                 logits = self._final_logits(h, residual)
             ops.sample(logits, st["temperature"], st["top_k"] if filtered else None, st["top_p"] if filtered else None,
                        self.seed, self.step_counter, bump_step=True, out_tokens=st["out_tokens"][s],
-                       out_logprobs=st["out_logprobs"][s])
+                       out_logprobs=st["out_logprobs"][s], active=st["active"], **pen)
             self._sync_tokens(st["out_tokens"][s], st["out_logprobs"][s])
-            ops.advance_step_(st["out_tokens"][s], st["input_ids"], st["positions"], st["context_lens"], st["slots"],
-                              st["block_tables"])
+            ops.decode_advance_(st["out_tokens"][s], st["input_ids"], st["positions"], st["context_lens"],
+                                st["slots"], st["block_tables"], st["active"], st["remaining"], st["min_remaining"],
+                                st["stop_ids"])
 
-    def _get_graph(self, Bp: int, filtered: bool):
-        key = (Bp, filtered)
+    _STATE_KEYS = ("input_ids", "positions", "context_lens", "slots", "active", "remaining", "min_remaining")
+
+    def _get_graph(self, Bp: int, filtered: bool, penalized: bool = False):
+        key = (Bp, filtered, penalized)
         if key in self.graphs:
             return self.graphs[key], self.static[Bp]
         if Bp not in self.static:
@@ -343,14 +397,17 @@ class ModelRunner:
         if not self.use_graph:
             self.graphs[key] = None
             return None, st
-        logger.info(f"capturing decode graph: batch bucket {Bp}, filtered={filtered}")
-        # warm up eagerly on a side stream (allocator + hipBLASLt workspaces), then capture
-        saved = {k: st[k].clone() for k in ("input_ids", "positions", "context_lens", "slots")}
+        logger.info(f"capturing decode graph: batch bucket {Bp}, filtered={filtered}, penalized={penalized}")
+        # warm up eagerly on a side stream (allocator + hipBLASLt workspaces), then capture. The warm-up runs on
+        # whatever the static buffers hold: rows are inactive (no KV writes) and no penalty slot is touched.
+        saved = {k: st[k].clone() for k in self._STATE_KEYS + ("penalty_slot",)}
+        st["active"].zero_()
+        st["penalty_slot"].fill_(-1)
         step_saved = self.step_counter.clone()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._decode_body(st, filtered)
+            self._decode_body(st, filtered, penalized)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         for k, v in saved.items():
@@ -358,78 +415,153 @@ class ModelRunner:
         g = torch.cuda.CUDAGraph()
         if self._graph_pool is None:
             self._graph_pool = torch.cuda.graph_pool_handle()
+        st["active"].zero_()
+        st["penalty_slot"].fill_(-1)
         with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
-            self._decode_body(st, filtered)
+            self._decode_body(st, filtered, penalized)
         for k, v in saved.items():
             st[k].copy_(v)
         self.step_counter.copy_(step_saved)
         self.graphs[key] = g
         logger.info(f"captured decode graph: batch bucket {Bp}, {self.decode_steps} step(s), "
-                    f"kv splits {st['nsplit']}, filtered={filtered}")
+                    f"kv splits {st['nsplit']}, filtered={filtered}, penalized={penalized}")
         return g, st
 
+    def _with_defaults(self, plan: Dict[str, Any], B: int) -> Dict[str, Any]:
+        """Hand-made plans (probes, tests) may leave out what only the scheduler knows: no stop ids, no
+        penalties, a budget that outlasts the plan."""
+        if "kill" in plan and "remaining" in plan and "penalty_slot" in plan:
+            return plan
+        plan = dict(plan)
+        plan.setdefault("kill", np.zeros(B, np.int32))
+        plan.setdefault("remaining", np.full(B, 1 << 30, np.int32))
+        plan.setdefault("min_remaining", np.zeros(B, np.int32))
+        plan.setdefault("stop_ids", np.full((B, self.n_stop_ids), -1, np.int32))
+        plan.setdefault("penalty_slot", np.full(B, -1, np.int32))
+        plan.setdefault("frequency_penalty", np.zeros(B, np.float32))
+        plan.setdefault("presence_penalty", np.zeros(B, np.float32))
+        return plan
+
     @torch.no_grad()
-    def decode(self, plan: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray]:
+    def decode_launch(self, plan: Dict[str, Any]) -> Dict[str, Any]:
+        """Issue a decode plan: uploads, graph replay, copy of the sampled tokens / log-probs into pinned memory,
+        completion event. Returns a handle for `decode_wait`. Nothing here waits for the device.
+
+        A continuation plan (`plan["continuation"]`) runs on the rows and the device state its predecessor left
+        behind (input tokens, positions, slots, activity, budgets are advanced on the device): only the page
+        tables and the kill mask are uploaded."""
         B = len(plan["req_ids"])
         assert int(plan["n_steps"]) == self.decode_steps
-        Bp = self._bucket(B)
-        filtered = bool((plan["top_k"] < self.V).any() or (plan["top_p"] < 1.0).any())
-        g, st = self._get_graph(Bp, filtered)
+        plan = self._with_defaults(plan, B)
+        cont = bool(plan.get("continuation", False))
+        if cont:
+            Bp, filtered, penalized = self._last_decode
+            assert B <= Bp, "a continuation keeps the rows of the plan it follows"
+        else:
+            Bp = self._bucket(B)
+            filtered = bool((plan["top_k"] < self.V).any() or (plan["top_p"] < 1.0).any())
+            penalized = bool((plan["penalty_slot"] >= 0).any())
+            self._last_decode = (Bp, filtered, penalized)
+        g, st = self._get_graph(Bp, filtered, penalized)
         mp = int(plan["max_pages"])
         assert mp <= self.max_pages, "request context exceeds the engine's context length"
-        if self.device.type == "cuda":
-            hi64, hi32, hf32, hbt = st["h_i64"], st["h_i32"], st["h_f32"], st["h_bt"]
-            hi64.zero_(); hi32.zero_(); hbt.zero_()
-            hi32[1].fill_(1)
-            hf32[0].fill_(1.0); hf32[1].fill_(1.0)
-            hi32[2].fill_(self.V)
-            hi64[0, :B] = torch.from_numpy(plan["input_ids"].astype(np.int64))
-            hi64[1, :B] = torch.from_numpy(plan["slot_mapping"])
-            hi32[0, :B] = torch.from_numpy(plan["positions"])
-            hi32[1, :B] = torch.from_numpy(plan["context_lens"])
-            hi32[2, :B] = torch.from_numpy(np.minimum(plan["top_k"], self.V).astype(np.int32))
-            if self.is_vl:
-                hi32[3, :B] = torch.tensor([self.mm.get(int(r), {}).get("delta", 0) for r in plan["req_ids"].tolist()],
-                                           dtype=torch.int32)
-                st["rope_delta"].copy_(hi32[3], non_blocking=True)
-            hf32[0, :B] = torch.from_numpy(plan["temperature"])
-            hf32[1, :B] = torch.from_numpy(plan["top_p"])
+        self._launches += 1
+        cuda = self.device.type == "cuda"
+        host = st["host"][self._launches % 2] if cuda else None
+        if cuda:
+            hbt, hi32 = host["bt"], host["i32"]
+            hbt.zero_()
             hbt[:B, :mp] = torch.from_numpy(plan["block_tables"])
-            st["input_ids"].copy_(hi64[0], non_blocking=True)
-            st["slots"].copy_(hi64[1], non_blocking=True)
-            st["positions"].copy_(hi32[0], non_blocking=True)
-            st["context_lens"].copy_(hi32[1], non_blocking=True)
-            st["top_k"].copy_(hi32[2], non_blocking=True)
-            st["temperature"].copy_(hf32[0], non_blocking=True)
-            st["top_p"].copy_(hf32[1], non_blocking=True)
             st["block_tables"].copy_(hbt, non_blocking=True)
+            hi32[4].fill_(1)  # kill: padded rows stay dead
+            hi32[4, :B] = torch.from_numpy(plan["kill"])
+            st["kill"].copy_(hi32[4], non_blocking=True)
         else:
-            for name, src, fill in (("input_ids", plan["input_ids"].astype(np.int64), 0),
-                                    ("slots", plan["slot_mapping"], 0), ("positions", plan["positions"], 0),
-                                    ("context_lens", plan["context_lens"], 1),
-                                    ("top_k", np.minimum(plan["top_k"], self.V).astype(np.int32), self.V),
-                                    ("temperature", plan["temperature"], 1.0), ("top_p", plan["top_p"], 1.0)):
-                st[name].fill_(fill)
-                st[name][:B] = torch.from_numpy(src)
             st["block_tables"].zero_()
             st["block_tables"][:B, :mp] = torch.from_numpy(plan["block_tables"])
+            st["kill"].fill_(1)
+            st["kill"][:B] = torch.from_numpy(plan["kill"])
+        if not cont:
+            top_k = np.minimum(plan["top_k"], self.V).astype(np.int32)
+            delta = None
             if self.is_vl:
-                st["rope_delta"].zero_()
-                st["rope_delta"][:B] = torch.tensor(
-                    [self.mm.get(int(r), {}).get("delta", 0) for r in plan["req_ids"].tolist()], dtype=torch.int32)
+                delta = np.asarray([self.mm.get(int(r), {}).get("delta", 0) for r in plan["req_ids"].tolist()],
+                                   dtype=np.int32)
+            if cuda:
+                hi64, hf32, hstop = host["i64"], host["f32"], host["stop"]
+                hi64.zero_()
+                hi32[:4].zero_(); hi32[5:].zero_()
+                hi32[1].fill_(1); hi32[2].fill_(self.V); hi32[5].fill_(1); hi32[7].fill_(-1)
+                hf32[0].fill_(1.0); hf32[1].fill_(1.0); hf32[2].zero_(); hf32[3].zero_()
+                hstop.fill_(-1)
+                hi64[0, :B] = torch.from_numpy(plan["input_ids"].astype(np.int64))
+                hi64[1, :B] = torch.from_numpy(plan["slot_mapping"])
+                hi32[0, :B] = torch.from_numpy(plan["positions"])
+                hi32[1, :B] = torch.from_numpy(plan["context_lens"])
+                hi32[2, :B] = torch.from_numpy(top_k)
+                if delta is not None:
+                    hi32[3, :B] = torch.from_numpy(delta)
+                    st["rope_delta"].copy_(hi32[3], non_blocking=True)
+                hi32[5, :B] = torch.from_numpy(plan["remaining"])
+                hi32[6, :B] = torch.from_numpy(plan["min_remaining"])
+                hi32[7, :B] = torch.from_numpy(plan["penalty_slot"])
+                hf32[0, :B] = torch.from_numpy(plan["temperature"])
+                hf32[1, :B] = torch.from_numpy(plan["top_p"])
+                hf32[2, :B] = torch.from_numpy(plan["frequency_penalty"])
+                hf32[3, :B] = torch.from_numpy(plan["presence_penalty"])
+                hstop[:B] = torch.from_numpy(plan["stop_ids"])
+                for name, src in (("input_ids", hi64[0]), ("slots", hi64[1]), ("positions", hi32[0]),
+                                  ("context_lens", hi32[1]), ("top_k", hi32[2]), ("remaining", hi32[5]),
+                                  ("min_remaining", hi32[6]), ("penalty_slot", hi32[7]), ("temperature", hf32[0]),
+                                  ("top_p", hf32[1]), ("freq_pen", hf32[2]), ("pres_pen", hf32[3]), ("stop_ids", hstop)):
+                    st[name].copy_(src, non_blocking=True)
+                st["active"].fill_(1)  # decode_begin retires the padded rows through `kill`
+            else:
+                for name, src, fill in (("input_ids", plan["input_ids"].astype(np.int64), 0),
+                                        ("slots", plan["slot_mapping"], 0), ("positions", plan["positions"], 0),
+                                        ("context_lens", plan["context_lens"], 1), ("top_k", top_k, self.V),
+                                        ("remaining", plan["remaining"], 1), ("min_remaining", plan["min_remaining"], 0),
+                                        ("penalty_slot", plan["penalty_slot"], -1),
+                                        ("temperature", plan["temperature"], 1.0), ("top_p", plan["top_p"], 1.0),
+                                        ("freq_pen", plan["frequency_penalty"], 0.0),
+                                        ("pres_pen", plan["presence_penalty"], 0.0)):
+                    st[name].fill_(fill)
+                    st[name][:B] = torch.from_numpy(src)
+                st["stop_ids"].fill_(-1)
+                st["stop_ids"][:B] = torch.from_numpy(plan["stop_ids"])
+                st["active"].fill_(1)
+                if self.is_vl:
+                    st["rope_delta"].zero_()
+                    st["rope_delta"][:B] = torch.from_numpy(delta)
         if g is not None:
             g.replay()
         else:
-            self._decode_body(st, filtered)
+            self._decode_body(st, filtered, penalized)
         self.n_decode_tokens += B * self.decode_steps
-        toks = st["out_tokens"].cpu().numpy()
-        lps = st["out_logprobs"].cpu().numpy()
-        return toks, lps
+        if cuda:
+            host["out_tokens"].copy_(st["out_tokens"], non_blocking=True)
+            host["out_logprobs"].copy_(st["out_logprobs"], non_blocking=True)
+            host["done"].record()
+            return dict(host=host)
+        return dict(tokens=st["out_tokens"].numpy().copy(), logprobs=st["out_logprobs"].numpy().copy())
+
+    @staticmethod
+    def decode_wait(handle: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray]:
+        """Sampled tokens / log-probs [n_steps, Bp] of a launched plan (blocks until its event has fired). The
+        arrays alias pinned memory that the launch after next overwrites: consume them before launching again."""
+        host = handle.get("host")
+        if host is None:
+            return handle["tokens"], handle["logprobs"]
+        host["done"].synchronize()
+        return host["out_tokens"].numpy(), host["out_logprobs"].numpy()
+
+    def decode(self, plan: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray]:
+        return self.decode_wait(self.decode_launch(plan))
 
     def warmup(self, batch_sizes: Optional[List[int]] = None):
         """Capture decode graphs ahead of time for the given batch sizes."""
         for b in batch_sizes or []:
-            self._get_graph(self._bucket(b), False)
+            self._get_graph(self._bucket(b), False, False)
 
     def reset_graphs(self):
         self.graphs.clear()

@@ -5,6 +5,10 @@ Speaks the REST verbs the reference's clients use against SGLang (``areal/engine
 
   GET  /health, /health_generate, /get_model_info, /get_server_info, /metrics (Prometheus text)
   POST /generate {input_ids, sampling_params, return_logprob, stream:false, rid}
+       sampling_params: max_new_tokens, min_new_tokens, temperature, top_p, top_k, stop_token_ids,
+       stop_sequences (token-id sequences), stop (strings: tokenised here with the server's tokenizer),
+       frequency_penalty, presence_penalty, ignore_eos, n (must be 1). Any other key is refused (400): a
+       sampling option is either honoured or rejected, never dropped.
   POST /pause_generation, /continue_generation, /flush_cache, /abort_request {rid}
   POST /update_weights_from_disk {model_path, abort_all_requests}
   POST /init_weights_update_group {master_address, master_port, rank_offset, world_size, backend, group_name}
@@ -40,6 +44,44 @@ from .engine import NativeInferenceEngine
 logger = logging.getLogger("inference-server")
 
 
+SAMPLING_KEYS = {"max_new_tokens", "min_new_tokens", "temperature", "top_p", "top_k", "stop_token_ids",
+                 "stop_sequences", "stop", "frequency_penalty", "presence_penalty", "ignore_eos", "n",
+                 "skip_special_tokens", "spaces_between_special_tokens", "no_stop_trim"}  # last three: text only
+REQUEST_KEYS = {"input_ids", "sampling_params", "return_logprob", "stream", "rid", "image_data", "logprob_start_len",
+                "top_logprobs_num", "return_text_in_logprobs"}
+
+
+class BadRequest(ValueError):
+    pass
+
+
+def parse_sampling_params(sp: Dict[str, Any], stop_to_ids=None) -> Dict[str, Any]:
+    """Validate the `sampling_params` of a /generate request and turn them into `NativeInferenceEngine.submit`
+    keywords. Unknown keys and options this engine cannot honour raise `BadRequest`. `stop_to_ids(str)` maps a
+    stop string to its token ids (None: stop strings are refused)."""
+    unknown = sorted(set(sp) - SAMPLING_KEYS)
+    if unknown:
+        raise BadRequest(f"unsupported sampling parameter(s) {unknown}; supported: {sorted(SAMPLING_KEYS)}")
+    if int(sp.get("n", 1)) != 1:
+        raise BadRequest("n > 1 is not supported: send one request per sample (they share the prompt's prefix cache)")
+    temp = float(sp.get("temperature", 1.0))
+    top_k = int(sp.get("top_k", -1))
+    seqs = [list(map(int, q)) for q in (sp.get("stop_sequences") or [])]
+    stops = sp.get("stop") or []
+    if isinstance(stops, str):
+        stops = [stops]
+    if stops:
+        if stop_to_ids is None:
+            raise BadRequest("stop strings need a tokenizer on the server (start it with --tokenizer-path), or send "
+                             "`stop_sequences` (token ids) instead")
+        seqs += [ids for ids in (stop_to_ids(x) for x in stops) if ids]
+    return dict(max_new_tokens=int(sp.get("max_new_tokens", 128)), min_new_tokens=int(sp.get("min_new_tokens", 0)),
+                temperature=temp, top_p=float(sp.get("top_p", 1.0)), top_k=top_k if top_k > 0 else 1 << 30,
+                stop_token_ids=[] if sp.get("ignore_eos") else list(sp.get("stop_token_ids") or []),
+                stop_sequences=seqs, frequency_penalty=float(sp.get("frequency_penalty", 0.0) or 0.0),
+                presence_penalty=float(sp.get("presence_penalty", 0.0) or 0.0), greedy=temp <= 0.0)
+
+
 def _finish(reason: str) -> Dict[str, Any]:
     if reason == "abort":
         return {"type": "abort", "message": "Abort by weight update or pause"}
@@ -51,6 +93,7 @@ class InferenceServer:
         self.engine = engine
         self.update_group = None
         self._image_processor = None
+        self._tokenizer = None  # loaded on the first request with stop strings; False: none available
         self.start_time = time.time()
         self.app = web.Application(client_max_size=1024**3)
         r = self.app.router
@@ -99,20 +142,23 @@ class InferenceServer:
         ids = body.get("input_ids")
         if ids is None:
             return web.json_response({"error": "this server takes token ids (`input_ids`)"}, status=400)
-        sp = body.get("sampling_params", {}) or {}
         rid = body.get("rid") or uuid.uuid4().hex
-        temp = float(sp.get("temperature", 1.0))
+        try:
+            extra = sorted(set(body) - REQUEST_KEYS)
+            if extra:
+                raise BadRequest(f"unsupported request field(s) {extra}")
+            if body.get("stream"):
+                raise BadRequest("streaming responses are not supported (stream must be false)")
+            kw = parse_sampling_params(body.get("sampling_params", {}) or {}, self._stop_to_ids())
+        except (BadRequest, TypeError, ValueError) as e:
+            return web.json_response({"error": str(e)}, status=400)
         multimodal = None
         if body.get("image_data"):
             try:
                 multimodal = await self._offload(self._process_images, body["image_data"])
             except Exception as e:
                 return web.json_response({"error": f"cannot process image_data: {e!r}"}, status=400)
-        res = await self.engine.agenerate_once(
-            f"{rid}-{uuid.uuid4().hex[:8]}", ids, max_new_tokens=int(sp.get("max_new_tokens", 128)),
-            min_new_tokens=int(sp.get("min_new_tokens", 0)), temperature=temp, top_p=float(sp.get("top_p", 1.0)),
-            top_k=int(sp.get("top_k", 1 << 30)) if int(sp.get("top_k", -1)) > 0 else 1 << 30,
-            stop_token_ids=sp.get("stop_token_ids") or [], greedy=temp <= 0.0, multimodal=multimodal)
+        res = await self.engine.agenerate_once(f"{rid}-{uuid.uuid4().hex[:8]}", ids, multimodal=multimodal, **kw)
         meta = {
             "id": rid, "finish_reason": _finish(res.finish_reason), "prompt_tokens": res.prompt_len,
             "completion_tokens": len(res.output_tokens),
@@ -121,6 +167,22 @@ class InferenceServer:
             "e2e_latency": res.latency, "ttft": res.ttft,
         }
         return web.json_response({"text": "", "output_ids": res.output_tokens, "meta_info": meta})
+
+    def _stop_to_ids(self):
+        """str -> token ids with the server's tokenizer, or None when there is none to load."""
+        if self._tokenizer is None:
+            path = getattr(self.engine.config, "tokenizer_path", None) or self.engine.config.model_path
+            self._tokenizer = False
+            if path and os.path.isdir(str(path)):
+                try:
+                    from transformers import AutoTokenizer
+
+                    self._tokenizer = AutoTokenizer.from_pretrained(path)
+                except Exception as e:  # no tokenizer files next to the weights
+                    logger.warning(f"no tokenizer at {path} ({e!r}): stop strings will be refused")
+        if not self._tokenizer:
+            return None
+        return lambda text: list(self._tokenizer.encode(text, add_special_tokens=False))
 
     def _process_images(self, image_data: List[str]) -> Dict[str, torch.Tensor]:
         """base64 images -> patch tensor + grids with the checkpoint's own image processor (the request's

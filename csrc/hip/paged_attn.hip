@@ -340,3 +340,84 @@ extern "C" int areal_advance_step(const int64_t* sampled, int64_t* input_ids, in
                      positions, context_lens, slots, block_tables, active, B, max_pages);
   return (int)hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// Device-side bookkeeping of a multi-step decode plan with early exit.
+//
+// Per row: `active` (1 while the request still generates), `remaining` (tokens it may still produce:
+// max_new_tokens and the context cap), `min_remaining` (tokens before stop ids count), `stop_ids`
+// [B, n_stop] (-1 padded). After every sampled token the row either advances (next input token, position,
+// context length, KV slot from the page table) or retires: no further KV writes (slot -1), attention over
+// a single token (context length 1), sampler skipped. The host applies the same rules to the tokens it
+// gets back, so both sides agree on where a request ends.
+__global__ void decode_advance_kernel(const int64_t* __restrict__ sampled, int64_t* __restrict__ input_ids,
+                                      int* __restrict__ positions, int* __restrict__ context_lens,
+                                      int64_t* __restrict__ slots, const int* __restrict__ block_tables,
+                                      int* __restrict__ active, int* __restrict__ remaining,
+                                      int* __restrict__ min_remaining, const int* __restrict__ stop_ids,
+                                      int n_stop, int B, int max_pages) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || !active[b]) return;
+  const int64_t tok = sampled[b];
+  const int rem = remaining[b] - 1;
+  const int mrem = min_remaining[b] > 0 ? min_remaining[b] - 1 : 0;
+  remaining[b] = rem;
+  min_remaining[b] = mrem;
+  bool stop = rem <= 0;
+  if (!stop && mrem == 0) {
+    // stop ids count once min_new_tokens have been produced INCLUDING this token
+    for (int j = 0; j < n_stop; ++j) stop |= stop_ids[(size_t)b * n_stop + j] == (int)tok;
+  }
+  if (stop) {
+    active[b] = 0;
+    slots[b] = -1;
+    context_lens[b] = 1;
+    return;
+  }
+  input_ids[b] = tok;
+  const int np = positions[b] + 1;
+  positions[b] = np;
+  context_lens[b] = np + 1;
+  const int pg = np / PAGE;
+  slots[b] = pg < max_pages ? (int64_t)block_tables[(size_t)b * max_pages + pg] * PAGE + np % PAGE : -1;
+}
+
+// Start of a decode plan that continues the previous one on the same rows: rows whose request ended on
+// the host (`kill`) retire, and live rows re-derive their KV slot from the refreshed page table.
+__global__ void decode_begin_kernel(const int* __restrict__ kill, int* __restrict__ active,
+                                    const int* __restrict__ positions, int* __restrict__ context_lens,
+                                    int64_t* __restrict__ slots, const int* __restrict__ block_tables, int B,
+                                    int max_pages) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (kill[b]) active[b] = 0;
+  if (!active[b]) {
+    slots[b] = -1;
+    context_lens[b] = 1;
+    return;
+  }
+  const int np = positions[b];
+  const int pg = np / PAGE;
+  slots[b] = pg < max_pages ? (int64_t)block_tables[(size_t)b * max_pages + pg] * PAGE + np % PAGE : -1;
+}
+
+extern "C" int areal_decode_advance(const int64_t* sampled, int64_t* input_ids, int* positions,
+                                    int* context_lens, int64_t* slots, const int* block_tables, int* active,
+                                    int* remaining, int* min_remaining, const int* stop_ids, int n_stop, int B,
+                                    int max_pages, hipStream_t st) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(decode_advance_kernel, dim3((B + 255) / 256), dim3(256), 0, st, sampled, input_ids,
+                     positions, context_lens, slots, block_tables, active, remaining, min_remaining, stop_ids,
+                     n_stop, B, max_pages);
+  return (int)hipGetLastError();
+}
+
+extern "C" int areal_decode_begin(const int* kill, int* active, const int* positions, int* context_lens,
+                                  int64_t* slots, const int* block_tables, int B, int max_pages,
+                                  hipStream_t st) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(decode_begin_kernel, dim3((B + 255) / 256), dim3(256), 0, st, kill, active, positions,
+                     context_lens, slots, block_tables, B, max_pages);
+  return (int)hipGetLastError();
+}

@@ -11,11 +11,18 @@
 //  * filtered: thresholds for top-k (k-th largest z) and top-p (smallest set whose mass
 //    reaches top_p of the top-k mass) are found by bisection on z, then Gumbel-max runs over
 //    the surviving entries. No sort, no [B, V] temporaries.
-// The reported log-prob is log_softmax(logit / T)[token] over the FULL vocabulary (before
-// filtering), which is what the trainer recomputes.
+//  * frequency / presence penalties: a request that asks for them owns a row of a token-count table
+//    (`counts`, int16 [slots, count_ld]); its logits become logit - freq * count - pres * (count > 0)
+//    before the temperature, in every pass, and the kernel bumps the count of the token it draws.
+//  * rows flagged inactive (`active[row] == 0`: finished inside a multi-step decode plan) return at
+//    once with token 0.
+// The reported log-prob is log_softmax(adjusted logit / T)[token] over the FULL vocabulary (before
+// top-k / top-p filtering); without penalties this is what the trainer recomputes.
 // Randomness: Philox keyed by (seed, row, step) where `step` is read from device memory and
 // can be bumped by the kernel itself, so a captured graph replays with fresh noise.
 #include "common.hpp"
+
+typedef short i16x8 __attribute__((ext_vector_type(8)));
 
 struct ArgMax {
   float v;
@@ -65,16 +72,41 @@ DEVINL void load8(const float* p, float* z) {
   for (int j = 0; j < 4; ++j) { z[j] = a[j]; z[4 + j] = b[j]; }
 }
 
+// One row of logits with its penalties: z_i = (logit_i - freq * count_i - pres * [count_i > 0]) / T.
+template <typename T>
+struct Row {
+  const T* p;
+  const int16_t* cnt;  // this request's token counts, or nullptr
+  float freq, pres, inv_t;
+  DEVINL float adjust(float x, int c) const { return x - freq * (float)c - (c > 0 ? pres : 0.f); }
+  DEVINL float z1(int i) const {
+    float x = ldz(p, i);
+    if (cnt) x = adjust(x, cnt[i]);
+    return x * inv_t;
+  }
+  // entries [i8, i8 + 8), i8 a multiple of 8 (16-byte loads of the logits and of the counts)
+  DEVINL void z8(int i8, float* z) const {
+    load8(p + i8, z);
+    if (cnt) {
+      const i16x8 c = *reinterpret_cast<const i16x8*>(cnt + i8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = adjust(z[j], c[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] *= inv_t;
+  }
+};
+
 // f(i, z_i) over one row: vector loads over [0, V8), scalar loads over the tail [V8, V)
 template <typename T, typename F>
-DEVINL void for_each_z(const T* p, int V, int V8, float inv_t, F f) {
+DEVINL void for_each_z(const Row<T>& r, int V, int V8, F f) {
   for (int i8 = threadIdx.x * 8; i8 < V8; i8 += blockDim.x * 8) {
     float z[8];
-    load8(p + i8, z);
+    r.z8(i8, z);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f(i8 + j, z[j] * inv_t);
+    for (int j = 0; j < 8; ++j) f(i8 + j, z[j]);
   }
-  for (int i = V8 + threadIdx.x; i < V; i += blockDim.x) f(i, ldz(p, i) * inv_t);
+  for (int i = V8 + threadIdx.x; i < V; i += blockDim.x) f(i, r.z1(i));
 }
 
 DEVINL float gumbel(uint32_t bits) { return -__logf(-__logf(u32_to_unit(bits) * 0.99999994f)); }
@@ -84,11 +116,20 @@ __global__ __launch_bounds__(1024) void sample_kernel(
     const T* __restrict__ logits, int64_t ld, int V, const float* __restrict__ temperature,
     const int* __restrict__ top_k, const float* __restrict__ top_p, uint64_t seed,
     const int64_t* __restrict__ step_ptr, int64_t* __restrict__ out_tok,
-    float* __restrict__ out_logp) {
+    float* __restrict__ out_logp, const int* __restrict__ active, int16_t* __restrict__ counts,
+    int64_t count_ld, const int* __restrict__ count_slot, const float* __restrict__ freq_pen,
+    const float* __restrict__ pres_pen) {
   __shared__ float red[16];
   __shared__ float redv[16];
   __shared__ int redi[16];
   const int row = blockIdx.x;
+  if (active && !active[row]) {  // uniform over the block
+    if (threadIdx.x == 0) {
+      out_tok[row] = 0;
+      if (out_logp) out_logp[row] = 0.f;
+    }
+    return;
+  }
   const T* p = logits + (size_t)row * ld;
   const float temp = temperature ? temperature[row] : 1.f;
   const bool greedy = temp <= 0.f;
@@ -100,6 +141,14 @@ __global__ __launch_bounds__(1024) void sample_kernel(
   // noise word of entry i: word i & 3 of the Philox block with counter ctr0 + i / 4
   const uint64_t ctr0 = step * (uint64_t)((V + 3) / 4);
   const int V8 = (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? (V & ~7) : 0;
+  const int slot = (counts && count_slot) ? count_slot[row] : -1;
+  int16_t* cnt = slot >= 0 ? counts + (size_t)slot * count_ld : nullptr;  // count_ld is a multiple of 8
+  Row<T> R;
+  R.p = p;
+  R.cnt = cnt;
+  R.freq = cnt && freq_pen ? freq_pen[row] : 0.f;
+  R.pres = cnt && pres_pen ? pres_pen[row] : 0.f;
+  R.inv_t = inv_t;
 
   // pass 1: running max / sum-exp (rescaled when the max moves) and min of z. Without filtering the
   // arg-max of z (+ Gumbel noise unless greedy) is taken in the same pass, so the row is read once.
@@ -111,11 +160,10 @@ __global__ __launch_bounds__(1024) void sample_kernel(
   best.i = 0x7fffffff;
   for (int i8 = threadIdx.x * 8; i8 < V8; i8 += blockDim.x * 8) {
     float z[8];
-    load8(p + i8, z);
+    R.z8(i8, z);
     float m8 = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      z[j] *= inv_t;
       m8 = fmaxf(m8, z[j]);
       mn = fminf(mn, z[j]);
     }
@@ -143,7 +191,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(
     }
   }
   for (int i = V8 + threadIdx.x; i < V; i += blockDim.x) {
-    const float z = ldz(p, i) * inv_t;
+    const float z = R.z1(i);
     mn = fminf(mn, z);
     if (z > mx) {
       se *= __expf(mx - z);
@@ -174,13 +222,13 @@ __global__ __launch_bounds__(1024) void sample_kernel(
       for (int it = 0; it < 32; ++it) {
         const float mid = 0.5f * (lo + hi);
         float cnt = 0.f;
-        for_each_z(p, V, V8, inv_t, [&](int, float z) { cnt += z >= mid ? 1.f : 0.f; });
+        for_each_z(R, V, V8, [&](int, float z) { cnt += z >= mid ? 1.f : 0.f; });
         cnt = block_sum(cnt, red);
         if (cnt >= (float)k) lo = mid; else hi = mid;
       }
       thr = lo;
       float mk = 0.f;
-      for_each_z(p, V, V8, inv_t, [&](int, float z) { mk += z >= thr ? __expf(z - mx) : 0.f; });
+      for_each_z(R, V, V8, [&](int, float z) { mk += z >= thr ? __expf(z - mx) : 0.f; });
       mass_k = block_sum(mk, red);
     }
     if (tp < 1.f) {
@@ -190,7 +238,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(
       for (int it = 0; it < 32; ++it) {
         const float mid = 0.5f * (lo + hi);
         float ms = 0.f;
-        for_each_z(p, V, V8, inv_t, [&](int, float z) { ms += z >= mid ? __expf(z - mx) : 0.f; });
+        for_each_z(R, V, V8, [&](int, float z) { ms += z >= mid ? __expf(z - mx) : 0.f; });
         ms = block_sum(ms, red);
         if (ms >= target) lo = mid; else hi = mid;
       }
@@ -203,7 +251,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(
       for (int j = 0; j < 4; ++j) {
         const int i = i4 + j;
         if (i < V) {
-          const float z = ldz(p, i) * inv_t;
+          const float z = R.z1(i);
           if (z >= thr) {
             ArgMax c;
             c.v = z + gumbel(r[j]);
@@ -219,7 +267,8 @@ __global__ __launch_bounds__(1024) void sample_kernel(
     int tok = best.i;
     if (tok < 0 || tok >= V) tok = 0;
     out_tok[row] = tok;
-    if (out_logp) out_logp[row] = ldz(p, tok) * inv_t - lse;
+    if (out_logp) out_logp[row] = R.z1(tok) - lse;
+    if (cnt && cnt[tok] < 32767) cnt[tok] += 1;
   }
 }
 
@@ -230,14 +279,19 @@ __global__ void bump_step_kernel(int64_t* step_ptr) {
 extern "C" int areal_sample(const void* logits, int dtype, int B, int V, int64_t ld,
                             const float* temperature, const int* top_k, const float* top_p,
                             uint64_t seed, int64_t* step_ptr, int bump_step, int64_t* out_tok,
-                            float* out_logp, hipStream_t st) {
+                            float* out_logp, const int* active, int16_t* counts, int64_t count_ld,
+                            const int* count_slot, const float* freq_pen, const float* pres_pen,
+                            hipStream_t st) {
   if (B == 0) return 0;
+  if (counts && (count_ld % 8 != 0 || count_ld < V)) return (int)hipErrorInvalidValue;
   if (dtype == 0)
     hipLaunchKernelGGL(sample_kernel<bf16_t>, dim3(B), dim3(1024), 0, st, (const bf16_t*)logits, ld, V,
-                       temperature, top_k, top_p, seed, step_ptr, out_tok, out_logp);
+                       temperature, top_k, top_p, seed, step_ptr, out_tok, out_logp, active, counts, count_ld,
+                       count_slot, freq_pen, pres_pen);
   else
     hipLaunchKernelGGL(sample_kernel<float>, dim3(B), dim3(1024), 0, st, (const float*)logits, ld, V,
-                       temperature, top_k, top_p, seed, step_ptr, out_tok, out_logp);
+                       temperature, top_k, top_p, seed, step_ptr, out_tok, out_logp, active, counts, count_ld,
+                       count_slot, freq_pen, pres_pen);
   if (bump_step && step_ptr)
     hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(64), 0, st, step_ptr);
   return (int)hipGetLastError();

@@ -5,8 +5,14 @@
 // whose token prefix hashes to the same chain share the page (ref-counted). Unreferenced cached
 // pages stay resident until the allocator needs them (LRU). A weight update invalidates the
 // cache because cached K/V were produced by older parameters.
+//
+// A hit is never trusted on the hash alone: every cached page keeps the tokens it holds, a match compares
+// them with the request's tokens, and a chain stops being published at the first page whose key is
+// already taken by different tokens. By induction over the chain, the K/V of a matched page were computed
+// under exactly the request's prefix.
 #pragma once
 #include <cstdint>
+#include <cstring>
 #include <deque>
 #include <list>
 #include <unordered_map>
@@ -30,7 +36,8 @@ class BlockManager {
  public:
   explicit BlockManager(int num_pages, bool enable_prefix_cache = true)
       : num_pages_(num_pages), enable_cache_(enable_prefix_cache), ref_(num_pages, 0),
-        page_hash_(num_pages, 0), cached_(num_pages, 0), in_lru_(num_pages, 0) {
+        page_hash_(num_pages, 0), cached_(num_pages, 0), in_lru_(num_pages, 0),
+        page_tokens_(enable_prefix_cache ? (size_t)num_pages * PAGE : 0, 0) {
     // page 0 is reserved as the scratch page that padded / inactive rows write into
     for (int i = num_pages - 1; i >= 1; --i) free_.push_back(i);
   }
@@ -38,6 +45,11 @@ class BlockManager {
   int num_free() const { return (int)free_.size() + (int)lru_.size(); }
   int num_total() const { return num_pages_ - 1; }
   int num_cached() const { return (int)hash_to_page_.size(); }
+  int64_t num_collisions() const { return n_collisions_; }
+  // test hook: overwrite the tokens remembered for a cached page (simulates a colliding key)
+  void corrupt_page_tokens_for_test(int p) {
+    if (!page_tokens_.empty()) page_tokens_[(size_t)p * PAGE] ^= 0x5a5a5a;
+  }
 
   // Allocate n fresh pages (evicting unreferenced cached pages if needed). Returns false and
   // allocates nothing when fewer than n are available.
@@ -98,6 +110,10 @@ class BlockManager {
       h = hash_page(h, toks + matched, PAGE);
       auto it = hash_to_page_.find(h);
       if (it == hash_to_page_.end()) break;
+      if (!same_tokens(it->second, toks + matched)) {  // hash collision: not this prefix
+        ++n_collisions_;
+        break;
+      }
       add_ref(it->second);
       pages.push_back(it->second);
       matched += PAGE;
@@ -113,11 +129,18 @@ class BlockManager {
     for (int i = 0; i < full && i < (int)pages.size(); ++i) {
       h = hash_page(h, toks + i * PAGE, PAGE);
       int p = pages[i];
-      if (cached_[p]) continue;
-      if (hash_to_page_.count(h)) continue;  // another page already serves this prefix
+      if (cached_[p] && page_hash_[p] == h) continue;  // matched from the cache earlier, or published before
+      auto it = hash_to_page_.find(h);
+      if (it != hash_to_page_.end()) {
+        if (same_tokens(it->second, toks + i * PAGE)) continue;  // another page already serves this prefix
+        ++n_collisions_;
+        break;  // key taken by other tokens: deeper pages of this chain could not be verified, stop here
+      }
+      if (cached_[p]) break;  // page is published under another key (cannot happen for owned pages)
       hash_to_page_[h] = p;
       page_hash_[p] = h;
       cached_[p] = 1;
+      std::memcpy(&page_tokens_[(size_t)p * PAGE], toks + i * PAGE, PAGE * sizeof(int32_t));
     }
   }
 
@@ -134,6 +157,9 @@ class BlockManager {
   }
 
  private:
+  bool same_tokens(int p, const int32_t* toks) const {
+    return std::memcmp(&page_tokens_[(size_t)p * PAGE], toks, PAGE * sizeof(int32_t)) == 0;
+  }
   void evict(int p) {
     if (cached_[p]) {
       hash_to_page_.erase(page_hash_[p]);
@@ -149,6 +175,8 @@ class BlockManager {
   std::list<int> lru_;
   std::unordered_map<int, std::list<int>::iterator> lru_pos_;
   std::unordered_map<uint64_t, int> hash_to_page_;
+  std::vector<int32_t> page_tokens_;  // [num_pages, PAGE]: tokens of every cached page
+  int64_t n_collisions_ = 0;
 };
 
 }  // namespace areal

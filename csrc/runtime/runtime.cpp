@@ -28,6 +28,7 @@ static py::array_t<T> to_np(const std::vector<T>& v) {
 static py::dict plan_to_dict(const Plan& p) {
   py::dict d;
   d["kind"] = p.kind;
+  d["plan_id"] = p.plan_id;
   d["req_ids"] = to_np(p.req_ids);
   d["input_ids"] = to_np(p.input_ids);
   d["positions"] = to_np(p.positions);
@@ -35,6 +36,9 @@ static py::dict plan_to_dict(const Plan& p) {
   d["temperature"] = to_np(p.temperature);
   d["top_p"] = to_np(p.top_p);
   d["top_k"] = to_np(p.top_k);
+  d["frequency_penalty"] = to_np(p.frequency_penalty);
+  d["presence_penalty"] = to_np(p.presence_penalty);
+  d["penalty_slot"] = to_np(p.penalty_slot);
   if (p.kind == 1) {
     d["cu_q"] = to_np(p.cu_q);
     d["cu_k"] = to_np(p.cu_k);
@@ -42,24 +46,39 @@ static py::dict plan_to_dict(const Plan& p) {
     d["max_k"] = p.max_k;
     d["has_prefix"] = p.has_prefix;
     d["ctx_slots"] = to_np(p.ctx_slots);
+    d["chunk_end"] = to_np(p.chunk_end);
+    d["sample"] = to_np(p.sample);
   } else if (p.kind == 2) {
     d["n_steps"] = p.n_steps;
+    d["continuation"] = p.continuation;
     d["context_lens"] = to_np(p.context_lens);
     d["max_pages"] = p.max_pages;
     py::array_t<int32_t> bt({(py::ssize_t)p.req_ids.size(), (py::ssize_t)p.max_pages});
     if (!p.block_tables.empty())
       std::memcpy(bt.mutable_data(), p.block_tables.data(), p.block_tables.size() * sizeof(int32_t));
     d["block_tables"] = bt;
+    d["remaining"] = to_np(p.remaining);
+    d["min_remaining"] = to_np(p.min_remaining);
+    py::array_t<int32_t> stops({(py::ssize_t)(p.stop_ids.size() / MAX_DEVICE_STOP_IDS),
+                                (py::ssize_t)MAX_DEVICE_STOP_IDS});
+    if (!p.stop_ids.empty())
+      std::memcpy(stops.mutable_data(), p.stop_ids.data(), p.stop_ids.size() * sizeof(int32_t));
+    d["stop_ids"] = stops;
+    d["kill"] = to_np(p.kill);
   }
   return d;
 }
 
+// Plans stay here from `schedule` until their results are processed (two can be open at once: a decode
+// plan and its continuation). `plan_id < 0` addresses the plan scheduled last.
 class PyScheduler {
  public:
   explicit PyScheduler(const SchedulerConfig& cfg) : s_(cfg) {}
   int64_t add_request(const std::string& rid, const std::vector<int32_t>& prompt, int max_new_tokens,
                       int min_new_tokens, float temperature, float top_p, int top_k,
-                      const std::vector<int32_t>& stop_token_ids) {
+                      const std::vector<int32_t>& stop_token_ids,
+                      const std::vector<std::vector<int32_t>>& stop_sequences, float frequency_penalty,
+                      float presence_penalty, int penalty_slot) {
     SamplingParams sp;
     sp.max_new_tokens = max_new_tokens;
     sp.min_new_tokens = min_new_tokens;
@@ -67,23 +86,49 @@ class PyScheduler {
     sp.top_p = top_p;
     sp.top_k = top_k;
     sp.stop_token_ids = stop_token_ids;
+    sp.stop_sequences = stop_sequences;
+    sp.frequency_penalty = frequency_penalty;
+    sp.presence_penalty = presence_penalty;
+    sp.penalty_slot = penalty_slot;
+    if ((frequency_penalty != 0.f || presence_penalty != 0.f) && penalty_slot < 0)
+      throw std::runtime_error("add_request: a penalty needs a slot of the token-count table");
     return s_.add_request(rid, prompt, sp);
   }
-  py::dict schedule() {
-    plan_ = s_.schedule();
-    return plan_to_dict(plan_);
+  py::dict remember(Plan&& p) {
+    last_ = p.plan_id;
+    py::dict d = plan_to_dict(p);
+    if (p.kind != 0) open_[p.plan_id] = std::move(p);
+    return d;
+  }
+  py::dict schedule() { return remember(s_.schedule()); }
+  py::dict schedule_continuation(int64_t prev_plan_id, int min_live_rows) {
+    auto it = open_.find(prev_plan_id);
+    if (it == open_.end()) throw std::runtime_error("schedule_continuation: unknown or already processed plan");
+    return remember(s_.schedule_continuation(it->second, min_live_rows));
+  }
+  Plan take(int64_t plan_id) {
+    auto it = open_.find(plan_id < 0 ? last_ : plan_id);
+    if (it == open_.end()) throw std::runtime_error("process: unknown or already processed plan");
+    Plan p = std::move(it->second);
+    open_.erase(it);
+    return p;
   }
   void process_prefill(py::array_t<int64_t, py::array::c_style | py::array::forcecast> toks,
-                       py::array_t<float, py::array::c_style | py::array::forcecast> lps) {
-    if ((size_t)toks.size() < plan_.req_ids.size() || (size_t)lps.size() < plan_.req_ids.size())
+                       py::array_t<float, py::array::c_style | py::array::forcecast> lps, int64_t plan_id) {
+    Plan p = take(plan_id);
+    if (p.kind != 1) throw std::runtime_error("process_prefill: not a prefill plan");
+    if ((size_t)toks.size() < p.req_ids.size() || (size_t)lps.size() < p.req_ids.size())
       throw std::runtime_error("process_prefill: output shorter than the batch");
-    s_.process_prefill(plan_, toks.data(), lps.data());
+    s_.process_prefill(p, toks.data(), lps.data());
   }
   void process_decode(py::array_t<int64_t, py::array::c_style | py::array::forcecast> toks,
-                      py::array_t<float, py::array::c_style | py::array::forcecast> lps) {
-    if (toks.ndim() != 2 || toks.shape(0) < plan_.n_steps || (size_t)toks.shape(1) < plan_.req_ids.size())
+                      py::array_t<float, py::array::c_style | py::array::forcecast> lps, int64_t plan_id,
+                      bool successor_in_flight) {
+    Plan p = take(plan_id);
+    if (p.kind != 2) throw std::runtime_error("process_decode: not a decode plan");
+    if (toks.ndim() != 2 || toks.shape(0) < p.n_steps || (size_t)toks.shape(1) < p.req_ids.size())
       throw std::runtime_error("process_decode: expected [n_steps, >=batch] outputs");
-    s_.process_decode(plan_, toks.data(), lps.data(), (int)toks.shape(1));
+    s_.process_decode(p, toks.data(), lps.data(), (int)toks.shape(1), successor_in_flight);
   }
   py::list take_finished() {
     py::list out;
@@ -95,6 +140,7 @@ class PyScheduler {
       d["output_versions"] = f.output_versions;
       d["finish_reason"] = f.finish_reason;
       d["prompt_len"] = f.prompt_len;
+      d["penalty_slot"] = f.penalty_slot;
       d["latency"] = f.latency;
       d["ttft"] = f.ttft;
       d["itl"] = f.itl;
@@ -103,7 +149,8 @@ class PyScheduler {
     return out;
   }
   Scheduler s_;
-  Plan plan_;
+  std::unordered_map<int64_t, Plan> open_;
+  int64_t last_ = 0;
 };
 
 // ------------------------------------------------------------------------------ datapack
@@ -183,6 +230,7 @@ static py::array_t<int64_t> merge_intervals(py::array_t<int64_t, py::array::c_st
 PYBIND11_MODULE(_runtime, m) {
   m.doc() = "C++ host runtime: rollout scheduler, block manager, sequence packing, interval merging";
   m.attr("PAGE_SIZE") = PAGE;
+  m.attr("MAX_DEVICE_STOP_IDS") = MAX_DEVICE_STOP_IDS;
   py::class_<SchedulerConfig>(m, "SchedulerConfig")
       .def(py::init<>())
       .def_readwrite("num_pages", &SchedulerConfig::num_pages)
@@ -197,10 +245,16 @@ PYBIND11_MODULE(_runtime, m) {
       .def(py::init<const SchedulerConfig&>())
       .def("add_request", &PyScheduler::add_request, py::arg("rid"), py::arg("prompt"), py::arg("max_new_tokens"),
            py::arg("min_new_tokens") = 0, py::arg("temperature") = 1.0f, py::arg("top_p") = 1.0f,
-           py::arg("top_k") = 1 << 30, py::arg("stop_token_ids") = std::vector<int32_t>{})
+           py::arg("top_k") = 1 << 30, py::arg("stop_token_ids") = std::vector<int32_t>{},
+           py::arg("stop_sequences") = std::vector<std::vector<int32_t>>{}, py::arg("frequency_penalty") = 0.f,
+           py::arg("presence_penalty") = 0.f, py::arg("penalty_slot") = -1)
       .def("schedule", &PyScheduler::schedule)
-      .def("process_prefill", &PyScheduler::process_prefill)
-      .def("process_decode", &PyScheduler::process_decode)
+      .def("schedule_continuation", &PyScheduler::schedule_continuation, py::arg("prev_plan_id"),
+           py::arg("min_live_rows") = 1)
+      .def("process_prefill", &PyScheduler::process_prefill, py::arg("tokens"), py::arg("logprobs"),
+           py::arg("plan_id") = -1)
+      .def("process_decode", &PyScheduler::process_decode, py::arg("tokens"), py::arg("logprobs"),
+           py::arg("plan_id") = -1, py::arg("successor_in_flight") = false)
       .def("take_finished", &PyScheduler::take_finished)
       .def("pause", [](PyScheduler& s) { s.s_.pause(); })
       .def("resume", [](PyScheduler& s) { s.s_.resume(); })
@@ -219,6 +273,11 @@ PYBIND11_MODULE(_runtime, m) {
       .def("total_prompt_tokens", [](PyScheduler& s) { return s.s_.total_prompt_tokens(); })
       .def("total_cached_tokens", [](PyScheduler& s) { return s.s_.total_cached_tokens(); })
       .def("num_preemptions", [](PyScheduler& s) { return s.s_.num_preemptions(); })
+      .def("num_prefix_collisions", [](PyScheduler& s) { return s.s_.num_prefix_collisions(); })
+      .def("num_deferred_pages", [](PyScheduler& s) { return s.s_.num_deferred_pages(); })
+      .def("prefill_possible", [](PyScheduler& s) { return s.s_.prefill_possible(); })
+      .def("corrupt_cached_page_for_test",
+           [](PyScheduler& s, int page) { s.s_.block_manager().corrupt_page_tokens_for_test(page); })
       .def("has_work", [](PyScheduler& s) { return s.s_.has_work(); });
   m.def("ffd_allocate", &ffd_allocate, py::arg("values"), py::arg("capacity"), py::arg("min_groups"));
   m.def("partition_balanced", &partition_balanced, py::arg("lens"), py::arg("k"), py::arg("min_size") = 1);

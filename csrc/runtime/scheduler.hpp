@@ -4,10 +4,19 @@
 // asks for a plan (`schedule`), executes it on the GPU (varlen prefill or hipGraph'd multi-step
 // decode), and hands sampled tokens back (`process_prefill` / `process_decode`). Semantics follow the
 // inference-server behaviour the reference relies on (SGLang flags in areal/api/cli_args.py:398-454;
-// abort-on-weight-update protocol in areal/engine/sglang_remote.py:121-309; the slot-refilling
-// generator of realhf/impl/model/nn/real_llm_generate.py:670-888):
-//   * prefill-first scheduling under a token budget (max_prefill_tokens), whole prompts (no chunking),
-//   * decode of all running requests, `decode_steps` tokens per plan,
+// sampling fields of areal/api/cli_args.py:81-133; abort-on-weight-update protocol in
+// areal/engine/sglang_remote.py:121-309; the slot-refilling generator of
+// realhf/impl/model/nn/real_llm_generate.py:670-888):
+//   * prefill-first scheduling under a token budget (max_prefill_tokens); a prompt longer than the
+//     budget is prefilled in chunks over several plans (only the last chunk samples a token),
+//   * decode of all running requests, `decode_steps` tokens per plan. A decode plan can be followed by
+//     a CONTINUATION plan that is scheduled before the first one's tokens are known: same rows, device
+//     state carried over, only page tables refreshed. Rows whose request finished meanwhile stay in
+//     place as dead rows (`kill`), and pages of requests that finish while a successor plan is in
+//     flight are released one plan later, when nothing on the device can write to them any more,
+//   * stop conditions: stop token ids, stop sequences (token-id sequences matched against the tail of
+//     the generated tokens), max_new_tokens, context length; min_new_tokens suppresses stops,
+//   * frequency / presence penalties: requests carry a slot of the runner's token-count table,
 //   * preemption by recompute when the page pool runs dry,
 //   * pause / continue and abort-all for interruptible generation: aborted requests return the tokens
 //     generated so far with finish reason "abort", their pages are released and the prefix cache is
@@ -29,6 +38,8 @@
 
 namespace areal {
 
+constexpr int MAX_DEVICE_STOP_IDS = 8;  // stop ids per row the device checks itself (the host checks all)
+
 struct SamplingParams {
   int max_new_tokens = 16;
   int min_new_tokens = 0;
@@ -36,9 +47,13 @@ struct SamplingParams {
   float top_p = 1.0f;
   int top_k = 1 << 30;
   std::vector<int32_t> stop_token_ids;
+  std::vector<std::vector<int32_t>> stop_sequences;
+  float frequency_penalty = 0.f;
+  float presence_penalty = 0.f;
+  int penalty_slot = -1;  // row of the runner's token-count table (>= 0 iff a penalty is set)
 };
 
-enum class ReqState { WAITING, RUNNING, FINISHED };
+enum class ReqState { WAITING, PREFILLING, RUNNING, FINISHED };
 
 struct Request {
   int64_t id = 0;
@@ -66,28 +81,37 @@ struct FinishedRequest {
   std::string finish_reason;
   int prompt_len = 0;
   int cached_tokens = 0;
+  int penalty_slot = -1;
   double latency = 0, ttft = 0;
   std::vector<float> itl;
 };
 
 struct Plan {
   int kind = 0;  // 0 idle, 1 prefill, 2 decode
-  std::vector<int64_t> req_ids;
+  int64_t plan_id = 0;
+  std::vector<int64_t> req_ids;  // decode continuation: -1 marks a dead row
   // prefill
   std::vector<int32_t> input_ids, positions;
   std::vector<int32_t> cu_q, cu_k;
   std::vector<int64_t> slot_mapping;  // where the new tokens' K/V go
   std::vector<int64_t> ctx_slots;     // slots of ALL context tokens (only when a prefix was reused)
+  std::vector<int32_t> chunk_end;     // per request: context length after this plan
+  std::vector<int32_t> sample;        // per request: 1 = the chunk reaches the end of the prompt, sample a token
   bool has_prefix = false;
   int max_q = 0, max_k = 0;
   // decode
   int n_steps = 0;
+  bool continuation = false;          // rows and device state carried over from the previous decode plan
   std::vector<int32_t> context_lens;
   std::vector<int32_t> block_tables;  // [B, max_pages]
   int max_pages = 0;
+  std::vector<int32_t> remaining;      // tokens the row may still generate (max_new_tokens and context cap)
+  std::vector<int32_t> min_remaining;  // tokens until stop tokens count (min_new_tokens)
+  std::vector<int32_t> stop_ids;       // [B, MAX_DEVICE_STOP_IDS], -1 padded
+  std::vector<int32_t> kill;           // continuation: 1 = the row's request is gone, deactivate it
   // sampling (both kinds)
-  std::vector<float> temperature, top_p;
-  std::vector<int32_t> top_k;
+  std::vector<float> temperature, top_p, frequency_penalty, presence_penalty;
+  std::vector<int32_t> top_k, penalty_slot;
 };
 
 struct SchedulerConfig {
@@ -135,13 +159,17 @@ class Scheduler {
   void set_version(int v) { version_ = v; }
   int version() const { return version_; }
 
-  // Abort everything in flight (weight update). Returns the number of aborted requests.
+  // Abort everything in flight (weight update). The caller must have processed every plan it launched:
+  // pages are released at once. Returns the number of aborted requests.
   int abort_all() {
+    release_deferred();
     int n = 0;
     std::vector<int64_t> ids;
     for (auto id : running_) ids.push_back(id);
+    for (auto id : prefilling_) ids.push_back(id);
     for (auto id : waiting_) ids.push_back(id);
     running_.clear();
+    prefilling_.clear();
     waiting_.clear();
     for (auto id : ids) {
       auto it = reqs_.find(id);
@@ -157,10 +185,12 @@ class Scheduler {
   }
 
   bool abort(const std::string& rid) {
+    release_deferred();
     for (auto& kv : reqs_) {
       if (kv.second->rid == rid) {
         int64_t id = kv.first;
         running_.erase(std::remove(running_.begin(), running_.end(), id), running_.end());
+        prefilling_.erase(std::remove(prefilling_.begin(), prefilling_.end(), id), prefilling_.end());
         waiting_.erase(std::remove(waiting_.begin(), waiting_.end(), id), waiting_.end());
         kv.second->finish_reason = "abort";
         release_pages(*kv.second, false);
@@ -175,9 +205,16 @@ class Scheduler {
   void flush_cache() { bm_.flush_cache(); }
 
   // ------------------------------------------------------------------------------ planning
+  bool prefill_possible() const {
+    return !paused_ && (!prefilling_.empty() ||
+                        (!waiting_.empty() &&
+                         (int)(running_.size() + prefilling_.size()) < cfg_.max_running_requests));
+  }
+
   Plan schedule() {
     Plan p;
-    if (!paused_ && !waiting_.empty() && (int)running_.size() < cfg_.max_running_requests) {
+    p.plan_id = next_plan_++;
+    if (prefill_possible()) {
       plan_prefill(p);
       if (p.kind == 1) return p;
     }
@@ -185,25 +222,80 @@ class Scheduler {
     return p;
   }
 
+  // A decode plan that follows `prev` (a decode plan whose results are NOT processed yet) on the same
+  // rows: device-side state (tokens, positions, slots, activity) carries over, only page tables and the
+  // kill mask travel. Returns kind 0 when a normal plan has to be made instead: a prefill is due, the
+  // batch would fit a much smaller bucket, or pages for the extra steps cannot be had without preemption.
+  Plan schedule_continuation(const Plan& prev, int min_live_rows) {
+    Plan p;
+    p.plan_id = next_plan_++;
+    if (prev.kind != 2 || paused_ || prefill_possible()) return p;
+    const int k = std::max(1, cfg_.decode_steps);
+    int live = 0, need_total = 0;
+    for (auto id : prev.req_ids) {
+      auto it = id < 0 ? reqs_.end() : reqs_.find(id);
+      if (it == reqs_.end() || it->second->state != ReqState::RUNNING) continue;
+      ++live;
+      const Request& r = *it->second;
+      // positions written by `prev` (not processed yet) and by this plan
+      int last_pos = std::min((int)r.tokens.size() - 1 + (2 * k - 1), cfg_.context_length - 1);
+      need_total += std::max(0, pages_for(last_pos + 1) - (int)r.pages.size());
+    }
+    if (live == 0 || live < min_live_rows || live != (int)running_.size() || need_total > bm_.num_free()) return p;
+    p.kind = 2;
+    p.n_steps = k;
+    p.continuation = true;
+    int max_pages = 0;
+    for (auto id : prev.req_ids) {
+      auto it = id < 0 ? reqs_.end() : reqs_.find(id);
+      if (it == reqs_.end() || it->second->state != ReqState::RUNNING) continue;
+      Request& r = *it->second;
+      int last_pos = std::min((int)r.tokens.size() - 1 + (2 * k - 1), cfg_.context_length - 1);
+      int need = pages_for(last_pos + 1) - (int)r.pages.size();
+      if (need > 0) bm_.allocate(need, r.pages);
+      max_pages = std::max(max_pages, (int)r.pages.size());
+    }
+    p.max_pages = max_pages;
+    const size_t B = prev.req_ids.size();
+    p.block_tables.assign(B * (size_t)max_pages, 0);
+    p.req_ids.assign(B, -1);
+    p.kill.assign(B, 1);
+    for (size_t row = 0; row < B; ++row) {
+      int64_t id = prev.req_ids[row];
+      auto it = id < 0 ? reqs_.end() : reqs_.find(id);
+      if (it == reqs_.end() || it->second->state != ReqState::RUNNING) continue;
+      Request& r = *it->second;
+      p.req_ids[row] = id;
+      p.kill[row] = 0;
+      std::copy(r.pages.begin(), r.pages.end(), p.block_tables.begin() + row * max_pages);
+    }
+    return p;
+  }
+
   // ---------------------------------------------------------------------- result handling
   void process_prefill(const Plan& p, const int64_t* tokens, const float* logprobs) {
+    release_deferred();
     double t = now_s();
     for (size_t i = 0; i < p.req_ids.size(); ++i) {
       auto it = reqs_.find(p.req_ids[i]);
       if (it == reqs_.end()) continue;
       Request& r = *it->second;
-      r.num_cached = (int)r.tokens.size();
+      r.num_cached = p.chunk_end[i];
+      if (!p.sample[i]) continue;  // more chunks of this prompt to come
       bm_.publish(r.tokens.data(), r.num_cached, r.pages);
       append_token(r, (int32_t)tokens[i], logprobs[i], t);
     }
-    sweep_finished();
+    sweep_finished(false);
   }
 
-  // tokens / logprobs are [n_steps, B_padded] row-major with row stride `stride`.
-  void process_decode(const Plan& p, const int64_t* tokens, const float* logprobs, int stride) {
+  // tokens / logprobs are [n_steps, B_padded] row-major with row stride `stride`. `successor_in_flight`:
+  // a continuation of this plan is already running on the device.
+  void process_decode(const Plan& p, const int64_t* tokens, const float* logprobs, int stride,
+                      bool successor_in_flight = false) {
+    release_deferred();  // what the plan before this one left behind: nothing can touch those pages now
     double t = now_s();
     for (size_t i = 0; i < p.req_ids.size(); ++i) {
-      auto it = reqs_.find(p.req_ids[i]);
+      auto it = p.req_ids[i] < 0 ? reqs_.end() : reqs_.find(p.req_ids[i]);
       if (it == reqs_.end()) continue;
       Request& r = *it->second;
       for (int s = 0; s < p.n_steps; ++s) {
@@ -212,7 +304,7 @@ class Scheduler {
         append_token(r, (int32_t)tokens[(size_t)s * stride + i], logprobs[(size_t)s * stride + i], t);
       }
     }
-    sweep_finished();
+    sweep_finished(successor_in_flight);
   }
 
   std::vector<FinishedRequest> take_finished() {
@@ -222,7 +314,7 @@ class Scheduler {
   }
 
   int num_waiting() const { return (int)waiting_.size(); }
-  int num_running() const { return (int)running_.size(); }
+  int num_running() const { return (int)(running_.size() + prefilling_.size()); }
   int num_free_pages() const { return bm_.num_free(); }
   int num_total_pages() const { return bm_.num_total(); }
   int num_cached_pages() const { return bm_.num_cached(); }
@@ -230,40 +322,83 @@ class Scheduler {
   int64_t total_prompt_tokens() const { return total_prompt_; }
   int64_t total_cached_tokens() const { return total_cached_; }
   int64_t num_preemptions() const { return n_preempt_; }
-  bool has_work() const { return !waiting_.empty() || !running_.empty(); }
+  int64_t num_prefix_collisions() const { return bm_.num_collisions(); }
+  int num_deferred_pages() const {
+    int n = 0;
+    for (auto& z : deferred_) n += (int)z->pages.size();
+    return n;
+  }
+  std::vector<int> deferred_pages() const {
+    std::vector<int> out;
+    for (auto& z : deferred_) out.insert(out.end(), z->pages.begin(), z->pages.end());
+    return out;
+  }
+  bool has_work() const { return !waiting_.empty() || !running_.empty() || !prefilling_.empty(); }
+  BlockManager& block_manager() { return bm_; }
 
  private:
   static int pages_for(int ntok) { return (ntok + PAGE - 1) / PAGE; }
 
-  void fill_sampling(Plan& p, const Request& r) {
+  void fill_sampling(Plan& p, const Request& r, bool sampled = true) {
     p.temperature.push_back(r.sp.temperature);
     p.top_p.push_back(r.sp.top_p);
     p.top_k.push_back(r.sp.top_k);
+    p.frequency_penalty.push_back(r.sp.frequency_penalty);
+    p.presence_penalty.push_back(r.sp.presence_penalty);
+    p.penalty_slot.push_back(sampled ? r.sp.penalty_slot : -1);
+  }
+
+  // Rows of a prefill plan for request r: tokens [r.num_cached, end).
+  void emit_prefill_rows(Plan& p, Request& r, int end) {
+    const int n = (int)r.tokens.size();
+    const int start = r.num_cached;
+    for (int t = start; t < end; ++t) {
+      p.input_ids.push_back(r.tokens[t]);
+      p.positions.push_back(t);
+      p.slot_mapping.push_back((int64_t)r.pages[t / PAGE] * PAGE + t % PAGE);
+    }
+    p.cu_q.push_back(p.cu_q.back() + (end - start));
+    p.cu_k.push_back(p.cu_k.back() + end);
+    p.max_q = std::max(p.max_q, end - start);
+    p.max_k = std::max(p.max_k, end);
+    p.req_ids.push_back(r.id);
+    p.chunk_end.push_back(end);
+    p.sample.push_back(end == n ? 1 : 0);
+    if (start > 0) p.has_prefix = true;
+    fill_sampling(p, r, end == n);
   }
 
   void plan_prefill(Plan& p) {
-    int budget = cfg_.max_prefill_tokens;
+    int budget = std::max(1, cfg_.max_prefill_tokens);
     int reserve = (int)(running_.size() * cfg_.schedule_conservativeness);
+    p.cu_q.push_back(0);
+    p.cu_k.push_back(0);
+    std::vector<std::pair<int64_t, int>> rows;  // (request, chunk end)
+    // 1. prompts that are part-way through their prefill go first (they already own their pages)
+    for (auto id : prefilling_) {
+      if (budget <= 0) break;
+      Request& r = *reqs_[id];
+      int end = std::min((int)r.tokens.size(), r.num_cached + budget);
+      budget -= end - r.num_cached;
+      rows.emplace_back(id, end);
+    }
+    // 2. new admissions
     if (cfg_.policy == "lpm" && waiting_.size() > 1) sort_waiting_lpm();
-    std::vector<int64_t> admitted;
-    while (!waiting_.empty() && (int)(running_.size() + admitted.size()) < cfg_.max_running_requests) {
+    while (budget > 0 && !waiting_.empty() &&
+           (int)(running_.size() + prefilling_.size()) < cfg_.max_running_requests) {
       int64_t id = waiting_.front();
       Request& r = *reqs_[id];
       int n = (int)r.tokens.size();
       std::vector<int> pages;
       int matched = bm_.match_prefix(r.tokens.data(), n, pages);
-      int new_tok = n - matched;
-      if (new_tok > budget && !admitted.empty()) {
-        bm_.release_all(pages);
-        break;
-      }
       // pages for the whole context plus the first generated token
       int need = pages_for(n + 1) - (int)pages.size();
       if (need > bm_.num_free() - reserve) {
         bm_.release_all(pages);
-        if (admitted.empty() && running_.empty() && need <= bm_.num_free()) {
+        const bool alone = rows.empty() && running_.empty() && prefilling_.empty();
+        if (alone && need <= bm_.num_free()) {
           // nothing else is running: ignore the reserve so a single large request can proceed
-        } else if (admitted.empty() && running_.empty()) {
+        } else if (alone) {
           // can never fit in the page pool: fail the request instead of stalling the queue
           waiting_.pop_front();
           r.finish_reason = "length";
@@ -274,7 +409,6 @@ class Scheduler {
           break;
         }
         matched = bm_.match_prefix(r.tokens.data(), n, pages);
-        new_tok = n - matched;
         need = pages_for(n + 1) - (int)pages.size();
       }
       if (!bm_.allocate(need, pages)) {
@@ -284,40 +418,30 @@ class Scheduler {
       waiting_.pop_front();
       r.pages = std::move(pages);
       r.num_cached = matched;
-      r.state = ReqState::RUNNING;
-      total_prompt_ += new_tok;
+      r.state = ReqState::PREFILLING;
+      prefilling_.push_back(id);
+      total_prompt_ += n - matched;
       total_cached_ += matched;
-      budget -= new_tok;
-      admitted.push_back(id);
-      if (matched > 0) p.has_prefix = true;
-      if (budget <= 0) break;
+      int end = std::min(n, matched + budget);
+      budget -= end - matched;
+      rows.emplace_back(id, end);
     }
-    if (admitted.empty()) return;
+    if (rows.empty()) return;
     p.kind = 1;
-    p.cu_q.push_back(0);
-    p.cu_k.push_back(0);
-    for (auto id : admitted) {
-      Request& r = *reqs_[id];
-      int n = (int)r.tokens.size();
-      int start = r.num_cached;
-      for (int t = start; t < n; ++t) {
-        p.input_ids.push_back(r.tokens[t]);
-        p.positions.push_back(t);
-        p.slot_mapping.push_back((int64_t)r.pages[t / PAGE] * PAGE + t % PAGE);
-      }
-      p.cu_q.push_back(p.cu_q.back() + (n - start));
-      p.cu_k.push_back(p.cu_k.back() + n);
-      p.max_q = std::max(p.max_q, n - start);
-      p.max_k = std::max(p.max_k, n);
-      p.req_ids.push_back(id);
-      fill_sampling(p, r);
-      running_.push_back(id);
-    }
+    for (auto& [id, end] : rows) emit_prefill_rows(p, *reqs_[id], end);
     if (p.has_prefix) {
-      for (auto id : admitted) {
+      for (auto& [id, end] : rows) {
         Request& r = *reqs_[id];
-        int n = (int)r.tokens.size();
-        for (int t = 0; t < n; ++t) p.ctx_slots.push_back((int64_t)r.pages[t / PAGE] * PAGE + t % PAGE);
+        for (int t = 0; t < end; ++t) p.ctx_slots.push_back((int64_t)r.pages[t / PAGE] * PAGE + t % PAGE);
+      }
+    }
+    // rows whose last chunk is in this plan start decoding after it
+    for (auto& [id, end] : rows) {
+      Request& r = *reqs_[id];
+      if (end == (int)r.tokens.size()) {
+        prefilling_.erase(std::remove(prefilling_.begin(), prefilling_.end(), id), prefilling_.end());
+        r.state = ReqState::RUNNING;
+        running_.push_back(id);
       }
     }
   }
@@ -346,6 +470,7 @@ class Scheduler {
     for (auto id : running_) max_pages = std::max(max_pages, (int)reqs_[id]->pages.size());
     p.max_pages = max_pages;
     p.block_tables.assign(running_.size() * (size_t)max_pages, 0);
+    p.stop_ids.assign(running_.size() * (size_t)MAX_DEVICE_STOP_IDS, -1);
     size_t row = 0;
     for (auto id : running_) {
       Request& r = *reqs_[id];
@@ -356,6 +481,12 @@ class Scheduler {
       p.context_lens.push_back(pos + 1);
       p.slot_mapping.push_back((int64_t)r.pages[pos / PAGE] * PAGE + pos % PAGE);
       std::copy(r.pages.begin(), r.pages.end(), p.block_tables.begin() + row * max_pages);
+      p.remaining.push_back(std::max(
+          1, std::min(r.sp.max_new_tokens - r.n_generated(), cfg_.context_length - (int)r.tokens.size())));
+      p.min_remaining.push_back(std::max(0, r.sp.min_new_tokens - r.n_generated()));
+      for (size_t j = 0; j < r.sp.stop_token_ids.size() && j < (size_t)MAX_DEVICE_STOP_IDS; ++j)
+        p.stop_ids[row * MAX_DEVICE_STOP_IDS + j] = r.sp.stop_token_ids[j];
+      p.kill.push_back(0);
       fill_sampling(p, r);
       ++row;
     }
@@ -389,6 +520,17 @@ class Scheduler {
     for (size_t i = 0; i < n; ++i) waiting_[i] = keyed[i].second;
   }
 
+  // does the tail of the generated tokens equal one of the request's stop sequences?
+  static bool ends_with_stop_sequence(const Request& r) {
+    const int gen = r.n_generated();
+    for (auto& seq : r.sp.stop_sequences) {
+      const int L = (int)seq.size();
+      if (L == 0 || L > gen) continue;
+      if (std::equal(seq.begin(), seq.end(), r.tokens.end() - L)) return true;
+    }
+    return false;
+  }
+
   void append_token(Request& r, int32_t tok, float lp, double t) {
     r.tokens.push_back(tok);
     r.logprobs.push_back(lp);
@@ -398,11 +540,13 @@ class Scheduler {
     else r.itl.push_back((float)(t - r.t_last));
     r.t_last = t;
     int gen = r.n_generated();
-    bool stop_tok = false;
-    if (gen >= r.sp.min_new_tokens)
+    bool stop = false;
+    if (gen >= r.sp.min_new_tokens) {
       for (auto s : r.sp.stop_token_ids)
-        if (s == tok) { stop_tok = true; break; }
-    if (stop_tok) {
+        if (s == tok) { stop = true; break; }
+      if (!stop && !r.sp.stop_sequences.empty()) stop = ends_with_stop_sequence(r);
+    }
+    if (stop) {
       r.finish_reason = "stop";
       r.state = ReqState::FINISHED;
     } else if (gen >= r.sp.max_new_tokens || (int)r.tokens.size() >= cfg_.context_length) {
@@ -411,19 +555,32 @@ class Scheduler {
     }
   }
 
-  void sweep_finished() {
+  // Finished requests leave the running list and are delivered at once. Their pages go back to the pool
+  // now, or - `defer` - after the next processed plan: a successor plan already running on the device
+  // still writes K/V for those rows.
+  void sweep_finished(bool defer) {
     std::vector<int64_t> keep;
     for (auto id : running_) {
-      Request& r = *reqs_[id];
+      auto it = reqs_.find(id);
+      Request& r = *it->second;
       if (r.state == ReqState::FINISHED) {
-        release_pages(r, true);
         finish(r);
-        reqs_.erase(id);
+        if (defer) {
+          deferred_.push_back(std::move(it->second));
+        } else {
+          release_pages(r, true);
+        }
+        reqs_.erase(it);
       } else {
         keep.push_back(id);
       }
     }
     running_.swap(keep);
+  }
+
+  void release_deferred() {
+    for (auto& z : deferred_) release_pages(*z, true);
+    deferred_.clear();
   }
 
   void release_pages(Request& r, bool publish) {
@@ -441,6 +598,7 @@ class Scheduler {
     f.output_versions = r.versions;
     f.finish_reason = r.finish_reason;
     f.prompt_len = r.prompt_len;
+    f.penalty_slot = r.sp.penalty_slot;
     f.latency = r.t_finish - r.t_arrive;
     f.ttft = r.t_first > 0 ? r.t_first - r.t_arrive : 0;
     f.itl = r.itl;
@@ -452,9 +610,11 @@ class Scheduler {
   BlockManager bm_;
   std::unordered_map<int64_t, std::unique_ptr<Request>> reqs_;
   std::deque<int64_t> waiting_;
+  std::vector<int64_t> prefilling_;  // admitted, prompt not completely prefilled yet (own their pages)
   std::vector<int64_t> running_;
+  std::vector<std::unique_ptr<Request>> deferred_;  // finished, pages still possibly written by the device
   std::vector<FinishedRequest> finished_;
-  int64_t next_id_ = 1;
+  int64_t next_id_ = 1, next_plan_ = 1;
   bool paused_ = false;
   int version_ = 0;
   int64_t total_generated_ = 0, total_prompt_ = 0, total_cached_ = 0, n_preempt_ = 0;

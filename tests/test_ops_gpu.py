@@ -458,6 +458,90 @@ def test_sampling_distribution_and_filters():
     assert set(tok.tolist()) <= nucleus
 
 
+@pytest.mark.parametrize("V", [1000, 151936, 517])
+def test_sampler_penalties_and_inactive_rows(V):
+    """Rows with a slot of the token-count table sample from logit - f * count - p * (count > 0) and bump the
+    count of what they draw; rows flagged inactive are skipped. Greedy rows make the comparison exact."""
+    torch.manual_seed(13)
+    B = 12
+    logits = (2 * torch.randn(B, V, device=DEV)).bfloat16()
+    counts = ops.TokenCounts(8, V, DEV)
+    counts.table[:, :V] = (torch.rand(8, V, device=DEV) < 0.3).short() * torch.randint(1, 5, (8, V), device=DEV).short()
+    before = counts.table.clone()
+    slot = torch.tensor([0, -1, 3, 7, -1, 2, 2, 5, -1, 1, 4, 6], dtype=torch.int32, device=DEV)
+    slot[6] = -1
+    freq = torch.rand(B, device=DEV) * 2
+    pres = torch.rand(B, device=DEV)
+    active = torch.ones(B, dtype=torch.int32, device=DEV)
+    active[3] = 0
+    active[8] = 0
+    temp = torch.zeros(B, device=DEV)  # greedy
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    tok, lp = ops.sample(logits, temp, None, None, seed=3, step=step, active=active, counts=counts, count_slot=slot,
+                         freq_pen=freq, pres_pen=pres)
+    for b in range(B):
+        if not active[b]:
+            assert tok[b] == 0 and lp[b] == 0
+            continue
+        row = logits[b].float()
+        if slot[b] >= 0:
+            c = before[slot[b], :V].float()
+            row = row - freq[b] * c - pres[b] * (c > 0).float()
+        want = int(row.argmax())
+        assert int(tok[b]) == want
+        assert abs(float(lp[b]) - float(torch.log_softmax(row, -1)[want])) < 2e-3
+    want_counts = before.clone()
+    for b in range(B):
+        if active[b] and slot[b] >= 0:
+            want_counts[slot[b], tok[b]] += 1
+    assert torch.equal(counts.table, want_counts)
+    # sampled rows: a token with an enormous count is never drawn, its neighbours keep their relative odds
+    hot = logits[0].float().argmax()
+    counts.table.zero_()
+    counts.table[0, hot] = 30000
+    t1 = torch.ones(B, device=DEV)
+    all0 = torch.zeros(B, dtype=torch.int32, device=DEV)
+    big = torch.full((B,), 10.0, device=DEV)
+    same = logits[0:1].repeat(B, 1)
+    for _ in range(20):
+        counts.table.zero_()
+        counts.table[0, hot] = 30000
+        tok, lp = ops.sample(same, t1, None, None, seed=9, step=step, counts=counts, count_slot=all0, freq_pen=big,
+                             pres_pen=torch.zeros(B, device=DEV))
+        assert (tok != hot).all()
+
+
+def test_decode_advance_and_begin_kernels_match_their_cpu_twins():
+    """Device bookkeeping of a multi-step decode plan (early exit on stop ids / budget, kill mask of a
+    continuation plan) against the PyTorch twins the CPU engine runs."""
+    torch.manual_seed(14)
+    B, max_pages, n_stop = 300, 6, 8
+    g = torch.Generator().manual_seed(1)
+    st = dict(
+        input_ids=torch.randint(0, 50, (B,), generator=g), positions=torch.randint(0, 150, (B,), generator=g).int(),
+        block_tables=torch.randint(1, 500, (B, max_pages), generator=g).int(), active=(torch.rand(B, generator=g) < 0.8).int(),
+        remaining=torch.randint(1, 4, (B,), generator=g).int(), min_remaining=torch.randint(0, 3, (B,), generator=g).int(),
+        stop_ids=torch.where(torch.rand(B, n_stop, generator=g) < 0.3, torch.randint(0, 6, (B, n_stop), generator=g),
+                             torch.full((B, n_stop), -1)).int())
+    st["context_lens"] = st["positions"] + 1
+    st["slots"] = torch.randint(0, 5000, (B,), generator=g)
+    kill = (torch.rand(B, generator=g) < 0.2).int()
+    cpu = {k: v.clone() for k, v in st.items()}
+    dev = {k: v.clone().to(DEV) for k, v in st.items()}
+    ops.decode_begin_(kill, cpu["active"], cpu["positions"], cpu["context_lens"], cpu["slots"], cpu["block_tables"])
+    ops.decode_begin_(kill.to(DEV), dev["active"], dev["positions"], dev["context_lens"], dev["slots"], dev["block_tables"])
+    for k in cpu:
+        assert torch.equal(dev[k].cpu(), cpu[k]), f"decode_begin: {k}"
+    for step in range(4):
+        sampled = torch.randint(0, 6, (B,), generator=g)
+        for d, smp in ((cpu, sampled), (dev, sampled.to(DEV))):
+            ops.decode_advance_(smp, d["input_ids"], d["positions"], d["context_lens"], d["slots"], d["block_tables"],
+                                d["active"], d["remaining"], d["min_remaining"], d["stop_ids"])
+        for k in cpu:
+            assert torch.equal(dev[k].cpu(), cpu[k]), f"decode_advance step {step}: {k}"
+    assert 0 < int(cpu["active"].sum()) < B or int(cpu["active"].sum()) == 0
+
+
 # ------------------------------------------------------------------------------ skinny GEMM
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [1, 7, 16, 40, 128, 200])

@@ -170,5 +170,180 @@ def test_scheduler_stress_under_address_and_ub_sanitizers():
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="halt_on_error=1"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "stress ok" in r.stdout and "runtime error" not in r.stderr
-    n_preempt = int(r.stdout.strip().split()[-2])
-    assert n_preempt > 0  # the pool was tight enough to exercise preemption
+    import re
+
+    counts = {k: int(v) for v, k in re.findall(r"(\d+) (preemptions|partial prefill chunks|continuation plans|"
+                                               r"deferred releases|stop-sequence finishes)", r.stdout)}
+    # the pool was tight enough to exercise preemption, and every newer code path ran as well
+    assert len(counts) == 5 and all(v > 0 for v in counts.values()), r.stdout
+
+
+# ------------------------------------------------------------------ stop sequences / penalties / chunks
+def _add(s, rid, prompt, max_new, **kw):
+    return s.add_request(rid, prompt, max_new, kw.get("min_new", 0), 1.0, 1.0, 1 << 30, kw.get("stop_ids", []),
+                         kw.get("stop_sequences", []), kw.get("freq", 0.0), kw.get("pres", 0.0), kw.get("slot", -1))
+
+
+def test_stop_sequence_matches_tail_of_generated_tokens_across_plans():
+    s = _sched(decode_steps=2)
+    stream = [11, 12, 13, 14, 15, 16, 17, 18]
+    _add(s, "a", [13, 14, 3], 50, stop_sequences=[[13, 14], [99]])  # the PROMPT ending in 13 14 does not count
+    _add(s, "b", [1, 2, 3], 50, stop_sequences=[[14, 15, 16]])  # straddles a plan boundary (steps 4|5 and 6)
+    _add(s, "c", [1, 2, 3], 50, stop_sequences=[[11]], min_new=3)  # too early: min_new_tokens not reached
+    done = _drive(s, lambda rid, pos: stream[(pos - 3) % len(stream)])
+    assert done["a"]["finish_reason"] == "stop" and done["a"]["output_tokens"] == [11, 12, 13, 14]
+    assert done["b"]["finish_reason"] == "stop" and done["b"]["output_tokens"] == [11, 12, 13, 14, 15, 16]
+    assert done["c"]["finish_reason"] == "stop" and done["c"]["output_tokens"] == stream + [11]
+
+
+def test_prompt_longer_than_the_prefill_budget_is_prefilled_in_chunks():
+    s = _sched(num_pages=64, max_prefill=32, ctx=512)
+    long_prompt = list(range(100, 200))  # 100 tokens -> chunks of 32, 32, 32, 4
+    _add(s, "long", long_prompt, 3)
+    seen, samples = [], []
+    for _ in range(4):
+        plan = s.schedule()
+        assert plan["kind"] == 1 and len(plan["input_ids"]) <= 32
+        seen += plan["input_ids"].tolist()
+        samples.append(int(plan["sample"][0]))
+        assert plan["positions"].tolist() == list(range(len(seen) - len(plan["input_ids"]), len(seen)))
+        assert int(plan["cu_k"][1]) == len(seen) == int(plan["chunk_end"][0])
+        # later chunks attend to the earlier ones through the page table
+        assert bool(plan["has_prefix"]) == (len(seen) > 32) and (len(plan["ctx_slots"]) == len(seen)) == (len(seen) > 32)
+        if len(seen) < 100:
+            assert s.num_running() == 1 and not s.take_finished()
+        s.process_prefill([7], [-0.5], plan["plan_id"])
+    assert seen == long_prompt and samples == [0, 0, 0, 1]
+    # a short prompt that arrives mid-way shares a plan with the next chunk, within the budget
+    _add(s, "long2", list(range(300, 350)), 2)
+    p1 = s.schedule()
+    s.process_prefill([7], [-0.5], p1["plan_id"])
+    _add(s, "short", [5, 6, 7], 2)
+    p2 = s.schedule()
+    assert p1["kind"] == p2["kind"] == 1 and len(p1["input_ids"]) == 32
+    assert len(p2["req_ids"]) == 2 and p2["sample"].tolist() == [1, 1] and len(p2["input_ids"]) == 18 + 3
+    s.process_prefill([7, 7], [-0.5, -0.5], p2["plan_id"])
+    done = _drive(s, lambda rid, pos: 7)
+    assert {k: len(v["output_tokens"]) for k, v in done.items()} == {"long": 3, "long2": 2, "short": 2}
+    assert s.num_free_pages() == s.num_total_pages()
+
+
+def test_continuation_plan_keeps_rows_and_defers_page_release():
+    s = _sched(num_pages=64, decode_steps=2, prefix=False)
+    _add(s, "a", [1, 2, 3], 40, stop_ids=[99])
+    _add(s, "b", [4, 5, 6, 7], 40, stop_ids=[99])
+    p = s.schedule()
+    s.process_prefill([8, 8], [-1.0, -1.0], p["plan_id"])
+    A = s.schedule()
+    assert A["kind"] == 2 and not A["continuation"] and A["kill"].tolist() == [0, 0]
+    assert A["remaining"].tolist() == [39, 39] and A["stop_ids"][:, 0].tolist() == [99, 99]
+    B = s.schedule_continuation(A["plan_id"], 1)  # scheduled BEFORE A's tokens are known
+    assert B["kind"] == 2 and B["continuation"] and B["req_ids"].tolist() == A["req_ids"].tolist()
+    free = s.num_free_pages()
+    # A's tokens: request "a" draws its stop token in the first step
+    s.process_decode(np.array([[99, 8], [8, 8]]), np.full((2, 2), -1.0, np.float32), A["plan_id"], True)
+    fin = s.take_finished()
+    assert [f["rid"] for f in fin] == ["a"] and fin[0]["output_tokens"] == [8, 99]
+    # delivered at once, but B (in flight) may still write K/V for that row: its pages are not free yet
+    assert s.num_deferred_pages() > 0 and s.num_free_pages() == free
+    C = s.schedule_continuation(B["plan_id"], 1)
+    assert C["kind"] == 2 and C["kill"].tolist() == [1, 0] and C["req_ids"].tolist() == [-1, int(A["req_ids"][1])]
+    assert not C["block_tables"][0].any()
+    s.process_decode(np.full((2, 2), 8), np.full((2, 2), -1.0, np.float32), B["plan_id"], True)
+    assert s.num_deferred_pages() == 0 and s.num_free_pages() > free  # B is done: now they are
+    # a continuation is refused when the batch would fit the next smaller bucket, or a prefill is due
+    assert s.schedule_continuation(C["plan_id"], 2)["kind"] == 0
+    _add(s, "c", [9, 9, 9], 4)
+    assert s.prefill_possible() and s.schedule_continuation(C["plan_id"], 1)["kind"] == 0
+    s.process_decode(np.full((2, 2), 8), np.full((2, 2), -1.0, np.float32), C["plan_id"], False)
+    done = _drive(s, lambda rid, pos: 8)
+    assert len(done["b"]["output_tokens"]) == 40 and s.num_free_pages() == s.num_total_pages()
+
+
+def test_prefix_cache_hit_is_checked_against_the_stored_tokens():
+    s = _sched(num_pages=32, prefix=True)
+    prompt = list(range(2, 2 + 70))
+    _add(s, "a", prompt, 2)
+    _drive(s, lambda rid, pos: 5)
+    _add(s, "b", prompt, 2)
+    plan = s.schedule()
+    assert plan["has_prefix"] and len(plan["input_ids"]) == 6  # both full pages come from the cache
+    first_page = int(plan["ctx_slots"][0]) // rt.PAGE_SIZE
+    s.process_prefill([5], [-1.0], plan["plan_id"])
+    _drive(s, lambda rid, pos: 5)
+    # same hash key, different tokens behind it (what a 64-bit collision would look like): no hit
+    s.corrupt_cached_page_for_test(first_page)
+    _add(s, "c", prompt, 2)
+    plan = s.schedule()
+    assert not plan["has_prefix"] and len(plan["input_ids"]) == 70 and s.num_prefix_collisions() >= 1
+    s.process_prefill([5], [-1.0], plan["plan_id"])
+    _drive(s, lambda rid, pos: 5)
+    assert s.num_free_pages() == s.num_total_pages()
+
+
+def test_penalties_travel_with_a_count_table_slot():
+    s = _sched()
+    with pytest.raises(RuntimeError):
+        _add(s, "x", [1, 2, 3], 4, freq=0.5)  # a penalty without a slot
+    _add(s, "a", [1, 2, 3], 2, freq=0.5, pres=0.25, slot=3)
+    _add(s, "b", [1, 2, 3], 2)
+    p = s.schedule()
+    assert p["penalty_slot"].tolist() == [3, -1] and p["frequency_penalty"].tolist() == [0.5, 0.0]
+    assert p["presence_penalty"].tolist() == [0.25, 0.0]
+    s.process_prefill([5, 5], [-1.0, -1.0], p["plan_id"])
+    d = s.schedule()
+    assert d["kind"] == 2 and d["penalty_slot"].tolist() == [3, -1]
+    s.process_decode(np.full((1, 2), 5), np.full((1, 2), -1.0, np.float32), d["plan_id"])
+    slots = {f["rid"]: f["penalty_slot"] for f in s.take_finished()}
+    assert slots == {"a": 3, "b": -1}  # handed back with the result so that the engine can recycle the row
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_device_early_exit_agrees_with_the_scheduler(seed):
+    """The bookkeeping the decode graph runs per sampled token (`decode_advance_`, CPU twin of the kernel) retires
+    a row exactly where the scheduler ends the request: stop ids after min_new_tokens, max_new_tokens, context cap."""
+    import torch
+
+    from areal_vllm_amd import ops
+
+    rng = np.random.RandomState(seed)
+    k = 6
+    s = _sched(num_pages=128, max_running=8, decode_steps=k, ctx=48, prefix=False)
+    n = 8
+    for i in range(n):
+        _add(s, f"r{i}", [3] * int(rng.randint(2, 30)), int(rng.randint(1, 30)), min_new=int(rng.randint(0, 5)),
+             stop_ids=[1, 2] if i % 2 else [1])
+    p = s.schedule()
+    s.process_prefill(rng.randint(1, 6, n).tolist(), [-1.0] * n, p["plan_id"])
+    s.take_finished()
+    while s.has_work():
+        plan = s.schedule()
+        assert plan["kind"] == 2
+        B = len(plan["req_ids"])
+        st = dict(input_ids=torch.from_numpy(plan["input_ids"].astype(np.int64)), positions=torch.from_numpy(plan["positions"].copy()),
+                  context_lens=torch.from_numpy(plan["context_lens"].copy()), slots=torch.from_numpy(plan["slot_mapping"].copy()),
+                  block_tables=torch.from_numpy(plan["block_tables"].copy()), active=torch.ones(B, dtype=torch.int32),
+                  remaining=torch.from_numpy(plan["remaining"].copy()), min_remaining=torch.from_numpy(plan["min_remaining"].copy()),
+                  stop_ids=torch.from_numpy(plan["stop_ids"].copy()))
+        toks = rng.randint(1, 6, (k, B))
+        alive_after = np.zeros((k, B), dtype=bool)
+        for j in range(k):
+            ops.decode_advance_(torch.from_numpy(toks[j].astype(np.int64)), st["input_ids"], st["positions"], st["context_lens"],
+                                st["slots"], st["block_tables"], st["active"], st["remaining"], st["min_remaining"], st["stop_ids"])
+            alive_after[j] = st["active"].numpy().astype(bool)
+        ids = plan["req_ids"].tolist()
+        s.process_decode(toks, np.full((k, B), -1.0, np.float32), plan["plan_id"])
+        gone = {f["rid"]: f for f in s.take_finished()}
+        # rows the device still counts as active are exactly the requests the scheduler keeps running
+        nxt = s.schedule() if s.has_work() else None
+        still = set(nxt["req_ids"].tolist()) if nxt is not None else set()
+        assert {ids[i] for i in range(B) if alive_after[-1, i]} == still
+        if nxt is not None:  # and their device-side state is what the next plan would upload
+            for i in range(B):
+                if alive_after[-1, i]:
+                    r = nxt["req_ids"].tolist().index(ids[i])
+                    assert int(st["positions"][i]) == int(nxt["positions"][r]) and int(st["input_ids"][i]) == int(nxt["input_ids"][r])
+                    assert int(st["slots"][i]) == int(nxt["slot_mapping"][r]) and int(st["remaining"][i]) == int(nxt["remaining"][r])
+            s.process_decode(np.full((k, len(nxt["req_ids"])), 1), np.full((k, len(nxt["req_ids"])), -1.0, np.float32),
+                             nxt["plan_id"])  # token 1 stops everyone whose min_new_tokens allow it
+            s.take_finished()

@@ -5,6 +5,11 @@
 Builds the model with random weights, fabricates decode plans (sequential page tables, every sequence at
 `ctx` tokens) and replays the `decode_steps`-step graph. Prints ms per decode step and tokens/s. Run it
 under ``rocprofv3 --kernel-trace --stats`` for the per-kernel split (``--iters 3`` is enough then).
+
+Two ways of driving the same plans are timed: plan by plan (upload everything, replay, wait for the tokens -
+the device idles while the host books a plan and prepares the next) and pipelined (the continuation of a plan
+is launched before the plan's tokens are awaited: only page tables travel, the device goes from one replay
+into the next). The difference between the two is the host gap per plan.
 """
 import argparse
 import os
@@ -22,8 +27,8 @@ from areal_vllm_amd.models.transformer import Transformer  # noqa: E402
 from areal_vllm_amd.ops.attention import PAGE_SIZE  # noqa: E402
 
 
-def make_plan(B, ctx, steps, max_pages, V, page_base=0):
-    pages_per_seq = (ctx + steps + PAGE_SIZE - 1) // PAGE_SIZE + 1
+def make_plan(B, ctx, steps, max_pages, V, page_base=0, pages_per_seq=None):
+    pages_per_seq = pages_per_seq or (ctx + steps + PAGE_SIZE - 1) // PAGE_SIZE + 1
     bt = np.zeros((B, pages_per_seq), dtype=np.int32)
     for b in range(B):
         bt[b] = page_base + b * pages_per_seq + np.arange(pages_per_seq)
@@ -59,23 +64,43 @@ def main():
     model.init_weights(seed=1)
     batches = [int(b) for b in args.batch.split(",")]
     maxb = max(batches)
-    pages_per_seq = (args.ctx + args.steps + PAGE_SIZE - 1) // PAGE_SIZE + 1
-    runner = ModelRunner(model, maxb * pages_per_seq + 8, args.ctx + 64, maxb, decode_steps=args.steps,
+    grow = args.steps * (args.iters + 2)  # every plan appends `steps` tokens to every sequence
+    pages_per_seq = (args.ctx + grow + PAGE_SIZE - 1) // PAGE_SIZE + 1
+    runner = ModelRunner(model, maxb * pages_per_seq + 8, args.ctx + grow + 64, maxb, decode_steps=args.steps,
                          use_graph=not args.no_graph, buckets=batches)
     for kc, vc in runner.kv:  # non-trivial cache contents (softmax over zeros is cheaper than real data)
         kc.normal_(0, 0.5)
         vc.normal_(0, 0.5)
     for B in batches:
-        plan = make_plan(B, args.ctx, args.steps, runner.max_pages, cfg.vocab_size)
-        runner.decode(plan)
+        plans = [make_plan(B, args.ctx + i * args.steps, args.steps, runner.max_pages, cfg.vocab_size,
+                           pages_per_seq=pages_per_seq) for i in range(args.iters + 1)]
+        runner.decode(plans[0])
         torch.cuda.synchronize()
+        # plan by plan: full upload, replay, wait
         t0 = time.perf_counter()
-        for _ in range(args.iters):
-            runner.decode(plan)
+        for i in range(args.iters):
+            runner.decode(plans[i])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / (args.iters * args.steps)
         print(f"B={B:4d} ctx={args.ctx}: {dt * 1e3:7.3f} ms/step  {B / dt:9.0f} tok/s  "
-              f"({dt * 1e6 / cfg.n_layers:6.1f} us/layer incl. head+sampler)", flush=True)
+              f"({dt * 1e6 / cfg.n_layers:6.1f} us/layer incl. head+sampler)  [plan by plan]", flush=True)
+        # pipelined: the continuation is launched before the previous plan's tokens are read
+        cont = dict(req_ids=plans[0]["req_ids"], n_steps=args.steps, continuation=True, max_pages=pages_per_seq,
+                    block_tables=plans[0]["block_tables"], kill=np.zeros(B, np.int32))
+        runner.decode(plans[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cur = runner.decode_launch(plans[0])
+        for i in range(1, args.iters):
+            nxt = runner.decode_launch(cont)
+            runner.decode_wait(cur)
+            cur = nxt
+        runner.decode_wait(cur)
+        torch.cuda.synchronize()
+        dp = (time.perf_counter() - t0) / (args.iters * args.steps)
+        print(f"B={B:4d} ctx={args.ctx}: {dp * 1e3:7.3f} ms/step  {B / dp:9.0f} tok/s  "
+              f"({dp * 1e6 / cfg.n_layers:6.1f} us/layer incl. head+sampler)  [pipelined]  "
+              f"host gap removed: {(dt - dp) * args.steps * 1e3:6.3f} ms per {args.steps}-step plan", flush=True)
 
 
 if __name__ == "__main__":
