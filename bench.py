@@ -60,6 +60,8 @@ def parse_args():
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--kv-cache-gb", type=float, default=24.0)
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--gradient-checkpointing", action="store_true",
+                   help="recompute block activations in the backward (long-context configurations)")
     p.add_argument("--eta", type=int, default=2, help="max_head_offpolicyness; 0 = synchronous RL")
     p.add_argument("--retain-kv", action="store_true",
                    help="keep the KV cache of running generations across weight updates (no re-prefill)")
@@ -169,6 +171,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank == 0:  # long configurations say nothing for minutes: a line a minute shows the run is alive
+        import threading
+
+        t_start = time.perf_counter()
+
+        def heartbeat():
+            while True:
+                time.sleep(60)
+                print(f"[bench] running, {time.perf_counter() - t_start:.0f} s since start", file=sys.stderr, flush=True)
+
+        threading.Thread(target=heartbeat, daemon=True, name="bench-heartbeat").start()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -232,7 +245,7 @@ def main():
     actor_cfg = PPOActorConfig(
         experiment_name="bench", trial_name="bench", path=args.model, init_from_scratch=True,
         dtype="bfloat16" if on_gpu else "float32",
-        gradient_checkpointing=False, mb_spec=MicroBatchSpec(max_tokens_per_mb=args.max_tokens_per_mb),
+        gradient_checkpointing=args.gradient_checkpointing, mb_spec=MicroBatchSpec(max_tokens_per_mb=args.max_tokens_per_mb),
         optimizer=OptimizerConfig(type="adam", lr=1.7e-5, weight_decay=0.017, beta1=0.9, beta2=0.999, eps=1e-8,
                                   lr_scheduler_type="constant", gradient_clipping=1.0, warmup_steps_proportion=0.001),
         group_size=args.n_samples, eps_clip=0.4, temperature=1.0, reward_scaling=10.0, reward_bias=-0.5, kl_ctl=0.0,
@@ -485,7 +498,8 @@ def main():
                        "interrupt_on_weight_update": "retain-kv" if args.retain_kv else "abort+recompute",
                        "algo": "GRPO, decoupled PPO loss, recompute_logprob, ppo_n_minibatches=1"
                                + (", proximal log-probs fused into the training forward" if args.fuse_prox else ""),
-                       "max_tokens_per_mb": args.max_tokens_per_mb, "decode_steps_per_plan": args.decode_steps},
+                       "max_tokens_per_mb": args.max_tokens_per_mb, "decode_steps_per_plan": args.decode_steps,
+                       "gradient_checkpointing": bool(args.gradient_checkpointing)},
         }
         sys.stdout.flush()
         os.dup2(result_fd, 1)

@@ -202,6 +202,85 @@ def test_flash_attn_separate_streams_fwd_bwd():
     assert float(qkv.grad[:, Hq:].abs().max()) == 0.0 and float(kv.grad[:8].abs().max()) == 0.0
 
 
+def _blockwise_attention_ref(q, k, v, lens_q, lens_k, g, block=2048):
+    """fp32 causal attention (bottom-right aligned) and its gradients for long packed sequences, on the GPU.
+    Query blocks of `block` rows bound the score matrix to [Hq, block, L_k]; each block backpropagates on its
+    own, the gradients accumulate in the fp32 leaves. -> out, dq, dk, dv (all fp32)."""
+    Hq, Hkv, D = q.shape[1], k.shape[1], q.shape[2]
+    rep = Hq // Hkv
+    qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    out = torch.empty_like(qf)
+    sq = sk = 0
+    for lq, lk in zip(lens_q, lens_k):
+        kk = kf[sk:sk + lk].transpose(0, 1).repeat_interleave(rep, 0)  # [Hq, lk, D]
+        vv = vf[sk:sk + lk].transpose(0, 1).repeat_interleave(rep, 0)
+        for b0 in range(0, lq, block):
+            b1 = min(lq, b0 + block)
+            qq = qf[sq + b0:sq + b1].transpose(0, 1)  # [Hq, rows, D]
+            last = lk - lq + b1  # keys visible to the block's last row
+            scores = torch.matmul(qq, kk[:, :last].transpose(1, 2)) / math.sqrt(D)
+            rows = torch.arange(b0, b1, device=q.device).unsqueeze(1) + (lk - lq)
+            cols = torch.arange(last, device=q.device).unsqueeze(0)
+            scores = scores.masked_fill(cols > rows, float("-inf"))
+            o = torch.matmul(torch.softmax(scores, -1), vv[:, :last]).transpose(0, 1)
+            out[sq + b0:sq + b1] = o.detach()
+            (o * g[sq + b0:sq + b1].float()).sum().backward()
+        sq, sk = sq + lq, sk + lk
+    return out, qf.grad, kf.grad, vf.grad
+
+
+def _close_long(a, b, name):
+    """Long-context bound: bf16 outputs of O(1) values - every element within 0.03 absolute / 3 % relative of the
+    fp32 reference, plus the usual <0.1 % allowance at half that tolerance."""
+    a, b = a.float(), b.float()
+    assert torch.isfinite(a).all(), f"{name}: non-finite values"
+    err = (a - b).abs()
+    worst = (err / (0.03 + 0.03 * b.abs())).max().item()
+    assert worst <= 1.0, f"{name}: max error {err.max().item():.4g} exceeds the hard bound ({worst:.2f}x)"
+    bad = (err > 0.015 + 0.015 * b.abs()).float().mean().item()
+    assert bad < 1e-3, f"{name}: {bad:.3g} of the elements miss the tight tolerance"
+
+
+@pytest.mark.parametrize("lens", [[4096], [8192, 300], [16384], [32768], [5000, 12000, 1]])
+def test_flash_attn_long_context_fwd_bwd(lens):
+    """Packed self-attention at 4k-32k tokens per sequence (the long-generation configurations), forward and
+    backward, against the blockwise fp32 reference with a hard per-element bound."""
+    torch.manual_seed(21)
+    D, Hq, Hkv = 128, 4, 2
+    T = sum(lens)
+    cu = torch.tensor([0] + np.cumsum(lens).tolist(), dtype=torch.int32, device=DEV)
+    qkv = (0.5 * torch.randn(T, Hq + 2 * Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
+    out = ops.flash_attn_varlen_qkv(qkv, cu, max(lens), Hq, Hkv)
+    g = torch.randn_like(out)
+    out.backward(g)
+    ref, dq, dk, dv = _blockwise_attention_ref(qkv[:, :Hq], qkv[:, Hq:Hq + Hkv], qkv[:, Hq + Hkv:], lens, lens, g)
+    _close_long(out, ref, f"out {lens}")
+    _close_long(qkv.grad[:, :Hq], dq, f"dq {lens}")
+    _close_long(qkv.grad[:, Hq:Hq + Hkv], dk, f"dk {lens}")
+    _close_long(qkv.grad[:, Hq + Hkv:], dv, f"dv {lens}")
+
+
+@pytest.mark.parametrize("lq,lk", [([1024], [16384]), ([4096, 100], [32768, 8292]), ([8192], [8192])])
+def test_flash_attn_long_context_q_shorter_than_k_bwd(lq, lk):
+    """A query chunk against a longer key range (context-parallel ring steps, chunked prefill) at long context:
+    bottom-right aligned causal mask, gradients of q, k and v."""
+    torch.manual_seed(22)
+    D, Hq, Hkv = 128, 4, 2
+    cu_q = torch.tensor([0] + np.cumsum(lq).tolist(), dtype=torch.int32, device=DEV)
+    cu_k = torch.tensor([0] + np.cumsum(lk).tolist(), dtype=torch.int32, device=DEV)
+    q = (0.5 * torch.randn(sum(lq), Hq, D, device=DEV)).bfloat16().requires_grad_(True)
+    k = (0.5 * torch.randn(sum(lk), Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
+    v = (0.5 * torch.randn(sum(lk), Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
+    out = ops.flash_attn_varlen_sep(q, k, v, cu_q, cu_k, max(lq), max(lk))
+    g = torch.randn_like(out)
+    out.backward(g)
+    ref, dq, dk, dv = _blockwise_attention_ref(q, k, v, lq, lk, g)
+    _close_long(out, ref, "out")
+    _close_long(q.grad, dq, "dq")
+    _close_long(k.grad, dk, "dk")
+    _close_long(v.grad, dv, "dv")
+
+
 @pytest.mark.parametrize("Hq,Hkv,D", [(12, 2, 128), (28, 4, 128), (8, 8, 128), (16, 2, 64)])
 @pytest.mark.parametrize("nsplit", [1, 4])
 def test_paged_decode_and_cache_write(Hq, Hkv, D, nsplit):

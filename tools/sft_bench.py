@@ -68,3 +68,5 @@ print(f"forward scoring : {t_fwd * 1e3:8.1f} ms/step  {T / t_fwd:9.0f} tokens/s 
       f"({100 * fwd_flops / t_fwd / 2.5e15:4.1f}% of dense bf16 peak)")
 print(f"train step      : {t_train * 1e3:8.1f} ms/step  {T / t_train:9.0f} tokens/s  {3 * fwd_flops / t_train / 1e12:6.0f} TFLOP/s "
       f"({100 * 3 * fwd_flops / t_train / 2.5e15:4.1f}% of dense bf16 peak)")
+print(f"peak device memory: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB allocated, "
+      f"{torch.cuda.max_memory_reserved() / 2**30:.1f} GiB reserved")
