@@ -26,8 +26,8 @@ def main():
     total = sum(r[2] for r in rows)
     print("kernel,calls,total_ms,mean_us,percent")
     for name, calls, dur, avg, pct in rows[:a.top]:
-        print(f'"{short(name)}",{calls},{dur / 1e6:.3f},{avg / 1e3:.2f},{pct:.2f}')
-    print(f'"(all {len(rows)} kernels)",{sum(r[1] for r in rows)},{total / 1e6:.3f},,100.00')
+        print(f'"{short(name)}",{calls},{dur / 1e3:.3f},{avg:.2f},{pct:.2f}')  # the view reports microseconds
+    print(f'"(all {len(rows)} kernels)",{sum(r[1] for r in rows)},{total / 1e3:.3f},,100.00')
 
 
 if __name__ == "__main__":
