@@ -3,7 +3,7 @@ models on model workers and the parsing of a train layout string. Role of
 ``realhf/experiments/common/{common,utils}.py`` and the model blocks of ``realhf/api/cli_args.py``."""
 import dataclasses
 import re
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, List, Optional, Tuple
 
 from ..api.alloc_mode import ParallelStrategy
 from ..api.cli_args import MicroBatchSpec, OptimizerConfig
@@ -71,7 +71,9 @@ def symmetric_model_workers(models: Dict[str, ModelTrainEvalConfig], layout: Par
                             trial_name: str, device: str, fileroot: str, realloc_root: str, base_seed: int,
                             datasets: Optional[List[DatasetAbstraction]], tokenizer_path: Optional[str],
                             eval_dataset: Optional[DatasetAbstraction] = None, eval_role: Optional[str] = None,
-                            shuffle_dataset: bool = True) -> List[ModelWorkerConfig]:
+                            shuffle_dataset: bool = True,
+                            replicas: Optional[Dict[ModelName, Tuple[ModelTrainEvalConfig, ParallelStrategy]]] = None,
+                            ) -> List[ModelWorkerConfig]:
     """Every model uses the same (dp, tp, pp) grid over all model workers: worker w hosts shard w of each
     model (the reference calls this the symmetric allocation; with 288 GB per GPU an actor, a reference
     copy and a critic of up to ~30B parameters each fit side by side, so nothing is offloaded)."""
@@ -87,6 +89,14 @@ def symmetric_model_workers(models: Dict[str, ModelTrainEvalConfig], layout: Par
             shards.append(StandaloneModelShard(
                 id=sid, model=model_abstraction(m, experiment_name, trial_name), backend=backend_abstraction(m),
                 eval_dataset=eval_dataset if role == eval_role else None))
+        # further replicas of a role with a layout of their own over the same workers (e.g. a dp-only copy of a
+        # tensor-parallel actor that generates): worker w hosts shard w of that layout as well
+        for rname, (m, lay) in (replicas or {}).items():
+            assert lay.world_size == n, f"replica {rname} must cover all {n} model workers"
+            sid = ModelShardID(rname, dp_rank=(w // lay.tp_size) % lay.dp_size, tp_rank=w % lay.tp_size,
+                               pp_rank=w // (lay.tp_size * lay.dp_size))
+            shards.append(StandaloneModelShard(id=sid, model=model_abstraction(m, experiment_name, trial_name),
+                                               backend=backend_abstraction(m)))
         workers.append(ModelWorkerConfig(base_seed=base_seed, shards=shards, datasets=datasets,
                                          tokenizer_name_or_path=tokenizer_path, device=device, fileroot=fileroot,
                                          realloc_root=realloc_root, shuffle_dataset=shuffle_dataset))

@@ -7,7 +7,7 @@ import dataclasses
 from typing import Any, Dict, List, Optional
 
 from ..api.cli_args import GenerationHyperparameters, MicroBatchSpec
-from ..system.dfg import MFCDef, ModelInterfaceAbstraction, ModelInterfaceType
+from ..system.dfg import MFCDef, ModelInterfaceAbstraction, ModelInterfaceType, ModelName
 from ..system.system_api import (DatasetAbstraction, Experiment, ExperimentConfig, ExperimentSaveEvalControl,
                                  ExperimentScheduling, Scheduling, TasksGroup, register_experiment)
 from .common import resolve_allocation_mode, ModelTrainEvalConfig, parse_layout, symmetric_model_workers
@@ -37,7 +37,7 @@ class PPOHyperparameters:
 
 
 def ppo_rpcs(ppo: PPOHyperparameters, group_size: int, n_seqs: int, mb_spec: MicroBatchSpec, with_gen: bool,
-             with_reward_mfc: bool, reward_args: Optional[Dict[str, Any]] = None) -> List[MFCDef]:
+             with_reward_mfc: bool, reward_args: Optional[Dict[str, Any]] = None, gen_model=None) -> List[MFCDef]:
     """The MFC graph of (a)synchronous PPO; asynchronous runs drop `actor_gen` (rollout workers generate)
     and usually the reward call (the environment scored the answers already)."""
     actor_args = dict(n_minibatches=ppo.ppo_n_minibatches, generation_config=dataclasses.asdict(ppo.gen),
@@ -57,7 +57,8 @@ def ppo_rpcs(ppo: PPOHyperparameters, group_size: int, n_seqs: int, mb_spec: Mic
     gen_keys = ("packed_input_ids", "prompt_mask", "packed_logprobs", "seq_no_eos_mask", "version_start", "version_end")
     if with_gen:
         rpcs.append(MFCDef(name="actor_gen", n_seqs=n_seqs, interface_type=ModelInterfaceType.GENERATE,
-                           interface_impl=actor_itf, model_name="actor", input_keys=("packed_prompts", "task_ids"),
+                           interface_impl=actor_itf, model_name=gen_model or "actor",
+                           input_keys=("packed_prompts", "task_ids"),
                            output_keys=gen_keys, mb_spec=mb_spec))
     if with_reward_mfc:
         rpcs.append(MFCDef(name="rew_inf", n_seqs=n_seqs, interface_type=ModelInterfaceType.INFERENCE,
@@ -103,6 +104,10 @@ class PPOMATHExperiment(Experiment):
     ppo: PPOHyperparameters = dataclasses.field(default_factory=PPOHyperparameters)
     allocation_mode: Optional[str] = None  # e.g. "sglang.d4p1m1+d2p2m1"; overrides layout / server counts
     layout: str = "d1t1p1"
+    # Layout of a second, generation-only copy of the actor over the same workers (tp = pp = 1, e.g. "d4" next to
+    # a "d2t2" trainer). Its weights are re-allocated from the trainer's shards after every actor train step,
+    # worker to worker, without a checkpoint. None: the trainer's own replica generates (needs tp = pp = 1).
+    gen_layout: Optional[str] = None
     dataset: DatasetAbstraction = dataclasses.field(default_factory=lambda: DatasetAbstraction("math_code_prompt"))
     reward_args: Dict[str, Any] = dataclasses.field(default_factory=dict)
     train_bs_n_seqs: int = 8
@@ -130,12 +135,16 @@ class PPOMATHExperiment(Experiment):
     def initial_setup(self) -> ExperimentConfig:
         resolve_allocation_mode(self)
         self.ppo.gen.n_samples = self.group_size
+        replicas, gen_model = None, None
+        if self.gen_layout:
+            gen_model = ModelName("actor", 1)
+            replicas = {gen_model: (dataclasses.replace(self.actor, backend="inference"), parse_layout(self.gen_layout))}
         rpcs = ppo_rpcs(self.ppo, self.group_size, self.train_bs_n_seqs, self.mb_spec, with_gen=True,
-                        with_reward_mfc=True, reward_args=self.reward_args)
+                        with_reward_mfc=True, reward_args=self.reward_args, gen_model=gen_model)
         workers = symmetric_model_workers(
             self._models(), parse_layout(self.layout), self.experiment_name, self.trial_name, self.device, self.fileroot,
             f"{self.fileroot}/param_realloc/{self.experiment_name}/{self.trial_name}", self.seed, [self.dataset],
-            self.actor.tokenizer_path)
+            self.actor.tokenizer_path, replicas=replicas)
         return ExperimentConfig(exp_ctrl=self.exp_ctrl, model_rpcs=rpcs, model_worker=workers, fileroot=self.fileroot)
 
 

@@ -61,6 +61,10 @@ class ModelFunctionCall:
         self.n_model_workers = n_model_workers
         self.topo = model_topos[rpc.model_name]
         self.workers, self.workers_by_dp, self.dp_heads = model_workers_of(rpc.model_name, self.topo, msid2mwid)
+        # workers of the models this call's hooks hand weights to (they take part in the transfer)
+        self.realloc_peers: Dict[ModelName, List[int]] = {
+            h.target: model_workers_of(h.target, model_topos[h.target], msid2mwid)[0]
+            for h in rpc._post_hooks if isinstance(h, ParamReallocHook) and h.target is not None}
         self.batch_taken = asyncio.Event()  # set once this step's batch has left the buffer
 
     # --------------------------------------------------------------------------- dispatch
@@ -90,6 +94,14 @@ class ModelFunctionCall:
         for w in sorted(involved - set(payloads)):
             payloads[w] = Payload(handler=w, handle_name="empty", pre_hooks=["data_transfer"], pre_hook_data=[hook])
         for h in self.rpc._post_hooks:
+            if isinstance(h, ParamReallocHook) and h.target is not None:
+                # a worker-to-worker transfer: every worker of the source AND of the target executes it
+                for w in sorted(set(self.realloc_peers[h.target]) - set(payloads)):
+                    payloads[w] = Payload(handler=w, handle_name="empty")
+                for w in sorted(set(self.workers) | set(self.realloc_peers[h.target])):
+                    payloads[w].post_hooks.append("param_realloc")
+                    payloads[w].post_hook_data.append(dict(source=h.source, target=h.target, eta=h.eta))
+                continue
             for w in self.workers:
                 if isinstance(h, ParamReallocHook):
                     payloads[w].post_hooks.append("param_realloc")

@@ -162,6 +162,12 @@ class ModelWorker(Worker):
         for r in cfg.model_rpcs:
             if r.model_name in self.models:
                 self.interfaces[r.name] = make_interface(r.interface_impl)
+        # further replicas of a role start from replica 0's weights (every worker walks the same list: the
+        # transfers are collective over the workers that host either side)
+        for name in sorted(cfg.model_topos, key=str):
+            first = ModelName(name.role, 0)
+            if name.replica_id > 0 and first in cfg.model_topos:
+                self._realloc_between_replicas(first, name, 1.0)
 
     # ----------------------------------------------------------------------------- handlers
     def _handle_spec(self, _):
@@ -290,7 +296,13 @@ class ModelWorker(Worker):
         self.data_manager.redistribute(hd["meta"], hd["plan"])
 
     def _hook_param_realloc(self, hd: Dict):
-        """Publish the source model's weights for the generation fleet."""
+        """Hand the source model's weights on. With a `target` - another replica of the role hosted by model
+        workers under its own (dp, tp, pp) layout - every destination shard pulls the slices it needs from the
+        source shards that own them (``parallel/param_realloc.py``; the hook of
+        ``realhf/system/model_worker.py:1046-1130``). Without one the weights are published for the
+        generation fleet."""
+        if hd.get("target") is not None:
+            return self._realloc_between_replicas(hd["source"], hd["target"], float(hd.get("eta", 1.0)))
         name = hd["source"]
         model = self.models.get(name)
         if model is None:
@@ -301,6 +313,52 @@ class ModelWorker(Worker):
         if self.grids[name].local_index == 0:
             name_resolve.add(names.model_version(self.experiment_name, self.trial_name, name.role), str(v), replace=True)
             logger.info(f"published weights of {name} version {v} at {path}")
+
+    def _realloc_between_replicas(self, source: ModelName, target: ModelName, eta: float):
+        from ..parallel.param_realloc import Layout, derive_realloc_plan, realloc_parameters
+
+        src_grid, dst_grid = self.grids[source], self.grids[target]
+        src_model, dst_model = self.models.get(source), self.models.get(target)
+        if src_model is None and dst_model is None:
+            return
+        eng = (src_model or dst_model).module
+        mc = eng.model_config
+        key = (source, target)
+        plans = self.__dict__.setdefault("_realloc_plans", {})
+        if key not in plans:
+            assert src_grid.cp == dst_grid.cp == 1 and src_grid.ep == dst_grid.ep == 1, \
+                "parameter re-allocation covers (dp, tp, pp) layouts"
+            dtype = eng.model.flat.flat.dtype
+            plans[key] = derive_realloc_plan(mc, Layout(src_grid.dp, src_grid.tp, src_grid.pp),
+                                             Layout(dst_grid.dp, dst_grid.tp, dst_grid.pp), dtype=dtype)
+        tik = time.perf_counter()
+        n = realloc_parameters(plans[key], list(src_grid.ranks), list(dst_grid.ranks),
+                               src_model.module.model.flat.flat if src_model is not None else None,
+                               dst_model.module.model.flat.flat if dst_model is not None else None, eta=eta)
+        if dst_model is not None:
+            opt = getattr(dst_model.module, "optimizer", None)
+            if opt is not None:  # a trainable target keeps its fp32 master copy in step with the new weights
+                opt.resync_master_from_params()
+            if src_model is not None:
+                dst_model.version.global_step = src_model.version.global_step
+            else:
+                dst_model.version.global_step += 1
+            logger.debug(f"{target} received {n} parameter elements from {source} in "
+                         f"{(time.perf_counter() - tik) * 1e3:.1f} ms")
+        if os.environ.get("AREAL_CHECK_REALLOC", "0") == "1" and eta == 1.0 and src_model is not None \
+                and dst_model is not None:
+            # debugging aid for layouts where every worker hosts a shard of both replicas: the two models, each
+            # gathered over its own grid, must now be the same checkpoint
+            from ..models import hf_io
+
+            a = {k: v.clone() for k, v in hf_io.native_to_hf_state(src_model.module.model)}
+            b = {k: v.clone() for k, v in hf_io.native_to_hf_state(dst_model.module.model)}
+            common = sorted(set(a) & set(b))  # pipeline stages of the two layouts own different layers
+            assert common, "the two replicas share no tensor on this worker"
+            for k in common:
+                assert torch.equal(a[k], b[k]), f"{target} differs from {source} in {k} after the re-allocation"
+            self._realloc_checked = getattr(self, "_realloc_checked", 0) + 1
+            logger.info(f"re-allocation {source} -> {target} verified on {len(common)} tensors")
 
     def _handle_save(self, data: Dict):
         model = self.models.get(data["model_name"])

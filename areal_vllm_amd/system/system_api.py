@@ -194,6 +194,13 @@ class ExperimentConfig:
             if r.interface_type == ModelInterfaceType.TRAIN_STEP and r.role in served and \
                     r.is_dst_of_model_role(r.role) and not any(isinstance(h, ParamReallocHook) for h in r._post_hooks):
                 r.add_post_hook(ParamReallocHook(source=r.model_name, target=None))
+        # replicas of a trained role that live in the worker world under another layout (a generation copy of a
+        # tensor-parallel actor): the last train step of the role hands them its weights, shard to shard
+        for r in self.model_rpcs:
+            if r.interface_type == ModelInterfaceType.TRAIN_STEP and r.is_dst_of_model_role(r.role):
+                for other in sorted((m for m in topos if m.role == r.role and m != r.model_name), key=str):
+                    if not any(isinstance(h, ParamReallocHook) and h.target == other for h in r._post_hooks):
+                        r.add_post_hook(ParamReallocHook(source=r.model_name, target=other))
         src = [r for r in self.model_rpcs if r.is_src]
         train_bs = src[0].n_seqs if src else 1
         for mw in self.model_worker:

@@ -46,6 +46,9 @@ DEVINL float wave_min(float v) {
 }
 
 // 16-byte vector load/store of 8 bf16.
+// v_exp_f32 without the denormal-safe wrapper of exp2f(): softmax terms do not need denormal results
+DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 DEVINL bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 DEVINL void st8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 

@@ -25,7 +25,6 @@ DEVINL f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 // v_exp_f32 directly: exp2f() expands to a denormal-safe sequence (scale, v_exp, ldexp, compare) that the
 // compiler then guards with per-element branches; softmax probabilities do not need denormal results.
-DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 DEVINL int swz_off(int row, int ch) {  // byte offset of 16-byte chunk `ch` of `row`
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mn = fmaxf(m, mx);
     if (__any(mn > m)) {
-      const float alpha = (m == -INFINITY) ? 0.f : exp2f(m - mn);
+      const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mn);
       l *= alpha;
 #pragma unroll
       for (int i = 0; i < DB; ++i) o[i] *= alpha;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
     float ls = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const float pr = (m == -INFINITY) ? 0.f : exp2f(s[r] - m);
+      const float pr = (m == -INFINITY) ? 0.f : fast_exp2(s[r] - m);
       ls += pr;
       pf[r] = f2bf(pr);
     }
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float mw = sm[w * 16 + qq];
-      const float f = (mw == -INFINITY) ? 0.f : exp2f(mw - mm);
+      const float f = (mw == -INFINITY) ? 0.f : fast_exp2(mw - mm);
       acc += so[(w * 16 + qq) * D + d] * f;
       ll += sl[w * 16 + qq] * f;
     }
@@ -166,7 +166,7 @@ __global__ void paged_decode_reduce_kernel(const float* __restrict__ part_o,
   float acc = 0.f, ll = 0.f;
   for (int s = 0; s < nsplit; ++s) {
     const float ms = part_ml[((size_t)bh * nsplit + s) * 2];
-    const float f = (ms == -INFINITY) ? 0.f : exp2f(ms - mm);
+    const float f = (ms == -INFINITY) ? 0.f : fast_exp2(ms - mm);
     acc += part_o[((size_t)bh * nsplit + s) * D + d] * f;
     ll += part_ml[((size_t)bh * nsplit + s) * 2 + 1] * f;
   }

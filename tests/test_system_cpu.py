@@ -273,3 +273,55 @@ def test_null_sft_experiment_runs_the_runtime_without_models(tmp_path):
     # every data-parallel head reports its half of the batch (prompt 3 + answer 2 + eos tokens per row)
     assert all(s["trainDefault/n_seqs"] in (4, 8) and s["trainDefault/n_tokens"] == 6 * s["trainDefault/n_seqs"]
                for s in st), st
+
+
+@pytest.mark.slow
+def test_sync_ppo_generation_replica_is_fed_by_parameter_reallocation(tmp_path, monkeypatch):
+    """The actor trains tensor-parallel (t2) while a second, data-parallel copy of it (d2) generates on the same
+    two workers: after every train step the trainer's shards are re-allocated into the generation copy, worker
+    to worker (no checkpoint); AREAL_CHECK_REALLOC makes the workers compare the two models after each hand-over."""
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters, OptimizerConfig
+    from areal_vllm_amd.apps.main import main_start
+    from areal_vllm_amd.experiments.common import ModelTrainEvalConfig
+    from areal_vllm_amd.experiments.ppo_math_exp import PPOHyperparameters, PPOMATHExperiment
+    from areal_vllm_amd.system.dfg import ModelName, ParamReallocHook
+    from areal_vllm_amd.system.system_api import DatasetAbstraction, ExperimentSaveEvalControl
+
+    monkeypatch.setenv("AREAL_CHECK_REALLOC", "1")
+    root = str(tmp_path)
+    rng = random.Random(0)
+    rows = [dict(query_id=str(i), input_ids=[rng.randint(2, 400) for _ in range(rng.randint(3, 10))], task="math",
+                 solutions=["\\boxed{1}"]) for i in range(16)]
+    p = os.path.join(root, "data.jsonl")
+    with open(p, "w") as f:
+        f.write("\n".join(json.dumps(r) for r in rows))
+    actor = ModelTrainEvalConfig(path="tiny", init_from_scratch=True, dtype="float32", backend="native_train",
+                                 optimizer=OptimizerConfig(lr=1e-3, lr_scheduler_type="constant",
+                                                           warmup_steps_proportion=0.0))
+    ppo = PPOHyperparameters(gen=GenerationHyperparameters(max_new_tokens=8), ppo_n_minibatches=1)
+
+    def exp():
+        return PPOMATHExperiment(experiment_name="t-ppo", trial_name="realloc", actor=actor, ppo=ppo, layout="t2",
+                                 gen_layout="d2", dataset=DatasetAbstraction("math_code_prompt", args=dict(dataset_path=p)),
+                                 reward_args=dict(dataset_path=p), train_bs_n_seqs=4, group_size=2, device="cpu",
+                                 fileroot=root, exp_ctrl=ExperimentSaveEvalControl(total_train_epochs=1, benchmark_steps=2))
+
+    cfg = exp().initial_setup().lazy_init()
+    gen = next(r for r in cfg.model_rpcs if r.name == "actor_gen")
+    train = next(r for r in cfg.model_rpcs if r.name == "actor_train")
+    assert gen.model_name == ModelName("actor", 1)
+    assert [(h.source, h.target) for h in train._post_hooks if isinstance(h, ParamReallocHook)] == \
+        [(ModelName("actor", 0), ModelName("actor", 1))]
+    topos = cfg.model_worker[0].model_topos
+    assert topos[ModelName("actor", 0)].tensor_parallel_size == 2 and topos[ModelName("actor", 1)].data_parallel_size == 2
+    main_start(exp(), "t-ppo", "realloc", fileroot=root, platform="cpu", timeout=400)
+    st = _stats(root, "t-ppo", "realloc")
+    assert len(st) == 2 and all(s["actor_train/update_successful"] == 1.0 for s in st)
+    logs = ""
+    for base, _, files in os.walk(os.path.join(root, "logs")):
+        for fn in files:
+            if fn.startswith("model_worker"):
+                with open(os.path.join(base, fn), errors="ignore") as f:
+                    logs += f.read()
+    # start-up hand-over + one per train step, on both workers
+    assert logs.count("re-allocation actor@0 -> actor@1 verified") >= 2 * 3, logs[-2000:]

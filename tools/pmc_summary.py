@@ -3,8 +3,9 @@
     python tools/pmc_summary.py <dir with *_counter_collection.csv> [more dirs...] > summary.md
 
 Counters of all given runs are merged by kernel name (one --pmc pass can hold only a few counters per
-hardware block, so a profile is several passes). Derived columns: MFMA busy % (MFMA busy cycles over SQ
-busy cycles), bf16 MFMA TFLOP/s (512 flops per MOP unit), LDS bank-conflict % (conflict cycles over LDS
+hardware block, so a profile is several passes). Derived columns: MFMA busy % (share of the SIMD-cycles of the
+kernel in which the matrix pipe was busy: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs of the chip,
+SQ_BUSY_CYCLES over its 32 shader engines, so their plain ratio overstates the figure 32-fold), bf16 MFMA TFLOP/s (512 flops per MOP unit), LDS bank-conflict % (conflict cycles over LDS
 active cycles), HBM read GB and GB/s (FETCH_SIZE is in KiB)."""
 import csv
 import glob
@@ -22,6 +23,10 @@ def short(name: str) -> str:
         return f"hipBLASLt {m.group(1)} {m.group(2)}"
     m = re.match(r"_Z\d+([A-Za-z_0-9]+?)(I|P|v|K)", name)
     return (m.group(1) if m else name)[:48]
+
+
+N_SIMD = 256 * 4  # MI355X: 256 CUs x 4 SIMDs, each with its own MFMA busy counter
+N_SE = 32         # shader engines (4 per XCD), each with its own SQ busy counter
 
 
 def main(dirs):
@@ -46,7 +51,7 @@ def main(dirs):
         n = len(calls[k][any_c])
         t_ns = dur[k][any_c]
         g = lambda name: c.get(name)  # noqa: E731
-        mfma_busy = 100.0 * g("SQ_VALU_MFMA_BUSY_CYCLES") / g("SQ_BUSY_CYCLES") if g("SQ_BUSY_CYCLES") and g("SQ_VALU_MFMA_BUSY_CYCLES") is not None else None
+        mfma_busy = 100.0 * g("SQ_VALU_MFMA_BUSY_CYCLES") / g("SQ_BUSY_CYCLES") * N_SE / N_SIMD if g("SQ_BUSY_CYCLES") and g("SQ_VALU_MFMA_BUSY_CYCLES") is not None else None
         t_m = dur[k].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)
         tfl = g("SQ_INSTS_VALU_MFMA_MOPS_BF16") * 512 / t_m / 1e3 if t_m and g("SQ_INSTS_VALU_MFMA_MOPS_BF16") is not None else None
         lds = 100.0 * g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE") if g("SQ_LDS_IDX_ACTIVE") and g("SQ_LDS_BANK_CONFLICT") is not None else None
