@@ -23,8 +23,8 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 DEVINL f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-// v_exp_f32 directly: exp2f() expands to a denormal-safe sequence (scale, v_exp, ldexp, compare) that the
-// compiler then guards with per-element branches; softmax probabilities do not need denormal results.
+// (exponentials go through fast_exp2 of common.hpp: v_exp_f32 directly; exp2f() expands to a denormal-safe
+// sequence (scale, v_exp, ldexp, compare) that the compiler then guards with per-element branches)
 DEVINL int swz_off(int row, int ch) {  // byte offset of 16-byte chunk `ch` of `row`
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
