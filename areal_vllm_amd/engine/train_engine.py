@@ -160,9 +160,9 @@ class NativeTrainEngine(TrainEngine):
             return
         if parallel_strategy is None:
             parallel_strategy = ParallelStrategy(data_parallel_size=dist.get_world_size())
-        if (getattr(parallel_strategy, "virtual_pipeline_parallel_size", None) or 1) > 1:
-            raise NotImplementedError("interleaved (virtual-stage) pipeline schedules are not implemented; "
-                                      "use contiguous stages (virtual_pipeline_parallel_size=1)")
+        vpp = getattr(parallel_strategy, "virtual_pipeline_parallel_size", None) or 1
+        if vpp > 1 and parallel_strategy.pp_size == 1:
+            raise ValueError("virtual pipeline stages need pipeline parallelism (pipeline_parallel_size > 1)")
         self.parallel_strategy = parallel_strategy
         assert parallel_strategy.world_size == dist.get_world_size(), (
             f"parallel strategy {parallel_strategy} needs {parallel_strategy.world_size} ranks, "
@@ -206,15 +206,20 @@ class NativeTrainEngine(TrainEngine):
         self.model_config = mc
         g = self.grid
         tik = time.perf_counter()
+        lr, chunks = (0, mc.n_layers), None
         if g.pp > 1:
             from ..parallel.pipeline import stage_layer_range
 
-            lr = stage_layer_range(mc.n_layers, g.pp, g.coord.pp)
-        else:
-            lr = (0, mc.n_layers)
+            if g.vpp > 1:
+                # interleaved stages: this rank hosts virtual stages pp_rank, pp_rank + pp, ... of pp * vpp
+                assert mc.n_layers >= g.pp * g.vpp, "fewer layers than virtual pipeline stages"
+                lr = None
+                chunks = [stage_layer_range(mc.n_layers, g.pp * g.vpp, c * g.pp + g.coord.pp) for c in range(g.vpp)]
+            else:
+                lr = stage_layer_range(mc.n_layers, g.pp, g.coord.pp)
         self.model = Transformer(
             mc, dtype=dtype, device=self.device, tp_size=g.tp, tp_rank=g.coord.tp, tp_group=g.group("tp"),
-            layer_range=lr, has_embed=g.coord.pp == 0, has_head=g.coord.pp == g.pp - 1,
+            layer_range=lr, layer_chunks=chunks, has_embed=g.coord.pp == 0, has_head=g.coord.pp == g.pp - 1,
             ep_size=g.ep, ep_rank=g.rank_in("ep"), ep_group=g.group("ep"),
             gradient_checkpointing=cfg.gradient_checkpointing,
             sequence_parallel=cfg.native.sequence_parallel and g.tp > 1,
@@ -384,19 +389,21 @@ class NativeTrainEngine(TrainEngine):
         mb_list = pad_mb_list(mb_list, pad_value=0.0, pad_to_maximum=self.config.pad_to_maximum, align_to=align)
         return mb_list.to(self.device)
 
-    def _run_model(self, mb: Dict[str, Any], hidden_in=None, residual_in=None):
+    def _run_model(self, mb: Dict[str, Any], hidden_in=None, residual_in=None, chunk: Optional[int] = None):
         """Packed (padded) micro-batch -> final hidden states [T_padded (/cp), H]; on a pipeline stage
-        that is not the last, the (h, residual) pair handed to the next stage."""
+        that is not the last, the (h, residual) pair handed to the next stage. `chunk`: the layer slice of an
+        interleaved pipeline stage to run."""
         ids = mb["input_ids"]
         pos = mb["position_ids"].to(torch.int32)
         cu = mb["cu_seqlens"].to(torch.int32)
         sp = self.model.sp
         if self.model_config.vision is not None and mb.get("multi_modal_input") is not None:
             assert sp is None, "vision-language batches do not combine with context parallelism"
+            assert chunk is None, "vision-language batches run on contiguous pipeline stages"
             return self._run_multimodal(mb, ids, cu, hidden_in, residual_in)
         if sp is not None:
             ids, pos = sp.local_slice(ids), sp.local_slice(pos)
-        return self.model(ids, pos, cu, int(mb["max_seqlen"]), hidden_in, residual_in)
+        return self.model(ids, pos, cu, int(mb["max_seqlen"]), hidden_in, residual_in, chunk=chunk)
 
     def _run_multimodal(self, mb: Dict[str, Any], ids: torch.Tensor, cu: torch.Tensor, hidden_in, residual_in):
         """Packed vision-language micro-batch: `multi_modal_input[i]` holds the pixel patches and grids of the
@@ -565,7 +572,7 @@ class NativeTrainEngine(TrainEngine):
         tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
         if g.coord.dp == 0 and g.coord.cp == 0:
             save_file({"flat": self.model.flat.flat.detach().cpu()}, os.path.join(meta.path, f"shard-{tag}.safetensors"))
-            manifest = dict(format="areal-sharded-v2", layout=dict(dp=g.dp, tp=g.tp, pp=g.pp, cp=g.cp, ep=g.ep),
+            manifest = dict(format="areal-sharded-v2", layout=dict(dp=g.dp, tp=g.tp, pp=g.pp, cp=g.cp, ep=g.ep, vpp=g.vpp),
                             dtype=str(self.model.dtype).replace("torch.", ""),
                             offsets={n: [int(o), int(k)] for n, (o, k) in self.model.flat.offsets.items()},
                             layer_range=list(self.model.layer_range))
@@ -604,7 +611,7 @@ class NativeTrainEngine(TrainEngine):
         with open(mans[0]) as f:
             lay = json.load(f)["layout"]
         flat = self.model.flat.flat
-        if (lay["tp"], lay["pp"]) == (g.tp, g.pp):
+        if (lay["tp"], lay["pp"], int(lay.get("vpp", 1))) == (g.tp, g.pp, g.vpp):
             tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
             with open(os.path.join(meta.path, f"manifest-{tag}.json")) as f:
                 man = json.load(f)
@@ -617,6 +624,9 @@ class NativeTrainEngine(TrainEngine):
 
             if self.model.flat_experts is not None:
                 raise NotImplementedError("resharding a mixture-of-experts checkpoint across tp / pp layouts: "
+                                          "convert through the hf format")
+            if g.vpp > 1 or int(lay.get("vpp", 1)) > 1:
+                raise NotImplementedError("resharding a checkpoint written or read with interleaved pipeline stages: "
                                           "convert through the hf format")
             src, dst = Layout(1, int(lay["tp"]), int(lay["pp"])), Layout(1, g.tp, g.pp)
             me = dst.index_of(g.coord.pp, 0, g.coord.tp)

@@ -717,7 +717,7 @@ def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]
     D = cfg.head_dim
     tp, tr = model.tp_size, model.tp_rank
     params = dict(model.named_parameters())
-    lo_layer, hi_layer = model.layer_range
+    own_layers = set(model.layer_ids)
     given = set(tensors)
 
     class _Seen(dict):  # records which of the given names were read
@@ -731,7 +731,7 @@ def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]
         return t[lo:hi]
 
     for li, blk in enumerate(model.layers):
-        i = lo_layer + li
+        i = model.layer_ids[li]
         names = hf_io.hf_names_for_layer(cfg, i)
         pre = f"layers.{li}."
         hq, hkv = blk.attn.hq, blk.attn.hkv
@@ -797,7 +797,7 @@ def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]
                 return True
             m = re.match(r"model\.layers\.(\d+)\.", n)
             if m:
-                return not (lo_layer <= int(m.group(1)) < hi_layer)
+                return int(m.group(1)) not in own_layers
             if n == "model.embed_tokens.weight" or n.startswith("visual."):
                 return not model.has_embed
             return n in ("model.norm.weight", "lm_head.weight", "score.weight") and not model.has_head

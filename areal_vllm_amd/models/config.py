@@ -243,6 +243,9 @@ PRESETS: Dict[str, Dict[str, Any]] = {
     "tiny": dict(family="qwen2", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
                  head_dim=128, intermediate_size=512, tie_word_embeddings=True, qkv_bias=True, rope_theta=1e4,
                  max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
+    "tiny-deep": dict(family="qwen2", vocab_size=512, hidden_size=256, n_layers=5, n_q_heads=2, n_kv_heads=1,
+                      head_dim=128, intermediate_size=512, tie_word_embeddings=True, qkv_bias=True, rope_theta=1e4,
+                      max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
     "small": dict(family="qwen2", vocab_size=4096, hidden_size=512, n_layers=4, n_q_heads=4, n_kv_heads=2,
                   head_dim=128, intermediate_size=1536, tie_word_embeddings=True, qkv_bias=True, rope_theta=1e4,
                   max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),

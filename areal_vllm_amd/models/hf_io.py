@@ -174,7 +174,6 @@ def load_hf_weights(model, path: str, strict: bool = True) -> None:
                 put("head", _vocab_rows(model, rd, "lm_head.weight"))
             else:  # tied checkpoint loaded into an untied stage (last pipeline stage)
                 put("head", _vocab_rows(model, rd, "model.embed_tokens.weight"))
-    lo_layer, hi_layer = model.layer_range
     hq_lo, hq_hi = _tp_range(cfg.n_q_heads, tp, tr)
     if cfg.n_kv_heads >= tp:
         hkv_lo, hkv_hi = _tp_range(cfg.n_kv_heads, tp, tr)
@@ -182,7 +181,7 @@ def load_hf_weights(model, path: str, strict: bool = True) -> None:
         rep = tp // cfg.n_kv_heads
         hkv_lo = tr // rep
         hkv_hi = hkv_lo + 1
-    for li, i in enumerate(range(lo_layer, hi_layer)):
+    for li, i in enumerate(model.layer_ids):
         names = hf_names_for_layer(cfg, i)
         pre = f"layers.{li}."
         put(pre + "ln1", rd.get(names["ln1"][0]))
@@ -238,8 +237,7 @@ def _load_gpt2(model, rd: "_ShardReader", put) -> None:
                 put("head", _vocab_rows(model, rd, "lm_head.weight" if rd.has("lm_head.weight") else pre_hf + "wte.weight"))
     q_lo, q_hi = (x * D for x in _tp_range(cfg.n_q_heads, tp, tr))
     f_lo, f_hi = _tp_range(cfg.intermediate_size, tp, tr)
-    lo_layer, hi_layer = model.layer_range
-    for li, i in enumerate(range(lo_layer, hi_layer)):
+    for li, i in enumerate(model.layer_ids):
         b, pre = f"{pre_hf}h.{i}.", f"layers.{li}."
         for ours, theirs in (("ln1", "ln_1.weight"), ("ln1_bias", "ln_1.bias"), ("ln2", "ln_2.weight"),
                              ("ln2_bias", "ln_2.bias"), ("attn.o_bias", "attn.c_proj.bias"),
@@ -260,9 +258,8 @@ def _gpt2_state(model, g) -> Iterable[Tuple[str, torch.Tensor]]:
     if model.has_embed:
         yield "transformer.wte.weight", _gather_vocab(model, params["embed"].data, g)
         yield "transformer.wpe.weight", params["pos_embed"].data
-    lo_layer, _ = model.layer_range
     for li, blk in enumerate(model.layers):
-        b, pre = f"transformer.h.{lo_layer + li}.", f"layers.{li}."
+        b, pre = f"transformer.h.{model.layer_ids[li]}.", f"layers.{li}."
         for ours, theirs in (("ln1", "ln_1.weight"), ("ln1_bias", "ln_1.bias"), ("ln2", "ln_2.weight"),
                              ("ln2_bias", "ln_2.bias"), ("attn.o_bias", "attn.c_proj.bias"),
                              ("mlp.proj_bias", "mlp.c_proj.bias")):
@@ -318,9 +315,8 @@ def native_to_hf_state(model, gather: bool = True, experts_only: bool = False) -
         for n, p in params.items():
             if n.startswith("visual."):
                 yield n, p.data
-    lo_layer, _ = model.layer_range
     for li, blk in enumerate(model.layers):
-        i = lo_layer + li
+        i = model.layer_ids[li]
         names = hf_names_for_layer(cfg, i)
         pre = f"layers.{li}."
         yield names["ln1"][0], params[pre + "ln1"].data

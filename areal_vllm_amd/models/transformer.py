@@ -302,13 +302,15 @@ class Block(nn.Module):
 
 
 class Transformer(nn.Module):
-    """Packed-sequence decoder. `layer_range` selects a pipeline stage's slice of the layers."""
+    """Packed-sequence decoder. `layer_range` selects a pipeline stage's slice of the layers; `layer_chunks`
+    (interleaved pipeline schedules) several slices, one per virtual stage this rank hosts: `forward(chunk=c)`
+    then runs only slice c. `layer_ids[i]` is the global index of local layer i."""
 
     def __init__(self, cfg: ModelConfig, dtype=torch.bfloat16, device="cpu", tp_size: int = 1, tp_rank: int = 0,
                  tp_group=None, layer_range: Optional[Tuple[int, int]] = None, has_embed: bool = True,
                  has_head: bool = True, ep_size: int = 1, ep_rank: int = 0, ep_group=None,
                  gradient_checkpointing: bool = False, sequence_parallel: bool = False,
-                 vocab_parallel: bool = False):
+                 vocab_parallel: bool = False, layer_chunks: Optional[List[Tuple[int, int]]] = None):
         super().__init__()
         # vocab-parallel: the token embedding and the LM head hold only this tp rank's vocabulary rows
         # (`vocab_range`); lookups are summed over the group and the loss merges per-shard softmax statistics
@@ -325,7 +327,19 @@ class Transformer(nn.Module):
         self.dtype = dtype
         self.tp_size, self.tp_rank, self.tp_group = tp_size, tp_rank, tp_group
         self.ep_group = ep_group
-        self.layer_range = layer_range or (0, cfg.n_layers)
+        if layer_chunks is not None:
+            assert layer_range is None and len(layer_chunks) >= 1
+            self.layer_chunks = [tuple(c) for c in layer_chunks]
+        else:
+            self.layer_chunks = [tuple(layer_range or (0, cfg.n_layers))]
+        # contiguous stages: the slice itself; interleaved stages: first .. last layer hosted (not contiguous)
+        self.layer_range = (self.layer_chunks[0][0], self.layer_chunks[-1][1])
+        self.layer_ids: List[int] = [i for lo, hi in self.layer_chunks for i in range(lo, hi)]
+        bounds, at = [], 0
+        for lo, hi in self.layer_chunks:
+            bounds.append((at, at + hi - lo))
+            at += hi - lo
+        self.chunk_bounds = bounds  # local layer index range of every chunk
         self.has_embed, self.has_head = has_embed, has_head
         self.gradient_checkpointing = gradient_checkpointing
         self.sp = None  # Ulysses sequence-parallel context (parallel/ulysses.py)
@@ -335,7 +349,7 @@ class Transformer(nn.Module):
                 self.pos_embed = nn.Parameter(torch.empty(cfg.max_position_embeddings, cfg.hidden_size, dtype=dtype,
                                                           device=device))
         self.layers = nn.ModuleList(
-            [Block(cfg, tp_size, dtype, device, ep_size, ep_rank) for _ in range(*self.layer_range)]
+            [Block(cfg, tp_size, dtype, device, ep_size, ep_rank) for _ in self.layer_ids]
         )
         if has_head:
             self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
@@ -452,9 +466,15 @@ class Transformer(nn.Module):
 
     def forward(self, input_ids: Optional[torch.Tensor], positions: torch.Tensor, cu_seqlens: torch.Tensor,
                 max_seqlen: int, hidden_in: Optional[torch.Tensor] = None,
-                residual_in: Optional[torch.Tensor] = None):
-        """Returns the final-norm hidden states [T, H] on the last stage, else (h, residual)."""
-        if self.has_embed and hidden_in is None:
+                residual_in: Optional[torch.Tensor] = None, chunk: Optional[int] = None):
+        """Returns the final-norm hidden states [T, H] on the last stage, else (h, residual). `chunk` selects
+        one of the rank's layer slices (interleaved pipeline): only the first slice of the first stage embeds,
+        only the last slice of the last stage applies the final norm."""
+        n_chunks = len(self.chunk_bounds)
+        first_chunk = chunk is None or chunk == 0
+        last_chunk = chunk is None or chunk == n_chunks - 1
+        layers = self.layers if chunk is None else self.layers[self.chunk_bounds[chunk][0]:self.chunk_bounds[chunk][1]]
+        if self.has_embed and first_chunk and hidden_in is None:
             h = self.embed_tokens(input_ids, positions, scatter=self.seq_par)
         else:
             h = hidden_in
@@ -466,7 +486,7 @@ class Transformer(nn.Module):
             positions = torch.arange(positions.shape[1], dtype=torch.int32, device=positions.device)
         else:
             rope = self.rope(h.device)
-        for blk in self.layers:
+        for blk in layers:
             if self.gradient_checkpointing and self.training and torch.is_grad_enabled():
                 from torch.utils.checkpoint import checkpoint
 
@@ -475,7 +495,7 @@ class Transformer(nn.Module):
             else:
                 h, residual = blk(h, residual, positions, rope, cu_seqlens, max_seqlen, self.tp_group, self.sp,
                                   self.ep_group, self.seq_par)
-        if not self.has_head:
+        if not (self.has_head and last_chunk):
             return h, residual
         x, _ = add_norm(self.cfg, h, self.norm, getattr(self, "norm_bias", None), residual)
         if self.seq_par:  # the LM head / value head sees all tokens again

@@ -33,6 +33,8 @@ class ProcessGrid:
         self.strategy = strategy
         self.tp, self.cp, self.dp, self.pp = strategy.tp_size, strategy.cp_size, strategy.dp_size, strategy.pp_size
         self.ep = strategy.ep_size
+        self.vpp = max(1, int(getattr(strategy, "virtual_pipeline_parallel_size", None) or 1))
+        self.links: Dict[str, Optional[dist.ProcessGroup]] = {}
         self.world = self.tp * self.cp * self.dp * self.pp
         self.ranks = ranks if ranks is not None else list(range(rank_offset, rank_offset + self.world))
         assert len(self.ranks) == self.world
@@ -100,6 +102,8 @@ class ProcessGrid:
             # first + last stage of every pipeline: owners of tied input / output embeddings
             self._new_group("embed", [[R(0, d, c, t), R(self.pp - 1, d, c, t)]
                                       for d in rng(self.dp) for c in rng(self.cp) for t in rng(self.tp)])
+        if self.pp > 1 and self.vpp > 1:
+            self._build_pipeline_links()
         if self.ep > 1:
             assert self.dp % self.ep == 0, "expert parallel size must divide the data parallel size"
             edp = self.dp // self.ep
@@ -111,6 +115,31 @@ class ProcessGrid:
         else:
             self.groups["ep"], self.group_ranks["ep"] = None, [self.global_rank]
             self.groups["edp"], self.group_ranks["edp"] = self.groups["dp_cp"], self.group_ranks["dp_cp"]
+
+    def _build_pipeline_links(self):
+        """Interleaved schedules send activations round the ring of stages (last -> first between two layer
+        chunks) with sends and receives of several micro-batches in flight. Every directed neighbour pair
+        gets a two-rank communicator per direction of travel, so a transfer on one link never queues behind a
+        transfer on another: `send_fwd` (me -> next), `recv_fwd` (prev -> me), `send_bwd` (me -> prev),
+        `recv_bwd` (next -> me)."""
+        R = lambda pp, dp, cp, tp: self.ranks[self.index_of(pp, dp, cp, tp)]  # noqa: E731
+        for d in range(self.dp):
+            for c in range(self.cp):
+                for t in range(self.tp):
+                    fwd, bwd = [], []
+                    for p in range(self.pp):
+                        nxt, prv = (p + 1) % self.pp, (p - 1) % self.pp
+                        fwd.append(dist.new_group(ranks=[R(p, d, c, t), R(nxt, d, c, t)], timeout=DIST_TIMEOUT,
+                                                  backend=self.backend))
+                        bwd.append(dist.new_group(ranks=[R(p, d, c, t), R(prv, d, c, t)], timeout=DIST_TIMEOUT,
+                                                  backend=self.backend))
+                    me = self.coord
+                    if me is not None and (me.dp, me.cp, me.tp) == (d, c, t):
+                        p = me.pp
+                        self.links = dict(send_fwd=fwd[p], recv_fwd=fwd[(p - 1) % self.pp], send_bwd=bwd[p],
+                                          recv_bwd=bwd[(p + 1) % self.pp])
+                        self.ring_next = R((p + 1) % self.pp, d, c, t)
+                        self.ring_prev = R((p - 1) % self.pp, d, c, t)
 
     # ---------------------------------------------------------------- convenience accessors
     def group(self, name: str):

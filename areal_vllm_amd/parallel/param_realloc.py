@@ -64,7 +64,6 @@ def shard_pieces(model: Transformer) -> Dict[str, np.ndarray]:
     tp, tr = model.tp_size, model.tp_rank
     D, H = cfg.head_dim, cfg.hidden_size
     out: Dict[str, np.ndarray] = {}
-    lo_layer, _ = model.layer_range
 
     def rows(off, row_lo, n_rows, width):  # a block of whole rows is contiguous in both spaces
         return [(off, row_lo * width, n_rows * width)]
@@ -79,7 +78,7 @@ def shard_pieces(model: Transformer) -> Dict[str, np.ndarray]:
         if parts[0] == "layers":
             li = int(parts[1])
             blk = model.layers[li]
-            gname = ".".join(["layers", str(lo_layer + li)] + parts[2:])
+            gname = ".".join(["layers", str(model.layer_ids[li])] + parts[2:])
         else:
             blk, gname = None, n
         if leaf in ("qkv", "qkv_bias"):

@@ -89,6 +89,8 @@ def sync_tied_embedding_weights(engine):
 # ------------------------------------------------------------------------------- schedules
 def pipeline_train_batch(engine, input_: Dict[str, Any], loss_fn: Callable, loss_weight_fn: Callable):
     g = engine.grid
+    if g.vpp > 1:
+        return interleaved_train_batch(engine, input_, loss_fn, loss_weight_fn)
     first, last = g.is_first_stage(), g.is_last_stage()
     dev = engine.device
     engine.zero_main_grads()
@@ -173,6 +175,140 @@ def pipeline_train_batch(engine, input_: Dict[str, Any], loss_fn: Callable, loss
     return engine.optimizer_step()
 
 
+# ------------------------------------------------------------------- interleaved (virtual) stages
+class _Ring:
+    """Point-to-point traffic of one rank in an interleaved pipeline: every transfer is an asynchronous send
+    or receive on the two-rank communicator of its link and direction (``ProcessGrid._build_pipeline_links``).
+    On each link the sender's order of sends equals the receiver's order of receives by construction of the
+    schedules below, and no rank ever waits for a send to be matched, so the schedules cannot dead-lock on
+    communication; they only wait for data they need."""
+
+    def __init__(self, grid):
+        self.g = grid
+        self.pending = []
+
+    def recv(self, direction: str, like):
+        buf = torch.empty(like[0], dtype=like[1], device=like[2])
+        src = self.g.ring_prev if direction == "fwd" else self.g.ring_next
+        dist.irecv(buf, src=src, group=self.g.links["recv_" + direction]).wait()
+        return buf
+
+    def send(self, direction: str, t: torch.Tensor):
+        dst = self.g.ring_next if direction == "fwd" else self.g.ring_prev
+        t = t.contiguous()
+        self.pending.append((dist.isend(t, dst=dst, group=self.g.links["send_" + direction]), t))
+
+    def drain(self):
+        for w, _t in self.pending:
+            w.wait()
+        self.pending.clear()
+
+
+def _virtual_order(M: int, P: int, V: int, backward: bool) -> List[Tuple[int, int]]:
+    """(micro-batch, chunk) in the depth-first order of interleaved schedules: micro-batches go through a
+    chunk in groups of P before the group moves on to the next chunk (backward: chunks in reverse)."""
+    order = []
+    for g0 in range(0, M, P):
+        group = range(g0, min(M, g0 + P))
+        for c in (range(V - 1, -1, -1) if backward else range(V)):
+            order += [(m, c) for m in group]
+    return order
+
+
+def interleaved_train_batch(engine, input_: Dict[str, Any], loss_fn: Callable, loss_weight_fn: Callable):
+    """One optimizer step with V layer chunks per rank (virtual stage c * P + r on rank r, chunk c): the bubble of
+    the 1F1B schedule shrinks from (P-1)/M to (P-1)/(M*V) of the step at the price of V times as many, V times
+    smaller, stage-to-stage messages - cheap on xGMI. Order of work on every rank: warm-up forwards, then one
+    forward / one backward alternately, then the remaining backwards, forwards and backwards each in
+    depth-first order (the schedule of Megatron's interleaved ``forward_backward_func`` that the reference
+    selects with ``virtual_pipeline_parallel_size``, ``areal/experimental/megatron_engine.py:169-179``). When
+    the number of micro-batches is not a multiple of P the alternation is not provably free of circular waits:
+    such a step runs all forwards, then all backwards."""
+    g = engine.grid
+    P, V, r = g.pp, g.vpp, g.coord.pp
+    dev = engine.device
+    engine.zero_main_grads()
+    mb_list = engine.prepare_mb_list(input_)
+    M = len(mb_list.padded_mbs)
+    weights = [loss_weight_fn(mb) for mb in mb_list.mbs]
+    total_w = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=dev) for w in weights]).sum()
+    comm.all_reduce_sum(total_w, g.group("dp"))
+    assert float(total_w) > 0, "total loss weight must be positive"
+    like = [_act_like(engine, pmb) for pmb in mb_list.padded_mbs]
+    ring = _Ring(g)
+    last_vs = P * V - 1
+    saved: Dict[Tuple[int, int], Any] = {}
+
+    def fwd(m: int, c: int):
+        vs = c * P + r
+        buf = None
+        if vs > 0:
+            buf = ring.recv("fwd", like[m])
+            buf.requires_grad_(True)
+        pmb = mb_list.padded_mbs[m]
+        out = engine._run_model(pmb, None if buf is None else buf[0], None if buf is None else buf[1], chunk=c)
+        scale = torch.as_tensor(weights[m], dtype=torch.float32, device=dev) / total_w
+        aux = engine.model.moe_aux_loss()
+        if vs == last_vs:
+            proxy = engine._proxy(out, mb_list.padding_lengths[m])
+            mb = engine._unpadded(pmb, mb_list.padding_lengths[m], mb_list.old_cu_seqlens_list[m])
+            loss = loss_fn(proxy, mb)
+            if aux is not None:
+                loss = loss + aux
+            saved[(m, c)] = (buf, loss * scale, None)
+        else:
+            y = torch.stack([out[0], out[1]])
+            ring.send("fwd", y.detach())
+            saved[(m, c)] = (buf, y, None if aux is None else aux * scale)
+
+    def bwd(m: int, c: int):
+        vs = c * P + r
+        buf, out, aux = saved.pop((m, c))
+        if vs == last_vs:
+            out.backward()
+        else:
+            grad = ring.recv("bwd", like[m])
+            if aux is None:
+                torch.autograd.backward([out], [grad])
+            else:
+                torch.autograd.backward([out, aux], [grad, None])
+        if buf is not None:
+            ring.send("bwd", buf.grad)
+
+    f_order, b_order = _virtual_order(M, P, V, False), _virtual_order(M, P, V, True)
+    total = M * V
+    warm = min((P - r - 1) * 2 + (V - 1) * P, total) if M % P == 0 else total
+    for k in range(warm):
+        fwd(*f_order[k])
+    for i in range(total - warm):
+        fwd(*f_order[warm + i])
+        bwd(*b_order[i])
+    for i in range(total - warm, total):
+        bwd(*b_order[i])
+    ring.drain()
+    assert not saved
+    sync_tied_embedding_grads(engine)
+    return engine.optimizer_step()
+
+
+def _interleaved_forward_only(engine, mb_list, on_last: Callable):
+    """Forward passes of all micro-batches through all virtual stages; `on_last(m, hidden)` runs on the rank
+    that hosts the last virtual stage."""
+    g = engine.grid
+    P, V, r = g.pp, g.vpp, g.coord.pp
+    ring = _Ring(g)
+    for m, c in _virtual_order(len(mb_list.padded_mbs), P, V, False):
+        vs = c * P + r
+        pmb = mb_list.padded_mbs[m]
+        buf = ring.recv("fwd", _act_like(engine, pmb)) if vs > 0 else None
+        out = engine._run_model(pmb, None if buf is None else buf[0], None if buf is None else buf[1], chunk=c)
+        if vs == P * V - 1:
+            on_last(m, out)
+        else:
+            ring.send("fwd", torch.stack([out[0], out[1]]))
+    ring.drain()
+
+
 @torch.no_grad()
 def pipeline_eval_batch(engine, input_, loss_fn, loss_weight_fn):
     g = engine.grid
@@ -183,7 +319,14 @@ def pipeline_eval_batch(engine, input_, loss_fn, loss_weight_fn):
     total_w = torch.stack([torch.as_tensor(w, dtype=torch.float32, device=dev) for w in weights]).sum()
     comm.all_reduce_sum(total_w, g.group("dp"))
     total = torch.zeros((), dtype=torch.float32, device=dev)
-    for i, pmb in enumerate(mb_list.padded_mbs):
+    if g.vpp > 1:
+        def on_last(m, out):
+            proxy = engine._proxy(out, mb_list.padding_lengths[m])
+            mb = engine._unpadded(mb_list.padded_mbs[m], mb_list.padding_lengths[m], mb_list.old_cu_seqlens_list[m])
+            total.add_(loss_fn(proxy, mb).float() * torch.as_tensor(weights[m], dtype=torch.float32, device=dev) / total_w)
+
+        _interleaved_forward_only(engine, mb_list, on_last)
+    for i, pmb in enumerate(mb_list.padded_mbs if g.vpp == 1 else []):
         buf, _n = _exchange(g, recv_prev_like=None if first else _act_like(engine, pmb))
         out = engine._run_model(pmb, None if buf is None else buf[0], None if buf is None else buf[1])
         if last:
@@ -209,7 +352,17 @@ def pipeline_forward(engine, input_, output_seqlens=None, post_hook=None, aggreg
     if output_seqlens is None:
         output_seqlens = input_["attention_mask"].sum(-1).long().tolist()
     results = []
-    for i, pmb in enumerate(mb_list.padded_mbs):
+    if g.vpp > 1:
+        by_mb: Dict[int, Any] = {}
+
+        def on_last(m, out):
+            proxy = engine._proxy(out, mb_list.padding_lengths[m])
+            mb = engine._unpadded(mb_list.padded_mbs[m], mb_list.padding_lengths[m], mb_list.old_cu_seqlens_list[m])
+            by_mb[m] = post_hook(proxy, mb) if post_hook is not None else proxy.materialize()
+
+        _interleaved_forward_only(engine, mb_list, on_last)
+        results = [by_mb[m] for m in sorted(by_mb)]
+    for i, pmb in enumerate(mb_list.padded_mbs if g.vpp == 1 else []):
         buf, _n = _exchange(g, recv_prev_like=None if first else _act_like(engine, pmb))
         out = engine._run_model(pmb, None if buf is None else buf[0], None if buf is None else buf[1])
         if last:

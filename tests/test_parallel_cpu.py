@@ -64,7 +64,12 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
     cfg.native.sequence_parallel = strategy_kwargs.pop("_seq_par", False)
     reshard_from = strategy_kwargs.pop("_reshard_from", None)
     eng = NativeTrainEngine(cfg)
-    st = ParallelStrategy(**strategy_kwargs)
+    if "virtual_pipeline_parallel_size" in strategy_kwargs:
+        from areal_vllm_amd.api.alloc_mode import MegatronParallelStrategy
+
+        st = MegatronParallelStrategy(**strategy_kwargs)
+    else:
+        st = ParallelStrategy(**strategy_kwargs)
     eng.create_process_group(st)
     eng.initialize(None, FinetuneSpec(1, 8, 4))
     if ckpt_in is None:
@@ -223,6 +228,28 @@ def test_qk_norm_weights_under_tensor_parallel():
     _run(1, {}, init, ref, preset_name="tiny-qknorm")
     _run(2, dict(tensor_parallel_size=2), init, out, preset_name="tiny-qknorm")
     _compare(ref, out, atol=5e-5)
+
+
+def test_interleaved_pipeline_stages_match_single_process():
+    """Virtual pipeline stages (two layer chunks per rank, five layers over four virtual stages): the interleaved
+    1F1B schedule, its all-forward-all-backward form for a micro-batch count that is no multiple of pp, and the
+    combination with tensor + sequence parallelism end at the single-process weights; eval and forward agree;
+    the sharded checkpoint round-trips in the interleaved layout."""
+    d = tempfile.mkdtemp(prefix="areal_vpp_")
+    init, ref = os.path.join(d, "init"), os.path.join(d, "ref")
+    _run(1, {}, None, init, preset_name="tiny-deep")
+    _run(1, {}, init, ref, preset_name="tiny-deep", n_mbs=2)
+    v2 = dict(pipeline_parallel_size=2, virtual_pipeline_parallel_size=2)
+    for name, world, kw, n_mbs in (("pp2v2", 2, v2, 4), ("pp2v2odd", 2, v2, 3),
+                                   ("tp2pp2v2sp", 4, dict(v2, tensor_parallel_size=2, _seq_par=True), 2)):
+        out = os.path.join(d, name)
+        _run(world, kw, init, out, preset_name="tiny-deep", n_mbs=n_mbs)
+        _compare(ref, out, atol=5e-5)
+        ref_fw = torch.load(os.path.join(ref, "fwd_dp0_r0.pt"), weights_only=True)
+        for f in sorted(f for f in os.listdir(out) if f.startswith("fwd_dp0_")):
+            fw = torch.load(os.path.join(out, f), weights_only=True)
+            for i, n in enumerate([23, 9, 31, 14][: fw.shape[0]]):
+                torch.testing.assert_close(fw[i, : n - 1], ref_fw[i, : n - 1], atol=1e-4, rtol=1e-4)
 
 
 def test_gpt2_family_under_tensor_and_pipeline_parallel():
