@@ -125,6 +125,15 @@ class NativeEngineConfig:
                                                       "recomputing the LM head"})
     logprob_chunk: int = 8192
     sequence_parallel: bool = False
+    zero_stage: int = field(default=1, metadata={
+        "help": "1: bf16 weights and fp32 gradients replicated, optimizer state sharded over dp (two large "
+                "collectives per step; the default with 288 GB per GPU). 3: weights, gradients and optimizer state "
+                "all sharded, decoder blocks gathered on demand (FSDP semantics; data / context parallel layouts)",
+        "choices": [1, 3]})
+    reshard_after_forward: bool = field(default=True, metadata={
+        "help": "ZeRO-3: drop a block's gathered weights after its forward and gather them again for the backward"})
+    offload_optimizer: bool = field(default=False, metadata={
+        "help": "ZeRO-3: keep fp32 master weights and Adam moments in pinned host memory"})
     context_parallel_mode: str = field(default="ulysses", metadata={
         "help": "what the `c` dimension of the allocation mode does: 'ulysses' (all-to-all between token and "
                 "head partitions, the reference's FSDP engine) or 'zigzag' (load-balanced token placement with "

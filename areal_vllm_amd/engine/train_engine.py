@@ -138,6 +138,7 @@ class NativeTrainEngine(TrainEngine):
         self._weight_update_group = None
         self._local_rollout_engine = None
         self._training = True
+        self.zero3 = None  # parallel/zero3.Zero3 when cfg.native.zero_stage == 3
 
     # ------------------------------------------------------------------ process groups
     def create_process_group(self, parallel_strategy: Optional[ParallelStrategy] = None,
@@ -250,7 +251,20 @@ class NativeTrainEngine(TrainEngine):
                 pass
         else:
             hf_io.load_hf_weights(self.model, cfg.path, strict=not (self.is_critic and cfg.init_critic_from_actor))
-        if self.optimizer_config is not None and self.optimizer_config.type != "empty":
+        with_optim = self.optimizer_config is not None and self.optimizer_config.type != "empty"
+        if int(cfg.native.zero_stage) == 3 or cfg.fsdp.offload_params:
+            from ..parallel.zero3 import Zero3
+
+            assert g.tp == 1 and g.pp == 1 and g.ep == 1 and self.model.flat_experts is None, \
+                "zero_stage 3 shards over data / context parallel ranks; combine tensor or pipeline parallelism " \
+                "with zero_stage 1"
+            self.zero3 = Zero3(self.model, self.optimizer_config if with_optim else None, group=g.group("dp_cp"),
+                               reshard_after_forward=cfg.native.reshard_after_forward,
+                               offload_optimizer=cfg.native.offload_optimizer or cfg.fsdp.offload_params)
+            if with_optim:
+                self.optimizer = self.zero3
+                self._total_steps = max(1, ft_spec.total_train_steps if ft_spec is not None else 1)
+        elif with_optim:
             flat.alloc_main_grad()
             mp_groups = tuple(x for x in (g.group("tp"), g.group("pp")) if x is not None)
             self.optimizer = ShardedAdamW(flat, self.optimizer_config, dp_group=g.group("dp_cp"), mp_groups=mp_groups,
@@ -474,6 +488,7 @@ class NativeTrainEngine(TrainEngine):
         assert float(total_w) > 0, "total loss weight must be positive"
         for i, (pmb, pad_len, old_cu) in enumerate(zip(mb_list.padded_mbs, mb_list.padding_lengths,
                                                        mb_list.old_cu_seqlens_list)):
+            self._begin_mb()
             hidden = self._run_model(pmb)
             proxy = self._proxy(hidden, pad_len)
             mb = self._unpadded(pmb, pad_len, old_cu)
@@ -482,10 +497,30 @@ class NativeTrainEngine(TrainEngine):
             aux = self.model.moe_aux_loss()
             if aux is not None:
                 loss = loss + aux
+            if self.zero3 is not None:
+                self.zero3.in_backward = True
             (loss * scale).backward()
+            self._end_mb()
         return self.optimizer_step()
 
+    def _begin_mb(self):
+        """ZeRO-3: the parameters outside the decoder blocks become whole for this micro-batch."""
+        if self.zero3 is not None:
+            self.zero3.begin_microbatch()
+
+    def _end_mb(self):
+        if self.zero3 is not None:
+            self.zero3.end_microbatch()
+
+    def full_params(self):
+        """Context in which every parameter of this rank's model is whole (no-op unless ZeRO-3 shards them)."""
+        import contextlib
+
+        return self.zero3.full_params() if self.zero3 is not None else contextlib.nullcontext()
+
     def zero_main_grads(self):
+        if self.zero3 is not None:
+            return self.zero3.zero_grad()
         self.model.flat.main_grad.zero_()
         if self.model.flat_experts is not None:
             self.model.flat_experts.main_grad.zero_()
@@ -520,9 +555,11 @@ class NativeTrainEngine(TrainEngine):
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         for i, (pmb, pad_len, old_cu) in enumerate(zip(mb_list.padded_mbs, mb_list.padding_lengths,
                                                        mb_list.old_cu_seqlens_list)):
+            self._begin_mb()
             proxy = self._proxy(self._run_model(pmb), pad_len)
             loss = loss_fn(proxy, self._unpadded(pmb, pad_len, old_cu))
             total += loss.float() * torch.as_tensor(weights[i], dtype=torch.float32, device=self.device) / total_w
+            self._end_mb()
         comm.all_reduce_sum(total, self.grid.group("dp"))
         return total
 
@@ -542,10 +579,12 @@ class NativeTrainEngine(TrainEngine):
             output_seqlens = input_["attention_mask"].sum(-1).long().tolist()
         results = []
         for pmb, pad_len, old_cu in zip(mb_list.padded_mbs, mb_list.padding_lengths, mb_list.old_cu_seqlens_list):
+            self._begin_mb()
             proxy = self._proxy(self._run_model(pmb), pad_len)
             mb = self._unpadded(pmb, pad_len, old_cu)
             out = post_hook(proxy, mb) if post_hook is not None else proxy.materialize()
             results.append(out)
+            self._end_mb()
         res = aggregate_fn(results)
         lens_fwd = [output_seqlens[i] for i in mb_list.forward_indices]
         seqs = unpack_sequence(res, lens=lens_fwd)
@@ -569,6 +608,19 @@ class NativeTrainEngine(TrainEngine):
 
         g = self.grid
         os.makedirs(meta.path, exist_ok=True)
+        if self.zero3 is not None:  # every data-parallel rank owns a different slice of every parameter
+            z = self.zero3
+            save_file({"param_shard": z.param_shard.detach().cpu()},
+                      os.path.join(meta.path, f"zero3-shard-{z.rank}-of-{z.n}.safetensors"))
+            if z.rank == 0:
+                with open(os.path.join(meta.path, "config.json"), "w") as f:
+                    json.dump(self.model_config.to_hf_dict(), f, indent=2)
+            if meta.with_optim and self.optimizer is not None:
+                torch.save(dict(optim=z.state_dict(), lr_step=self._lr_step),
+                           os.path.join(meta.path, f"optim_world_size_{self.world_size}_rank_{self.rank}.pt"))
+            if dist.is_initialized():
+                dist.barrier(group=self.grid.group("world"))
+            return
         tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
         if g.coord.dp == 0 and g.coord.cp == 0:
             save_file({"flat": self.model.flat.flat.detach().cpu()}, os.path.join(meta.path, f"shard-{tag}.safetensors"))
@@ -605,6 +657,16 @@ class NativeTrainEngine(TrainEngine):
         from safetensors.torch import load_file
 
         g = self.grid
+        if self.zero3 is not None:
+            z = self.zero3
+            fn = os.path.join(meta.path, f"zero3-shard-{z.rank}-of-{z.n}.safetensors")
+            if not os.path.exists(fn):
+                raise FileNotFoundError(f"{fn}: a ZeRO-3 sharded checkpoint is read back by the same number of "
+                                        "data-parallel ranks (convert through the hf format otherwise)")
+            t = load_file(fn)["param_shard"]
+            assert t.numel() == z.param_shard.numel(), "parameter shard layout of the checkpoint differs"
+            z.param_shard.copy_(t.to(z.param_shard.dtype))
+            return
         mans = sorted(glob.glob(os.path.join(meta.path, "manifest-pp*-tp*.json")))
         if not mans:
             raise FileNotFoundError(f"no sharded checkpoint manifest under {meta.path}")
@@ -667,9 +729,10 @@ class NativeTrainEngine(TrainEngine):
         if g.ep > 1:
             tag += f"-ep{g.coord.dp}"
         wm = {}
-        if participate:
-            wm = hf_io.save_hf_checkpoint(self.model, meta.path, stage_tag=tag, write=writer,
-                                          experts_only=g.coord.dp > 0)
+        with self.full_params():  # ZeRO-3: every rank helps to make the writer's parameters whole
+            if participate:
+                wm = hf_io.save_hf_checkpoint(self.model, meta.path, stage_tag=tag, write=writer,
+                                              experts_only=g.coord.dp > 0)
         if dist.is_initialized() and (g.pp > 1 or g.ep > 1):
             maps = [None] * g.world
             dist.all_gather_object(maps, wm if writer else {}, group=g.group("world"))
@@ -692,7 +755,10 @@ class NativeTrainEngine(TrainEngine):
         if meta.weight_format in ("dcp", "naive_distributed"):
             self._load_sharded(meta)
         elif meta.weight_format == "hf":
-            hf_io.load_hf_weights(self.model, meta.path)
+            with self.full_params():
+                hf_io.load_hf_weights(self.model, meta.path)
+                if self.zero3 is not None:
+                    self.zero3.reshard_from_full()
         else:
             raise NotImplementedError(f"weight format {meta.weight_format} (use 'hf', 'dcp' or 'naive_distributed')")
         if self.optimizer is not None:
@@ -720,7 +786,10 @@ class NativeTrainEngine(TrainEngine):
         return [[specs[i] for i in sorted(g)] for g in sorted(groups, key=lambda g: min(g))]
 
     def _iter_full_hf_params(self, meta_only: bool = False):
-        if meta_only and self.grid.tp == 1:
+        if meta_only and self.zero3 is not None:  # shapes only, no collective: an unsharded copy on the meta device
+            twin = Transformer(self.model_config, dtype=self.model.dtype, device="meta")
+            yield from hf_io.native_to_hf_state(twin, gather=False)
+        elif meta_only and self.grid.tp == 1:
             yield from hf_io.native_to_hf_state(self.model, gather=False)
         else:
             yield from hf_io.native_to_hf_state(self.model, gather=True)
@@ -748,22 +817,26 @@ class NativeTrainEngine(TrainEngine):
             if self.grid.pp > 1:
                 raise NotImplementedError("a colocated rollout engine needs a trainer without pipeline stages "
                                           "(use a decoupled allocation such as native:d4+native:d2p2)")
-            if self.grid.tp == 1:
+            if self.grid.tp == 1 and self.zero3 is None:
                 if eng is not None:  # same flat layout: one device copy
                     eng.load_weights_from_trainer(self.model, version=None,
                                                   abort_running=getattr(eng, "abort_on_weight_update", True))
-            else:  # tensor-parallel trainer: gather the shards (every tp rank takes part), load by name on the head
-                full = dict(self._iter_full_hf_params())
-                if self.device.type == "cuda":
-                    torch.cuda.current_stream().synchronize()  # the engine reads the gathered tensors on its stream
-                if eng is not None:
-                    eng.load_named_tensors(full, version=None,
-                                           abort_running=getattr(eng, "abort_on_weight_update", True))
+            else:  # sharded trainer (tp, ZeRO-3): gather the shards (every rank takes part), load by name on the head
+                with self.full_params():
+                    full = dict(self._iter_full_hf_params())
+                    if self.device.type == "cuda":
+                        torch.cuda.current_stream().synchronize()  # the engine reads the tensors on its stream
+                    if eng is not None:
+                        eng.load_named_tensors(full, version=None,
+                                               abort_running=getattr(eng, "abort_on_weight_update", True))
         elif meta.type == "disk":
             self._upload_disk(meta)
         elif meta.type in ("nccl", "xgmi"):
             self._upload_collective(meta)
         elif meta.type == "ipc":
+            if self.zero3 is not None:
+                raise NotImplementedError("the peer-memory transport exports the whole flat parameter buffer, which a "
+                                          "ZeRO-3 trainer never holds: use the collective or disk transport")
             self._upload_ipc(meta)
         else:
             raise NotImplementedError(f"Unknown weight update type {meta.type}")
@@ -825,6 +898,12 @@ class NativeTrainEngine(TrainEngine):
         ``fsdp_engine.py:399-433``). The chunks of one round (one per sender) travel concurrently."""
         self._init_weight_update_group(meta)
         n = max(1, meta.nccl_n_senders)
+        if self.zero3 is not None:
+            with self.zero3.full_params():
+                return self._broadcast_chunks(meta, n)
+        return self._broadcast_chunks(meta, n)
+
+    def _broadcast_chunks(self, meta: WeightUpdateMeta, n: int):
         # Only the tensors of this rank's own chunks are kept: a tensor-parallel rank still takes part in every
         # gather of the stream, but a full gathered copy of the model never exists on any rank, and ranks that
         # send nothing from an unsharded replica skip the stream altogether.

@@ -569,3 +569,55 @@ def test_fused_decode_path_matches_library_path(B):
     np.testing.assert_allclose(l0[0][same], l1[0][same], atol=0.05)
     for a, b in zip(k0, k1):
         assert (a - b).abs().max().item() < 0.1
+
+
+def test_zero3_engine_follows_zero1_on_the_device(engine):
+    """ZeRO-3 on one MI355X (a data-parallel group of one still runs every code path: storage dropped and
+    re-allocated per block, gathers and gradient reductions on the communication stream, gradient
+    checkpointing re-gathering inside the backward): same initial weights as the ZeRO-1 fixture, same
+    batch -> the same forward log-probs and, after two steps each, the same losses within bf16 noise."""
+    from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
+    from areal_vllm_amd.api.io_struct import FinetuneSpec, SaveLoadMeta
+    from areal_vllm_amd.engine.train_engine import NativeTrainEngine
+
+    cfg = TrainEngineConfig(experiment_name="t", trial_name="z3", path="small", init_from_scratch=True,
+                            dtype="bfloat16", gradient_checkpointing=True,
+                            optimizer=OptimizerConfig(lr=2e-3, weight_decay=0.0, gradient_clipping=1.0,
+                                                      warmup_steps_proportion=0.0, lr_scheduler_type="constant"),
+                            mb_spec=MicroBatchSpec(max_tokens_per_mb=1024))
+    cfg.native.zero_stage = 3
+    z = NativeTrainEngine(cfg)
+    z.create_process_group()
+    z.initialize(None, FinetuneSpec(1, 64, 8))
+    try:
+        assert z.zero3 is not None and z.zero3.resident_param_bytes() == z.zero3.param_shard.numel() * 2
+        # start both engines from the ZeRO-1 fixture's current weights
+        import tempfile
+
+        d = tempfile.mkdtemp(prefix="areal_z3_")
+        engine.save(SaveLoadMeta(path=d, weight_format="hf", with_optim=False))
+        z.load(SaveLoadMeta(path=d, weight_format="hf", with_optim=False))
+        batch = _batch(engine.model_config.vocab_size, [257, 64, 300, 129, 33, 512, 77, 90], seed=5)
+        a = engine.forward(batch, post_hook=_logp_hook).float()
+        b = z.forward(batch, post_hook=_logp_hook).float()
+        assert float((a - b).abs().max()) < 1e-3  # identical kernels on identical weights
+        # the fixture engine is shared with other tests: train a private ZeRO-1 copy instead
+        ref = NativeTrainEngine(TrainEngineConfig(experiment_name="t", trial_name="z1", path="small", init_from_scratch=True,
+                                                  dtype="bfloat16", gradient_checkpointing=True, optimizer=cfg.optimizer,
+                                                  mb_spec=cfg.mb_spec))
+        ref.create_process_group()
+        ref.initialize(None, FinetuneSpec(1, 64, 8))
+        ref.load(SaveLoadMeta(path=d, weight_format="hf", with_optim=False))
+        la, lb = [], []
+        for _ in range(2):
+            sa = ref.train_batch(batch, _sft_loss, _weight)
+            sb = z.train_batch(batch, _sft_loss, _weight)
+            assert sb["update_successful"] == 1.0
+            assert sb["grad_norm"] == pytest.approx(sa["grad_norm"], rel=2e-2)
+            la.append(float(ref.eval_batch(batch, _sft_loss, _weight)))
+            lb.append(float(z.eval_batch(batch, _sft_loss, _weight)))
+        assert lb[-1] < lb[0] and lb == pytest.approx(la, rel=2e-2, abs=2e-2)
+        assert z.zero3.resident_param_bytes() == z.zero3.param_shard.numel() * 2  # everything re-sharded at rest
+        ref.destroy()
+    finally:
+        z.destroy()
