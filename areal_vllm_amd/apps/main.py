@@ -46,6 +46,15 @@ def main_start(experiment: Experiment, expr_name: str, trial_name: str, mode: st
     exp_pkl = os.path.join(log_dir, "experiment.pkl")
     with open(exp_pkl, "wb") as f:
         pickle.dump(experiment, f)
+    if mode == "ray":
+        # the controller launches the workers itself, as Ray tasks (no scheduler client, no controller process)
+        from ..system.controller import RayController
+
+        name_resolve.clear_subtree(names.trial_root(expr_name, trial_name))
+        RayController(expr_name, trial_name).start(
+            experiment, ignore_worker_error=ignore_worker_error, timeout=timeout,
+            env=dict(AREAL_RECOVER_RUN="1" if recover_run else "0", AREAL_PLATFORM=platform))
+        return
     attempt = 0
     while True:
         name_resolve.clear_subtree(names.trial_root(expr_name, trial_name))
@@ -89,7 +98,7 @@ def main(argv=None):
     s = sub.add_parser("start")
     s.add_argument("-e", "--experiment_name", required=True, help="a registered experiment name")
     s.add_argument("-f", "--trial_name", default="trial")
-    s.add_argument("--mode", default="local", choices=["local", "slurm"])
+    s.add_argument("--mode", default="local", choices=["local", "slurm", "ray"])
     s.add_argument("--fileroot", default="/tmp/areal")
     s.add_argument("--recover_mode", default="disabled", choices=["disabled", "auto", "fault", "resume"])
     s.add_argument("--recover_retries", type=int, default=1)

@@ -101,8 +101,16 @@ class SlurmSchedulerClient(SchedulerClient):
     writes a multiprog file per job, ``realhf/scheduler/slurm/client.py:78-400``)."""
 
     def __init__(self, expr_name: str, trial_name: str, fileroot: str = "/tmp/areal", container_type: str = "none",
-                 container_image: Optional[str] = None, container_mounts: Optional[str] = None):
+                 container_image: Optional[str] = None, container_mounts: Optional[str] = None,
+                 allocate: bool = False, node_resources=None):
+        """`allocate`: place the tasks of every array on nodes here (``scheduler/slurm_utils.py``: free resources
+        from ``scontrol show node`` or `node_resources`, GPU arrays packed node by node so that neighbouring
+        worker indices share a node) and pin the placement with a hostfile and a multi-prog file, instead of
+        leaving the distribution to Slurm."""
         super().__init__(expr_name, trial_name)
+        self.allocate = allocate
+        self._free = node_resources  # {host: NodeResource}; queried on first use when None
+        self.placements: Dict[str, object] = {}
         self.fileroot = fileroot
         self.container_type, self.container_image, self.container_mounts = container_type, container_image, \
             container_mounts
@@ -138,6 +146,45 @@ class SlurmSchedulerClient(SchedulerClient):
             cpus_per_task=cpu, mem_per_cpu=max(1, mem // max(1, cpu)), extra="\n".join(extra), exports=exports,
             container=container, cmd=cmd.replace("{index}", "$SLURM_PROCID").replace("'", "'\\''"))
 
+    def render_allocated(self, worker_type: str, cmd: str, count: int, gpu: int = 0, cpu: int = 1, mem: int = 1024,
+                         env_vars: Optional[Dict[str, str]] = None, nodelist: Optional[str] = None,
+                         exclude: Optional[str] = None, time_limit: Optional[str] = None, **_) -> str:
+        """sbatch script of an array whose tasks were placed by `allocate_resources`: the job asks for exactly
+        the chosen nodes, `SLURM_HOSTFILE` + ``--distribution=arbitrary`` put task i on its host and the
+        multi-prog file gives it its worker index and its device ordinal on that host."""
+        from . import slurm_utils as su
+
+        if self._free is None:
+            self._free = su.get_all_node_resources()
+        req = su.LaunchRequest(worker_type, count, su.NodeResource(cpu=cpu, mem=mem, gpu=int(gpu)), nodelist, exclude)
+        (pl,), self._free = su.allocate_resources([req], self._free)
+        self.placements[worker_type] = pl
+        d = self._dir()
+        with open(f"{d}/{worker_type}.hostfile", "w") as f:
+            f.write(pl.hostfile())
+        task = ("export LOCAL_RANK={local}; " if gpu else "") + cmd
+        container = ""
+        if self.container_type == "apptainer" and self.container_image:
+            mounts = f"--bind {self.container_mounts} " if self.container_mounts else ""
+            container = f"apptainer exec --rocm {mounts}{self.container_image} "
+        with open(f"{d}/{worker_type}.multiprog", "w") as f:
+            f.write(pl.multiprog(f"{container}bash -c '" + task.replace("'", "'\\''") + "'"))
+        per_node = max(pl.hosts.count(h) for h in set(pl.hosts))
+        lines = ["#!/bin/bash", f"#SBATCH --job-name={self.run_name}:{worker_type}",
+                 f"#SBATCH --output={d}/{worker_type}.log", "#SBATCH --open-mode=append",
+                 f"#SBATCH --nodelist={pl.nodelist()}", f"#SBATCH --nodes={len(set(pl.hosts))}",
+                 f"#SBATCH --ntasks={count}", f"#SBATCH --cpus-per-task={cpu}",
+                 f"#SBATCH --mem-per-cpu={max(1, mem // max(1, cpu))}M"]
+        if gpu:
+            lines.append(f"#SBATCH --gres=gpu:{int(gpu) * per_node}")
+        if time_limit:
+            lines.append(f"#SBATCH --time={time_limit}")
+        lines += [f"export {k}={v}" for k, v in (env_vars or {}).items()]
+        lines += [f"export SLURM_HOSTFILE={d}/{worker_type}.hostfile",
+                  f"srun --ntasks={count} --distribution=arbitrary --kill-on-bad-exit=1 --multi-prog "
+                  f"{d}/{worker_type}.multiprog"]
+        return "\n".join(lines) + "\n"
+
     def submit(self, worker_type: str, cmd: str, **kwargs):
         return self.submit_array(worker_type, cmd, 1, **kwargs)
 
@@ -145,7 +192,7 @@ class SlurmSchedulerClient(SchedulerClient):
         import re
         import subprocess
 
-        script = self.render(worker_type, cmd, count, **kwargs)
+        script = (self.render_allocated if self.allocate else self.render)(worker_type, cmd, count, **kwargs)
         path = f"{self._dir()}/{worker_type}.sh"
         with open(path, "w") as f:
             f.write(script)

@@ -325,3 +325,102 @@ def test_sync_ppo_generation_replica_is_fed_by_parameter_reallocation(tmp_path, 
                     logs += f.read()
     # start-up hand-over + one per train step, on both workers
     assert logs.count("re-allocation actor@0 -> actor@1 verified") >= 2 * 3, logs[-2000:]
+
+
+class _FakeRay:
+    """Stand-in for the `ray` module (not installed here): tasks are spawned processes, resources a fixed dict."""
+
+    class exceptions:  # noqa: N801
+        class GetTimeoutError(Exception):
+            pass
+
+    def __init__(self, resources):
+        self.resources, self.launched, self.inited = resources, [], False
+
+    def is_initialized(self):
+        return self.inited
+
+    def init(self, runtime_env=None):
+        self.inited, self.runtime_env = True, runtime_env
+
+    def shutdown(self):
+        self.inited = False
+        for _o, p in self.launched:
+            if p.is_alive():
+                p.terminate()
+
+    def available_resources(self):
+        return dict(self.resources)
+
+    def remote(self, **opts):
+        import multiprocessing as mp
+
+        ray = self
+
+        class _Fn:
+            def __init__(self, fn):
+                self.fn = fn
+
+            def remote(self, *args):
+                p = mp.get_context("spawn").Process(target=self.fn, args=args, daemon=True)
+                p.start()
+                ray.launched.append((opts, p))
+                return p
+
+        return _Fn
+
+    def get(self, refs, timeout=None):
+        import time
+
+        deadline = time.time() + (timeout or 0)
+        for p in refs:
+            p.join(max(0.0, deadline - time.time()))
+            if p.is_alive():
+                raise self.exceptions.GetTimeoutError()
+            assert p.exitcode == 0, f"ray task exited with {p.exitcode}"
+
+
+def test_ray_placement_plan_packs_gpu_workers_node_by_node():
+    from areal_vllm_amd.system.controller import plan_ray_placement
+    from areal_vllm_amd.system.system_api import Scheduling, TasksGroup
+
+    res = {"CPU": 256, "GPU": 16, "memory": 4000 * 1024 ** 3, "node:10.0.0.1": 1.0, "node:10.0.0.2": 1.0}
+    counts = [("master_worker", 1, TasksGroup(1, Scheduling(cpu=4, mem=16000))),
+              ("model_worker", 12, TasksGroup(12, Scheduling(cpu=8, gpu=1, mem=64000))),
+              ("generation_server", 4, TasksGroup(4, Scheduling(cpu=8, gpu=1, mem=64000)))]
+    plan = plan_ray_placement(counts, res)
+    mw = [o for wt, _i, o in plan if wt == "model_worker"]
+    assert [list(o["resources"])[0] for o in mw] == ["node:10.0.0.1"] * 8 + ["node:10.0.0.2"] * 4
+    assert all(o["resources"][list(o["resources"])[0]] == 1 / 8 and o["num_gpus"] == 1 for o in mw)
+    gs = [o for wt, _i, o in plan if wt == "generation_server"]
+    assert [list(o["resources"])[0] for o in gs] == ["node:10.0.0.2"] * 4  # continue after the model workers
+    assert "resources" not in [o for wt, _i, o in plan if wt == "master_worker"][0]
+    with pytest.raises(RuntimeError, match="required"):
+        plan_ray_placement(counts, dict(res, GPU=8))
+
+
+def test_ray_controller_runs_an_experiment_with_ray_tasks_as_workers(tmp_path, monkeypatch):
+    """`RayController` launches the workers as (fake) Ray tasks with the planned options, then configures and
+    supervises them like the process-based controller: the null SFT experiment completes."""
+    from areal_vllm_amd.system.controller import RayController
+    from areal_vllm_amd.system.system_api import DatasetAbstraction, ExperimentSaveEvalControl, make_experiment
+    from areal_vllm_amd.utils import name_resolve, names
+
+    root = str(tmp_path)
+    rows = [dict(id=str(i), prompt_ids=[3 + i, 4, 5], answer_ids=[7, 8]) for i in range(16)]
+    p = os.path.join(root, "data.jsonl")
+    with open(p, "w") as f:
+        f.write("\n".join(json.dumps(r) for r in rows))
+    exp = make_experiment("null-sft")
+    exp.experiment_name, exp.trial_name, exp.layout, exp.fileroot, exp.device = "t-ray", "t0", "d2", root, "cpu"
+    exp.dataset = DatasetAbstraction("prompt_answer", args=dict(dataset_path=p, eos_token_id=1))
+    exp.train_bs_n_seqs = 8
+    exp.exp_ctrl = ExperimentSaveEvalControl(total_train_epochs=1)
+    monkeypatch.setenv("AREAL_PLATFORM", "cpu")
+    name_resolve.clear_subtree(names.trial_root("t-ray", "t0"))
+    ray = _FakeRay({"CPU": 64, "GPU": 2, "memory": 512 * 1024 ** 3, "node:127.0.0.1": 1.0})
+    RayController("t-ray", "t0", ray_module=ray).start(exp, env=dict(AREAL_PLATFORM="cpu"), timeout=300)
+    assert sorted(o["name"] for o, _p in ray.launched) == ["master_worker/0", "model_worker/0", "model_worker/1"]
+    assert all(p.exitcode == 0 for _o, p in ray.launched) and not ray.inited
+    st = _stats(root, "t-ray", "t0")
+    assert [s["global_step"] for s in st] == [1, 2]

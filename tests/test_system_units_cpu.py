@@ -652,3 +652,74 @@ def test_best_of_k_keeps_the_highest_scored_longest_answers():
     assert [r.output_tokens[0] for r in kept] == [4, 1]
     with pytest.raises(AssertionError):
         PPOActorInterface(group_size=4, generation_size=2)
+
+
+# ------------------------------------------------------------------------ slurm resource allocation
+SCONTROL = """NodeName=gpu01 Arch=x86_64 CoresPerSocket=64
+   CPUAlloc=0 CPUTot=128 State=IDLE ThreadsPerCore=1
+   CfgTRES=cpu=128,mem=2000G,billing=128,gres/gpu=8
+   AllocTRES=
+
+NodeName=gpu02 Arch=x86_64
+   State=MIXED
+   CfgTRES=cpu=128,mem=2000G,billing=128,gres/gpu:mi355x=8
+   AllocTRES=cpu=32,mem=500G,gres/gpu:mi355x=2
+
+NodeName=gpu03 Arch=x86_64
+   State=IDLE+DRAIN
+   CfgTRES=cpu=128,mem=2000G,gres/gpu=8
+   AllocTRES=
+
+NodeName=cpu01 Arch=x86_64
+   State=IDLE
+   CfgTRES=cpu=64,mem=256G,billing=64
+   AllocTRES=cpu=8,mem=16G
+"""
+
+
+def test_slurm_free_resources_and_packed_allocation(tmp_path):
+    from areal_vllm_amd.scheduler import slurm_utils as su
+
+    nodes = su.parse_scontrol_nodes(SCONTROL)
+    assert set(nodes) == {"gpu01", "gpu02", "cpu01"}  # the draining node is not offered
+    assert nodes["gpu01"] == su.NodeResource(128, 2000 * 1024, 8)
+    assert nodes["gpu02"] == su.NodeResource(96, 1500 * 1024, 6) and nodes["cpu01"] == su.NodeResource(56, 240 * 1024, 0)
+    assert su.expand_nodelist("gpu[01-03,07],cpu1") == ["gpu01", "gpu02", "gpu03", "gpu07", "cpu1"]
+    reqs = [su.LaunchRequest("master_worker", 1, su.NodeResource(4, 16000, 0)),
+            su.LaunchRequest("model_worker", 12, su.NodeResource(8, 64000, 1)),
+            su.LaunchRequest("rollout_worker", 4, su.NodeResource(2, 4000, 0)),
+            su.LaunchRequest("generation_server", 2, su.NodeResource(8, 64000, 1))]
+    placed, left = su.allocate_resources(reqs, nodes)
+    by = {p.name: p for p in placed}
+    # model workers 0-7 fill the emptiest node in order, 8-11 continue on the next: rank neighbours share a node
+    assert by["model_worker"].hosts == ["gpu01"] * 8 + ["gpu02"] * 4
+    assert by["model_worker"].local_ids == list(range(8)) + list(range(4))
+    assert by["generation_server"].hosts == ["gpu02", "gpu02"] and left["gpu02"].gpu == 0 and left["gpu01"].gpu == 0
+    assert len(set(by["rollout_worker"].hosts)) >= 2  # CPU-only arrays spread out
+    assert all(v.valid() for v in left.values())
+    assert by["model_worker"].multiprog("run -i {index} -l {local}").splitlines()[9] == "9 run -i 9 -l 1"
+    with pytest.raises(su.SlurmResourceNotEnoughException, match="model_worker"):
+        su.allocate_resources([su.LaunchRequest("model_worker", 15, su.NodeResource(8, 64000, 1))], nodes)
+    only = su.allocate_resources([su.LaunchRequest("x", 2, su.NodeResource(1, 100, 1), nodelist="gpu[02-03]")], nodes)[0][0]
+    assert only.hosts == ["gpu02", "gpu02"]
+
+
+def test_slurm_client_pins_the_allocation_with_hostfile_and_multiprog(tmp_path):
+    from areal_vllm_amd.scheduler import slurm_utils as su
+    from areal_vllm_amd.scheduler.client import SlurmSchedulerClient
+
+    nodes = su.parse_scontrol_nodes(SCONTROL)
+    c = SlurmSchedulerClient("e", "t", fileroot=str(tmp_path), allocate=True, node_resources=nodes)
+    script = c.render_allocated("model_worker", "python -m areal_vllm_amd.apps.remote worker -w model_worker -i {index}",
+                                10, gpu=1, cpu=8, mem=64000, env_vars={"A": "1"})
+    assert "#SBATCH --nodelist=gpu01,gpu02" in script and "#SBATCH --gres=gpu:8" in script
+    assert "--distribution=arbitrary" in script and "export SLURM_HOSTFILE=" in script and "export A=1" in script
+    d = c._dir()
+    assert open(f"{d}/model_worker.hostfile").read().split() == ["gpu01"] * 8 + ["gpu02"] * 2
+    mp = open(f"{d}/model_worker.multiprog").read().splitlines()
+    assert mp[8].startswith("8 bash -c 'export LOCAL_RANK=0; python") and mp[8].rstrip().endswith("-i 8'")
+    # the second array sees what the first one left
+    c.render_allocated("generation_server", "serve {index}", 4, gpu=1, cpu=8, mem=64000)
+    assert open(f"{d}/generation_server.hostfile").read().split() == ["gpu02"] * 4
+    with pytest.raises(su.SlurmResourceNotEnoughException):
+        c.render_allocated("one_more", "x", 1, gpu=1)
