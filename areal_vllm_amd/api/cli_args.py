@@ -125,6 +125,9 @@ class NativeEngineConfig:
                                                       "recomputing the LM head"})
     logprob_chunk: int = 8192
     sequence_parallel: bool = False
+    overlap_grad_reduce: bool = field(default=True, metadata={
+        "help": "ZeRO-1: reduce gradient buckets to their owners during the last backward pass of a step instead "
+                "of one reduce-scatter after it"})
     zero_stage: int = field(default=1, metadata={
         "help": "1: bf16 weights and fp32 gradients replicated, optimizer state sharded over dp (two large "
                 "collectives per step; the default with 288 GB per GPU). 3: weights, gradients and optimizer state "

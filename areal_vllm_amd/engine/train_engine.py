@@ -499,9 +499,20 @@ class NativeTrainEngine(TrainEngine):
                 loss = loss + aux
             if self.zero3 is not None:
                 self.zero3.in_backward = True
+            elif i == len(mb_list.padded_mbs) - 1 and self._can_overlap_grad_reduce():
+                self.optimizer.arm_overlap()
             (loss * scale).backward()
             self._end_mb()
         return self.optimizer_step()
+
+    def _can_overlap_grad_reduce(self) -> bool:
+        """Gradient buckets may leave during the backward only if nothing still has to touch the full buffer
+        afterwards: tensor-parallel replicas whose gradients are partial sums are combined on the full buffer
+        first, and routed experts have an optimizer (and a group) of their own."""
+        g = self.grid
+        if not self.config.native.overlap_grad_reduce or self.expert_optimizer is not None:
+            return False
+        return not (g.tp > 1 and (self._kv_replication() > 1 or self._partial_grad_ranges()))
 
     def _begin_mb(self):
         """ZeRO-3: the parameters outside the decoder blocks become whole for this micro-batch."""

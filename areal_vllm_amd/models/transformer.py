@@ -81,6 +81,9 @@ def _fold_grad(p: torch.Tensor):
     if p.grad is not None:
         p.main_grad.add_(p.grad)
         p.grad = None
+        done = getattr(p, "_after_fold", None)
+        if done is not None:  # overlapped gradient reduction (parallel/zero.py) counts finished parameters
+            done(p)
 
 
 # ----------------------------------------------------------------------------- TP collectives

@@ -48,6 +48,9 @@ class _LinearMainGrad(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if main:
                 _accumulate_wgrad(weight, dy2, x.reshape(-1, x.shape[-1]))
+                done = getattr(weight, "_after_fold", None)
+                if done is not None:  # the gradient went into the fp32 buffer without passing the accumulation hook
+                    done(weight)
             else:
                 dw = torch.mm(dy2.t(), x.reshape(-1, x.shape[-1]))
         db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
@@ -87,6 +90,9 @@ class _EmbeddingMainGrad(torch.autograd.Function):
         (ids,) = ctx.saved_tensors
         w = ctx.weight
         w.main_grad.index_add_(0, ids.reshape(-1), dy.reshape(-1, dy.shape[-1]).to(w.main_grad.dtype))
+        done = getattr(w, "_after_fold", None)
+        if done is not None:  # this contribution never passes the accumulation hook: report it ourselves
+            done(w)
         return None, None
 
 

@@ -5,7 +5,10 @@ kept replicated (ZeRO-1) and only the fp32 master weights and Adam moments are s
 data-parallel group. A step is then ONE reduce-scatter of the flat fp32 gradient buffer and ONE
 all-gather of the flat bf16 parameter buffer (large, bandwidth-efficient xGMI transfers) instead of the
 per-layer all-gather / reduce-scatter traffic of FSDP2 that the reference uses
-(``areal/utils/fsdp.py:253-285``). A 7B model costs 14 GB (bf16 params) + 28 GB (fp32 grads) replicated
+(``areal/utils/fsdp.py:253-285``). The reduce-scatter can hide behind the last backward of the step
+(`arm_overlap`): every rank's shard range is cut into a few buckets, and as soon as the gradients of all
+parameters that touch a bucket are final, the bucket is reduced to its owner asynchronously - the same bytes over
+the same links, issued while the remaining layers still compute. A 7B model costs 14 GB (bf16 params) + 28 GB (fp32 grads) replicated
 plus 84/dp GB of sharded optimizer state per GPU; larger models add tensor / pipeline parallelism.
 
 The whole step (norm -> clip coefficient -> non-finite check -> AdamW -> bf16 shadow) runs on device
@@ -51,12 +54,86 @@ class ShardedAdamW:
         self.replicated_ranges = sorted(replicated_ranges or [])
         self._norm_buf = torch.zeros(2, dtype=torch.float32, device=dev)
         self.lr = cfg.lr
+        # ---- overlapped reduction: buckets = `buckets_per_shard` equal slices of every rank's shard range
+        self.buckets: List[Tuple[int, int, int]] = []  # (lo, hi, owner rank in the group)
+        self._bucket_of: Dict[int, List[int]] = {}  # id(parameter) -> buckets its flat range touches
+        self._bucket_params: List[int] = []
+        self._armed = False
+        self._pending: List[int] = []
+        self._works: List = []
+        self._launched: List[bool] = []
+        self.overlapped_buckets = 0  # buckets that left during a backward pass (all steps so far)
+        if self.n > 1:
+            per = max(1, 4)
+            for r in range(self.n):
+                step = (self.shard_numel + per - 1) // per
+                for b in range(per):
+                    lo = r * self.shard_numel + b * step
+                    hi = min((r + 1) * self.shard_numel, lo + step)
+                    if hi > lo:
+                        self.buckets.append((lo, hi, r))
+            self._bucket_params = [0] * len(self.buckets)
+            starts = [b[0] for b in self.buckets]
+            import bisect
+
+            for name, (o, numel) in flat.offsets.items():
+                p = flat._named[name]
+                first = max(0, bisect.bisect_right(starts, o) - 1)
+                ids = [i for i in range(first, len(self.buckets))
+                       if self.buckets[i][0] < o + numel and self.buckets[i][1] > o]
+                self._bucket_of[id(p)] = ids
+                # An embedding table reports twice when it is also the (tied) LM head: once through the
+                # accumulation hook (head GEMM) and once from the lookup's backward, which adds its rows to the
+                # fp32 buffer directly (ops/linear.py). Its buckets wait for both; an untied table never fires
+                # the hook, so its buckets leave with the flush after the backward.
+                events = 2 if name.split(".")[-1] in ("embed", "pos_embed") else 1
+                for i in ids:
+                    self._bucket_params[i] += events
+                p._after_fold = self._param_done
+
+    # ------------------------------------------------------------- overlapped gradient reduction
+    def arm_overlap(self):
+        """Call right before the LAST backward pass of a step: from now on a bucket is reduced to the rank that
+        owns it as soon as every parameter touching it has folded its gradient into the fp32 buffer."""
+        if self.n == 1:
+            return
+        self._armed = True
+        self._pending = list(self._bucket_params)
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def _launch(self, i: int):
+        lo, hi, owner = self.buckets[i]
+        dst = dist.get_global_rank(self.group, owner) if self.group is not None else owner
+        self._works.append(dist.reduce(self.flat.main_grad[lo:hi], dst=dst, op=dist.ReduceOp.SUM, group=self.group,
+                                       async_op=True))
+        self._launched[i] = True
+
+    def _param_done(self, p):
+        if not self._armed:
+            return
+        for i in self._bucket_of.get(id(p), ()):
+            self._pending[i] -= 1
+            if self._pending[i] == 0:
+                self._launch(i)
+                self.overlapped_buckets += 1
 
     # ------------------------------------------------------------------ gradient reduction
     def reduce_gradients(self):
         g = self.flat.main_grad
         if self.n == 1:
             return g
+        if self._armed:
+            # buckets some of whose parameters got no gradient in the last backward (and the padding at the end
+            # of the buffer, when it is not empty) were never launched: reduce them now, then wait for all
+            self._armed = False
+            for i, done in enumerate(self._launched):
+                if not done and self._bucket_params[i] > 0:
+                    self._launch(i)
+            for w in self._works:
+                w.wait()
+            self._works = []
+            return g[self.lo:self.hi]
         comm.reduce_scatter_sum(self.grad_shard, g, self.group)
         return self.grad_shard
 
@@ -95,6 +172,7 @@ class ShardedAdamW:
         gshard = self.reduce_gradients()
         if self.n == 1:
             gshard = gshard[self.lo:self.hi]
+        assert gshard.numel() == self.shard_numel
         self._sumsq(gshard)
         self._gshard = gshard
         return self.state[0:1]

@@ -98,6 +98,11 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
     for _ in range(2):
         stats.append(eng.train_batch(local, _sft_loss, _weight))
         eng.step_lr_scheduler()
+    if eng.zero3 is None and eng.grid.pp == 1 and eng.grid.dp * eng.grid.cp > 1 and eng.expert_optimizer is None \
+            and eng._can_overlap_grad_reduce():
+        # both steps sent (almost) all gradient buckets on their way while the last backward was still running
+        assert eng.optimizer.overlapped_buckets >= len(eng.optimizer.buckets), \
+            (eng.optimizer.overlapped_buckets, len(eng.optimizer.buckets))
     ev = eng.eval_batch(local, _sft_loss, _weight)
     fw = eng.forward(local, post_hook=lambda proxy, mb: proxy.logprobs(torch.roll(mb["input_ids"], -1, 0)))
     eng.save(SaveLoadMeta(path=ckpt_out, weight_format="hf", with_optim=False))
