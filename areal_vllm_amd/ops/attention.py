@@ -164,10 +164,13 @@ def _flash_bwd_hip(q, k, v, out, dout, lse, dq, dk, dv, cu_q, cu_k, max_k, scale
     Hkv = k.shape[1]
     B = cu_q.numel() - 1
     delta = torch.empty(Hq, Tq, dtype=torch.float32, device=q.device)
-    dq_acc = torch.zeros(Tq, Hq, D, dtype=torch.float32, device=q.device)
+    # the fp32 accumulator of the atomic dQ path; long sequences compute dQ in a kernel of its own and need none
+    split = bool(L.lib().areal_flash_bwd_split(L.c_int(int(max_k))))
+    dq_acc = None if split else torch.zeros(Tq, Hq, D, dtype=torch.float32, device=q.device)
     L.check(
         L.lib().areal_flash_bwd(
-            L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dq_acc),
+            L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), L.ptr(dout), L.ptr(lse), L.ptr(delta),
+            L.ptr(dq_acc) if dq_acc is not None else None,
             L.ptr(dq), L.ptr(dk), L.ptr(dv), L.ptr(cu_q), L.ptr(cu_k), L.c_int(B), L.c_int(int(max_k)),
             L.c_int(Tq), L.c_int(Hq), L.c_int(Hkv), L.c_int(D), L.c_int64(_strides(q)), L.c_int64(_strides(k)),
             L.c_int64(_strides(v)), L.c_int64(_strides(out)), L.c_int64(_strides(dout)), L.c_int64(_strides(dq)),

@@ -417,6 +417,9 @@ def test_ray_controller_runs_an_experiment_with_ray_tasks_as_workers(tmp_path, m
     exp.train_bs_n_seqs = 8
     exp.exp_ctrl = ExperimentSaveEvalControl(total_train_epochs=1)
     monkeypatch.setenv("AREAL_PLATFORM", "cpu")
+    # the tasks are fresh processes with the default (file-based) name service; an earlier test of this session
+    # may have left the in-memory one selected here
+    name_resolve.reconfigure("nfs", nfs_record_root="/tmp/areal/name_resolve")
     name_resolve.clear_subtree(names.trial_root("t-ray", "t0"))
     ray = _FakeRay({"CPU": 64, "GPU": 2, "memory": 512 * 1024 ** 3, "node:127.0.0.1": 1.0})
     RayController("t-ray", "t0", ray_module=ray).start(exp, env=dict(AREAL_PLATFORM="cpu"), timeout=300)

@@ -1,4 +1,8 @@
-"""Time the varlen flash-attention forward / backward kernels on a trainer-shaped packed batch."""
+"""Time the varlen flash-attention forward / backward kernels on a trainer-shaped packed batch.
+
+    python tools/attn_probe.py                      # 25 sequences of ~1150 tokens, 12 q / 2 kv heads (Qwen2-1.5B)
+    python tools/attn_probe.py 24576 28 4           # one sequence of 24576 tokens, 28 q / 4 kv heads (Qwen2.5-7B)
+"""
 import sys, time, torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +11,9 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 Hq, Hkv, D = 12, 2, 128
 lens = torch.randint(1050, 1216, (25,)).tolist()
+if len(sys.argv) > 1:
+    lens = [int(x) for x in sys.argv[1].split(",")]
+    Hq, Hkv = int(sys.argv[2]), int(sys.argv[3])
 T = sum(lens)
 cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=dev)
 qkv = torch.randn(T, Hq + 2 * Hkv, D, device=dev, dtype=torch.bfloat16, requires_grad=True)
@@ -16,7 +23,7 @@ out = fwd(); g = torch.randn_like(out)
 def fb():
     qkv.grad = None
     fwd().backward(g)
-def bench(fn, n=20):
+def bench(fn, n=20 if sum(lens) < 60000 else 5):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(n): fn()
