@@ -49,8 +49,9 @@ def attention_varlen_ref(q, k, v, cu_q, cu_k, scale, causal=True):
 
 
 def attention_varlen_sdpa(q, k, v, cu_q, cu_k, scale, causal=True):
-    """Head sizes other than 128 on the GPU (the MFMA kernels are specialised for D = 128, the head size
-    of the Qwen2 / Llama-3 8B+ families): PyTorch's fused attention, one call per packed sequence, the
+    """Head sizes above 128 on the GPU (the MFMA kernels are specialised for D = 128, the head size of the
+    Qwen2 / Llama-3 8B+ families; smaller heads run on them zero-padded, see `_pad_heads`; 256 of Gemma comes
+    here): PyTorch's fused attention, one call per packed sequence, the
     causal mask aligned to the bottom-right corner. Differentiable through autograd; returns out only."""
     import torch.nn.functional as F
 
@@ -76,6 +77,18 @@ def attention_varlen_sdpa(q, k, v, cu_q, cu_k, scale, causal=True):
 
 
 HIP_HEAD_DIM = 128  # the head size flash_attn.hip / paged_attn.hip are built for
+
+
+def _pad_heads(t: torch.Tensor) -> torch.Tensor:
+    """[.., D] -> [.., 128] with zeros. Zero columns change neither q.k nor the first D columns of p.v, so a
+    smaller head (64 of Qwen2-0.5B, 80 / 96 of the Phi and small Llama families) runs on the same MFMA kernels,
+    packed sequences and all, at the price of the idle half of every K-slab; the caller passes the softmax scale
+    of the true head size and drops the padded output columns. Autograd slices the gradients back."""
+    return torch.nn.functional.pad(t, (0, HIP_HEAD_DIM - t.shape[-1]))
+
+
+def _paddable(d: int) -> bool:
+    return d < HIP_HEAD_DIM and d % 8 == 0
 
 
 # ------------------------------------------------------------------------------- autograd op
@@ -130,6 +143,10 @@ def flash_attn_varlen_qkv(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqle
     if scale is None:
         scale = 1.0 / math.sqrt(qkv.shape[-1])
     if L.use_hip(qkv) and qkv.shape[-1] != HIP_HEAD_DIM:
+        d = qkv.shape[-1]
+        if _paddable(d):
+            return _FlashVarlenFn.apply(_pad_heads(qkv), cu_seqlens, int(max_seqlen), n_q_heads, n_kv_heads,
+                                        float(scale), causal)[..., :d]
         q, k, v = qkv.split([n_q_heads, n_kv_heads, n_kv_heads], 1)
         return attention_varlen_sdpa(q, k, v, cu_seqlens, cu_seqlens, float(scale), causal)
     return _FlashVarlenFn.apply(qkv, cu_seqlens, int(max_seqlen), n_q_heads, n_kv_heads, float(scale), causal)
@@ -224,6 +241,10 @@ def flash_attn_varlen_sep(q, k, v, cu_q, cu_k, max_q: int, max_k: int, scale: Op
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
     if L.use_hip(q) and q.shape[-1] != HIP_HEAD_DIM:
+        d = q.shape[-1]
+        if _paddable(d):
+            return _FlashVarlenSepFn.apply(_pad_heads(q), _pad_heads(k), _pad_heads(v), cu_q, cu_k, int(max_q),
+                                           int(max_k), float(scale), causal)[..., :d]
         return attention_varlen_sdpa(q, k, v, cu_q, cu_k, float(scale), causal)
     return _FlashVarlenSepFn.apply(q, k, v, cu_q, cu_k, int(max_q), int(max_k), float(scale), causal)
 
@@ -234,7 +255,11 @@ def flash_attn_varlen(q, k, v, cu_q, cu_k, max_q, scale=None, causal=True):
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
     if L.use_hip(q):
-        if q.shape[-1] != HIP_HEAD_DIM:  # no log-sum-exp on this path (the prefill does not need it)
+        d = q.shape[-1]
+        if _paddable(d):
+            out, lse = _flash_fwd_hip(_pad_heads(q), _pad_heads(k), _pad_heads(v), cu_q, cu_k, max_q, scale, causal)
+            return out[..., :d], lse
+        if d != HIP_HEAD_DIM:  # no log-sum-exp on this path (the prefill does not need it)
             return attention_varlen_sdpa(q, k, v, cu_q, cu_k, float(scale), causal), None
         return _flash_fwd_hip(q, k, v, cu_q, cu_k, max_q, scale, causal)
     return attention_varlen_ref(q, k, v, cu_q, cu_k, scale, causal)

@@ -133,10 +133,11 @@ def test_flash_attn_fwd_bwd(Hq, Hkv, lens):
     _close(qkv.grad[:, Hq + Hkv:].cpu(), qf.grad[:, Hq + Hkv:], 3e-2, 5e-2, "dv")
 
 
-@pytest.mark.parametrize("D,Hq,Hkv", [(64, 8, 2), (256, 4, 1), (80, 4, 4)])
+@pytest.mark.parametrize("D,Hq,Hkv", [(64, 8, 2), (256, 4, 1), (80, 4, 4), (96, 6, 2)])
 def test_attention_head_sizes_other_than_128(D, Hq, Hkv):
-    """Head sizes the MFMA kernel is not built for take PyTorch's fused attention per sequence; forward,
-    backward and the bottom-right aligned mask of the separate-stream entry against the fp32 reference."""
+    """Smaller heads run zero-padded on the MFMA kernels, larger ones take PyTorch's fused attention per
+    sequence; forward, backward and the bottom-right aligned mask of the separate-stream entries against the
+    fp32 reference."""
     torch.manual_seed(5)
     lens = [33, 1, 130, 64]
     T = sum(lens)
@@ -159,6 +160,18 @@ def test_attention_head_sizes_other_than_128(D, Hq, Hkv):
     want, _ = A.attention_varlen_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), cq.cpu(), cu.cpu(),
                                      1.0 / math.sqrt(D), True)
     _close(got.cpu(), want, 2e-2, 2e-2, "prefix-extend out")
+    q2 = q.clone().requires_grad_(True)
+    kv2 = qkv.detach()[:, Hq:].clone().requires_grad_(True)
+    o2 = ops.flash_attn_varlen_sep(q2, kv2[:, :Hkv], kv2[:, Hkv:], cq, cu, max(lq), max(lens))
+    g2 = torch.randn_like(o2)
+    o2.backward(g2)
+    qf2 = q.float().cpu().requires_grad_(True)
+    kvf2 = kv2.detach().float().cpu().requires_grad_(True)
+    r2, _ = A.attention_varlen_ref(qf2, kvf2[:, :Hkv], kvf2[:, Hkv:], cq.cpu(), cu.cpu(), 1.0 / math.sqrt(D), True)
+    r2.backward(g2.float().cpu())
+    _close(o2.cpu(), r2, 2e-2, 2e-2, "sep out")
+    _close(q2.grad.cpu(), qf2.grad, 3e-2, 5e-2, "sep dq")
+    _close(kv2.grad.cpu(), kvf2.grad, 3e-2, 5e-2, "sep dkv")
 
 
 def test_flash_attn_prefix_extend():
