@@ -99,6 +99,7 @@ class NativeInferenceEngine:
         self._free_penalty_slots: List[int] = []
         self._slots_to_clear: List[int] = []
         self._mm_ids: Dict[str, int] = {}  # request id -> scheduler id of requests that carry images
+        self._streams: Dict[str, list] = {}  # streaming requests: request id -> [scheduler id, tokens sent, callback]
         self.update_group = None
         self.update_groups: Dict[str, Any] = {}
         # tensor-parallel serving: rank 0 of the TP group owns the scheduler and tells the other ranks
@@ -344,6 +345,8 @@ class NativeInferenceEngine:
             req_id = self.sched.add_request(rid, sched_prompt, sp["max_new_tokens"], sp["min_new_tokens"],
                                             sp["temperature"], sp["top_p"], sp["top_k"], sp["stop_token_ids"],
                                             sp["stop_sequences"], sp["frequency_penalty"], sp["presence_penalty"], slot)
+            if sp.get("on_tokens") is not None:
+                self._streams[rid] = [req_id, 0, sp["on_tokens"]]
             if mm is not None and self.runner.is_vl:
                 self.runner.register_multimodal(req_id, prompt, mm["pixel_values"], mm["image_grid_thw"])
                 self._mm_ids[rid] = req_id
@@ -362,8 +365,22 @@ class NativeInferenceEngine:
                 traceback.print_exc()
                 done.put((False, e))
 
+    def _flush_streams(self):
+        """Hand streaming requests the tokens they have produced since the last call."""
+        for rid, st in self._streams.items():
+            p = self.sched.progress(st[0], st[1])
+            if p is not None and p[0]:
+                st[1] += len(p[0])
+                st[2](list(p[0]), list(p[1]), list(p[2]))
+
     def _deliver(self):
+        if self._streams:
+            self._flush_streams()
         for f in self.sched.take_finished():
+            st = self._streams.pop(f["rid"], None)
+            if st is not None and len(f["output_tokens"]) > st[1]:  # the tail produced by the request's last plan
+                st[2](list(f["output_tokens"][st[1]:]), list(f["output_logprobs"][st[1]:]),
+                      list(f["output_versions"][st[1]:]))
             res = GenerationResult(rid=f["rid"], output_tokens=list(f["output_tokens"]),
                                    output_logprobs=list(f["output_logprobs"]),
                                    output_versions=list(f["output_versions"]), finish_reason=f["finish_reason"],
@@ -381,6 +398,7 @@ class NativeInferenceEngine:
                 w(res)
 
     def _fail_all(self, msg):
+        self._streams.clear()
         with self._lock:
             ws = list(self._waiters.items())
             self._waiters.clear()
@@ -407,8 +425,11 @@ class NativeInferenceEngine:
                callback: Optional[Callable[[GenerationResult], None]] = None,
                multimodal: Optional[Dict[str, torch.Tensor]] = None,
                stop_sequences: Optional[List[List[int]]] = None, frequency_penalty: float = 0.0,
-               presence_penalty: float = 0.0):
-        """`multimodal`: {"pixel_values" [n_patches, C*tp*P*P], "image_grid_thw" [n_images, 3]} for prompts
+               presence_penalty: float = 0.0,
+               on_tokens: Optional[Callable[[List[int], List[float], List[int]], None]] = None):
+        """`on_tokens(tokens, logprobs, versions)`: streaming - called from the engine thread with every batch of
+        newly generated tokens (one call per processed plan), before `callback` receives the complete result.
+        `multimodal`: {"pixel_values" [n_patches, C*tp*P*P], "image_grid_thw" [n_images, 3]} for prompts
         whose `input_ids` contain image placeholder tokens (vision-language models). `stop_sequences`: token-id
         sequences; generation stops (reason "stop") when the generated tokens end with one of them.
         `frequency_penalty` / `presence_penalty`: logit - f * count - p * (count > 0) over the tokens this
@@ -417,7 +438,8 @@ class NativeInferenceEngine:
                   temperature=0.0 if greedy else float(temperature), top_p=float(top_p),
                   top_k=int(min(top_k, 1 << 30)), stop_token_ids=[int(x) for x in (stop_token_ids or [])],
                   stop_sequences=[[int(t) for t in seq] for seq in (stop_sequences or []) if len(seq)],
-                  frequency_penalty=float(frequency_penalty), presence_penalty=float(presence_penalty))
+                  frequency_penalty=float(frequency_penalty), presence_penalty=float(presence_penalty),
+                  on_tokens=on_tokens)
         with self._lock:
             if rid in self._waiters:
                 raise ValueError(f"duplicate request id {rid}")
@@ -482,6 +504,14 @@ class NativeInferenceEngine:
             n = self.sched.abort_all()
             self._deliver()
             return n
+        return self._control(f)
+
+    def abort(self, rid: str) -> bool:
+        """Abort one request (its waiter receives finish reason "abort"); False if the scheduler does not hold it."""
+        def f():
+            ok = self.sched.abort(rid)
+            self._deliver()
+            return ok
         return self._control(f)
 
     def flush_cache(self):

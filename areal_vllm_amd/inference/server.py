@@ -4,7 +4,7 @@ Speaks the REST verbs the reference's clients use against SGLang (``areal/engine
 251-309, 368-480``; ``realhf/system/gserver_manager.py:158-173``):
 
   GET  /health, /health_generate, /get_model_info, /get_server_info, /metrics (Prometheus text)
-  POST /generate {input_ids, sampling_params, return_logprob, stream:false, rid}
+  POST /generate {input_ids, sampling_params, return_logprob, stream, rid}   (stream: true -> server-sent events)
        sampling_params: max_new_tokens, min_new_tokens, temperature, top_p, top_k, stop_token_ids,
        stop_sequences (token-id sequences), stop (strings: tokenised here with the server's tokenizer),
        frequency_penalty, presence_penalty, ignore_eos, n (must be 1). Any other key is refused (400): a
@@ -147,8 +147,6 @@ class InferenceServer:
             extra = sorted(set(body) - REQUEST_KEYS)
             if extra:
                 raise BadRequest(f"unsupported request field(s) {extra}")
-            if body.get("stream"):
-                raise BadRequest("streaming responses are not supported (stream must be false)")
             kw = parse_sampling_params(body.get("sampling_params", {}) or {}, self._stop_to_ids())
         except (BadRequest, TypeError, ValueError) as e:
             return web.json_response({"error": str(e)}, status=400)
@@ -158,6 +156,8 @@ class InferenceServer:
                 multimodal = await self._offload(self._process_images, body["image_data"])
             except Exception as e:
                 return web.json_response({"error": f"cannot process image_data: {e!r}"}, status=400)
+        if body.get("stream"):
+            return await self._generate_stream(req, rid, ids, multimodal, kw)
         res = await self.engine.agenerate_once(f"{rid}-{uuid.uuid4().hex[:8]}", ids, multimodal=multimodal, **kw)
         meta = {
             "id": rid, "finish_reason": _finish(res.finish_reason), "prompt_tokens": res.prompt_len,
@@ -167,6 +167,51 @@ class InferenceServer:
             "e2e_latency": res.latency, "ttft": res.ttft,
         }
         return web.json_response({"text": "", "output_ids": res.output_tokens, "meta_info": meta})
+
+    async def _generate_stream(self, req, rid, ids, multimodal, kw):
+        """Server-sent events: one `data: {...}` event per batch of new tokens (`output_ids` = the tokens of this
+        event, `meta_info.output_token_logprobs` / `output_versions` likewise, `completion_tokens` cumulative,
+        `finish_reason` null), a last event that carries the finish reason and no tokens, then `data: [DONE]`.
+        A client that goes away aborts its request."""
+        import json
+
+        loop = asyncio.get_running_loop()
+        q: "asyncio.Queue" = asyncio.Queue()
+        engine_rid = f"{rid}-{uuid.uuid4().hex[:8]}"
+        self.engine.submit(
+            engine_rid, ids, multimodal=multimodal,
+            on_tokens=lambda t, l, v: loop.call_soon_threadsafe(q.put_nowait, ("tokens", (t, l, v))),
+            callback=lambda res: loop.call_soon_threadsafe(q.put_nowait, ("done", res)), **kw)
+        resp = web.StreamResponse(headers={"Content-Type": "text/event-stream", "Cache-Control": "no-cache"})
+        await resp.prepare(req)
+        sent = 0
+        try:
+            while True:
+                kind, item = await q.get()
+                if kind == "tokens":
+                    toks, lps, vers = item
+                    sent += len(toks)
+                    ev = {"text": "", "output_ids": toks,
+                          "meta_info": {"id": rid, "finish_reason": None, "prompt_tokens": len(ids),
+                                        "completion_tokens": sent, "output_versions": vers,
+                                        "output_token_logprobs": [(lp, t, None) for lp, t in zip(lps, toks)]}}
+                else:
+                    res = item
+                    ev = {"text": "", "output_ids": [],
+                          "meta_info": {"id": rid, "finish_reason": _finish(res.finish_reason),
+                                        "prompt_tokens": res.prompt_len, "completion_tokens": len(res.output_tokens),
+                                        "output_versions": [], "output_token_logprobs": [],
+                                        "weight_version": self.engine.get_version(), "e2e_latency": res.latency,
+                                        "ttft": res.ttft}}
+                await resp.write(f"data: {json.dumps(ev)}\n\n".encode())
+                if kind == "done":
+                    break
+            await resp.write(b"data: [DONE]\n\n")
+            await resp.write_eof()
+        except (ConnectionResetError, asyncio.CancelledError):
+            await self._offload(self.engine.abort, engine_rid)
+            raise
+        return resp
 
     def _stop_to_ids(self):
         """str -> token ids with the server's tokenizer, or None when there is none to load."""

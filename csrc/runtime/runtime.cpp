@@ -256,6 +256,14 @@ PYBIND11_MODULE(_runtime, m) {
       .def("process_decode", &PyScheduler::process_decode, py::arg("tokens"), py::arg("logprobs"),
            py::arg("plan_id") = -1, py::arg("successor_in_flight") = false)
       .def("take_finished", &PyScheduler::take_finished)
+      .def("progress",
+           [](PyScheduler& s, int64_t id, int from) -> py::object {
+             std::vector<int32_t> t, v;
+             std::vector<float> l;
+             if (!s.s_.progress(id, from, t, l, v)) return py::none();
+             return py::make_tuple(t, l, v);
+           },
+           py::arg("req_id"), py::arg("from_index"))
       .def("pause", [](PyScheduler& s) { s.s_.pause(); })
       .def("resume", [](PyScheduler& s) { s.s_.resume(); })
       .def("paused", [](PyScheduler& s) { return s.s_.paused(); })

@@ -184,6 +184,22 @@ class Scheduler {
     return n;
   }
 
+  // Streaming: the tokens request `id` has generated beyond its first `from` (with log-probs and weight versions).
+  // False when the request is no longer live (its complete output is in the finished list).
+  bool progress(int64_t id, int from, std::vector<int32_t>& toks, std::vector<float>& lps,
+                std::vector<int32_t>& vers) const {
+    auto it = reqs_.find(id);
+    if (it == reqs_.end()) return false;
+    const Request& r = *it->second;
+    const int n = r.n_generated();
+    for (int i = std::max(0, from); i < n; ++i) {
+      toks.push_back(r.tokens[r.prompt_len + i]);
+      lps.push_back(i < (int)r.logprobs.size() ? r.logprobs[i] : 0.f);
+      vers.push_back(i < (int)r.versions.size() ? r.versions[i] : version_);
+    }
+    return true;
+  }
+
   bool abort(const std::string& rid) {
     release_deferred();
     for (auto& kv : reqs_) {

@@ -4,6 +4,7 @@ request validation of the HTTP front end. The sampling fields are those of the r
 ``GenerationHyperparameters`` (``areal/api/cli_args.py:81-133``) as its client sends them
 (``areal/engine/sglang_remote.py:121-143``)."""
 import asyncio
+import json
 import socket
 import threading
 
@@ -205,7 +206,6 @@ def test_generate_rejects_what_it_cannot_honour(server):
     bad = _gen(server, {"max_new_tokens": 4, "repetition_penalty": 1.1, "beam_width": 4})
     assert bad.status_code == 400 and "repetition_penalty" in bad.json()["error"] and "beam_width" in bad.json()["error"]
     assert _gen(server, {"max_new_tokens": 4, "n": 2}).status_code == 400
-    assert _gen(server, {"max_new_tokens": 4}, stream=True).status_code == 400
     assert _gen(server, {"max_new_tokens": 4}, lora_path="x").status_code == 400
     no_tok = _gen(server, {"max_new_tokens": 4, "stop": ["</answer>"]})  # the preset has no tokenizer to map it with
     assert no_tok.status_code == 400 and "stop_sequences" in no_tok.json()["error"]
@@ -237,3 +237,38 @@ def test_parse_sampling_params_maps_stop_strings_through_the_tokenizer():
     assert kw["stop_sequences"] == [[9, 9], [97, 98], [99]] and kw["top_k"] == 1 << 30 and not kw["greedy"]
     with pytest.raises(BadRequest):
         parse_sampling_params({"stop": "x"}, stop_to_ids=None)
+
+
+def test_generate_streams_tokens_as_server_sent_events(server, eng):
+    """stream=true: tokens arrive in several events while the request runs, their concatenation (tokens,
+    log-probs, versions) is the non-streamed answer, the last event carries the finish reason."""
+    want = _gen(server, {"max_new_tokens": 40, "temperature": 0.0}).json()
+    events = []
+    with requests.post(f"{server}/generate", json={"input_ids": PROMPT, "stream": True, "sampling_params":
+                                                    {"max_new_tokens": 40, "temperature": 0.0}},
+                       stream=True, timeout=60) as r:
+        assert r.status_code == 200 and r.headers["Content-Type"].startswith("text/event-stream")
+        for line in r.iter_lines():
+            if line.startswith(b"data: "):
+                events.append(line[6:].decode())
+    assert events[-1] == "[DONE]"
+    evs = [json.loads(e) for e in events[:-1]]
+    chunks = [e for e in evs if e["output_ids"]]
+    assert len(chunks) >= 2, "the whole answer arrived in one event"
+    assert sum((e["output_ids"] for e in chunks), []) == want["output_ids"]
+    lps = [lp for e in chunks for lp, _t, _ in e["meta_info"]["output_token_logprobs"]]
+    assert lps == pytest.approx([lp for lp, _t, _ in want["meta_info"]["output_token_logprobs"]], abs=1e-4)
+    assert [e["meta_info"]["completion_tokens"] for e in chunks] == list(
+        __import__("itertools").accumulate(len(e["output_ids"]) for e in chunks))
+    assert all(e["meta_info"]["finish_reason"] is None for e in chunks)
+    last = evs[-1]
+    assert last["output_ids"] == [] and last["meta_info"]["finish_reason"]["type"] == "length"
+    assert last["meta_info"]["completion_tokens"] == 40
+    # engine-level callback: same stream without HTTP, a stop token ends it
+    got, done = [], threading.Event()
+    stop_at = want["output_ids"][5]
+    eng.submit("stream-direct", PROMPT, max_new_tokens=40, greedy=True, stop_token_ids=[stop_at],
+               on_tokens=lambda t, l, v: got.extend(t), callback=lambda res: (got.append(res), done.set()))
+    assert done.wait(60)
+    res = got.pop()
+    assert got == res.output_tokens == want["output_ids"][:want["output_ids"].index(stop_at) + 1]
