@@ -221,7 +221,7 @@ class NativeTrainEngine(TrainEngine):
         self.model = Transformer(
             mc, dtype=dtype, device=self.device, tp_size=g.tp, tp_rank=g.coord.tp, tp_group=g.group("tp"),
             layer_range=lr, layer_chunks=chunks, has_embed=g.coord.pp == 0, has_head=g.coord.pp == g.pp - 1,
-            ep_size=g.ep, ep_rank=g.rank_in("ep"), ep_group=g.group("ep"),
+            ep_size=g.ep, ep_rank=g.rank_in("ep"), ep_group=g.group("ep"), etp_size=g.etp,
             gradient_checkpointing=cfg.gradient_checkpointing,
             sequence_parallel=cfg.native.sequence_parallel and g.tp > 1,
             vocab_parallel=g.tp > 1,
@@ -236,7 +236,7 @@ class NativeTrainEngine(TrainEngine):
                 from ..parallel.ulysses import UlyssesContext
 
                 self.model.sp = UlyssesContext(g.group("cp"), g.cp, g.coord.cp)
-        edp = max(1, (g.dp // g.ep) * g.cp)
+        edp = max(1, len(g.group_ranks["edp"]))  # replicas of every expert shard
         flat = self.model.flatten(pad_to=g.dp * g.cp, expert_pad_to=edp if g.ep > 1 else None)
         if cfg.init_from_scratch or not (cfg.path and os.path.isdir(cfg.path)):
             # same seed on every dp replica; tp/pp shards draw from different streams
@@ -272,7 +272,10 @@ class NativeTrainEngine(TrainEngine):
             fe = self.model.flat_experts
             if fe is not None:
                 fe.alloc_main_grad()
-                emp = tuple(x for x in (g.group("tp"), g.group("pp"), g.group("ep")) if x is not None)
+                # groups whose members hold DIFFERENT expert parameters (their squared norms add up): whole
+                # experts are not split over tp - those ranks are part of the ep / edp groups
+                emp = tuple(x for x in (g.group("tp") if g.etp == g.tp else None, g.group("pp"), g.group("ep"))
+                            if x is not None)
                 self.expert_optimizer = ShardedAdamW(fe, self.optimizer_config, dp_group=g.group("edp"), mp_groups=emp)
             self._total_steps = max(1, ft_spec.total_train_steps if ft_spec is not None else 1)
         self.initialized = True
@@ -635,7 +638,7 @@ class NativeTrainEngine(TrainEngine):
         tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
         if g.coord.dp == 0 and g.coord.cp == 0:
             save_file({"flat": self.model.flat.flat.detach().cpu()}, os.path.join(meta.path, f"shard-{tag}.safetensors"))
-            manifest = dict(format="areal-sharded-v2", layout=dict(dp=g.dp, tp=g.tp, pp=g.pp, cp=g.cp, ep=g.ep, vpp=g.vpp),
+            manifest = dict(format="areal-sharded-v2", layout=dict(dp=g.dp, tp=g.tp, pp=g.pp, cp=g.cp, ep=g.ep, etp=g.etp, vpp=g.vpp),
                             dtype=str(self.model.dtype).replace("torch.", ""),
                             offsets={n: [int(o), int(k)] for n, (o, k) in self.model.flat.offsets.items()},
                             layer_range=list(self.model.layer_range))
@@ -644,10 +647,9 @@ class NativeTrainEngine(TrainEngine):
             if g.coord.pp == 0 and g.coord.tp == 0:
                 with open(os.path.join(meta.path, "config.json"), "w") as f:
                     json.dump(self.model_config.to_hf_dict(), f, indent=2)
-        if self.model.flat_experts is not None and g.coord.dp < g.ep and g.coord.cp == 0:
-            # ep rank = dp % ep: ranks dp = 0 .. ep-1 hold the ep distinct expert sets
+        if self.model.flat_experts is not None and g.holds_first_expert_replica():
             save_file({"flat_experts": self.model.flat_experts.flat.detach().cpu()},
-                      os.path.join(meta.path, f"experts-{tag}-ep{g.rank_in('ep')}.safetensors"))
+                      os.path.join(meta.path, self._expert_shard_file()))
         if meta.with_optim and self.optimizer is not None:
             sd = dict(optim=self.optimizer.state_dict(), lr_step=self._lr_step)
             if self.expert_optimizer is not None:
@@ -720,10 +722,16 @@ class NativeTrainEngine(TrainEngine):
             if int(lay.get("ep", 1)) != g.ep:
                 raise ValueError(f"sharded checkpoint holds ep{lay.get('ep', 1)} expert shards, this engine is ep{g.ep}; "
                                  "convert through the hf format")
-            tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
+            if int(lay.get("etp", lay.get("tp", 1))) != g.etp:
+                raise ValueError(f"sharded checkpoint splits experts over {lay.get('etp', lay.get('tp', 1))} ranks, "
+                                 f"this engine over {g.etp}; convert through the hf format")
             fe = self.model.flat_experts.flat
-            t = load_file(os.path.join(meta.path, f"experts-{tag}-ep{g.rank_in('ep')}.safetensors"))
+            t = load_file(os.path.join(meta.path, self._expert_shard_file()))
             fe.copy_(t["flat_experts"].to(fe.dtype))
+
+    def _expert_shard_file(self) -> str:
+        g = self.grid
+        return f"experts-pp{g.coord.pp}-tp{g.coord.tp if g.etp == g.tp else 0}-ep{g.rank_in('ep')}.safetensors"
 
     def save(self, meta: SaveLoadMeta):
         if meta.weight_format in ("dcp", "naive_distributed"):
@@ -734,16 +742,24 @@ class NativeTrainEngine(TrainEngine):
         # one writer per pipeline stage: dp rank 0, cp rank 0, tp rank 0 (tp shards are gathered)
         # (with expert parallelism every ep rank of the first expert-data-parallel replica also writes
         # its own experts)
-        participate = g.coord.dp < g.ep and g.coord.cp == 0
-        writer = participate and g.coord.tp == 0
+        if g.etp == g.tp:
+            participate = g.coord.dp < g.ep and g.coord.cp == 0
+            writer = participate and g.coord.tp == 0
+            experts_only = g.coord.dp > 0
+        else:
+            # whole experts: stage ranks 0 .. ep-1 (tp fastest) hold the distinct expert sets; the dense tensors
+            # need every rank of a participating tp group for their gathers, rank 0 writes them
+            participate = g.coord.dp < max(1, g.ep // g.tp)
+            writer = g.holds_first_expert_replica()
+            experts_only = g.expert_slot() > 0
         tag = f"-stage{g.coord.pp}" if g.pp > 1 else ""
         if g.ep > 1:
-            tag += f"-ep{g.coord.dp}"
+            tag += f"-ep{g.rank_in('ep')}"
         wm = {}
         with self.full_params():  # ZeRO-3: every rank helps to make the writer's parameters whole
             if participate:
                 wm = hf_io.save_hf_checkpoint(self.model, meta.path, stage_tag=tag, write=writer,
-                                              experts_only=g.coord.dp > 0)
+                                              experts_only=experts_only)
         if dist.is_initialized() and (g.pp > 1 or g.ep > 1):
             maps = [None] * g.world
             dist.all_gather_object(maps, wm if writer else {}, group=g.group("world"))

@@ -794,15 +794,16 @@ def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor]
         if cfg.n_experts > 0:
             gu, dn = params[pre + "mlp.gate_up"], params[pre + "mlp.down"]
             f = gu.shape[1] // 2
+            er = model.etp_rank  # position among the ranks that split an expert (0: whole experts)
             for le in range(gu.shape[0]):
                 e = blk.mlp.ep_rank * blk.mlp.n_local + le
                 gn, un, dnn = hf_io.hf_expert_names(cfg, i, e)
                 if gn in tensors:
-                    gu.data[le, :f].copy_(tensors[gn][tr * f:(tr + 1) * f])
+                    gu.data[le, :f].copy_(tensors[gn][er * f:(er + 1) * f])
                 if un in tensors:
-                    gu.data[le, f:].copy_(tensors[un][tr * f:(tr + 1) * f])
+                    gu.data[le, f:].copy_(tensors[un][er * f:(er + 1) * f])
                 if dnn in tensors:
-                    dn.data[le].copy_(tensors[dnn][:, tr * f:(tr + 1) * f])
+                    dn.data[le].copy_(tensors[dnn][:, er * f:(er + 1) * f])
     v_lo, v_hi = model.vocab_range  # the whole vocabulary unless the model shards it over tp
     if model.has_embed and "model.embed_tokens.weight" in tensors:
         params["embed"].data.copy_(tensors["model.embed_tokens.weight"][v_lo:v_hi])

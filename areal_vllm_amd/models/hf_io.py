@@ -200,7 +200,7 @@ def load_hf_weights(model, path: str, strict: bool = True) -> None:
         if cfg.n_experts > 0:
             put(pre + "mlp.router", rd.get(names["mlp.router"][0]))
             blk = model.layers[li].mlp
-            f_lo, f_hi = _tp_range(cfg.moe_intermediate_size, tp, tr)
+            f_lo, f_hi = _tp_range(cfg.moe_intermediate_size, model.etp_size, model.etp_rank)
             gus, downs = [], []
             for e in range(blk.ep_rank * blk.n_local, (blk.ep_rank + 1) * blk.n_local):
                 g, u, d = hf_expert_names(cfg, i, e)
@@ -349,12 +349,13 @@ def native_to_hf_state(model, gather: bool = True, experts_only: bool = False) -
             yield names["mlp.router"][0], params[pre + "mlp.router"].data
             gu, dn = params[pre + "mlp.gate_up"].data, params[pre + "mlp.down"].data
             f = gu.shape[1] // 2
+            eg = model.etp_group if gather else None  # the ranks an expert is split over (none: whole experts)
             for le in range(gu.shape[0]):
                 e = blk.mlp.ep_rank * blk.mlp.n_local + le
                 gn, un, dnn = hf_expert_names(cfg, i, e)
-                yield gn, _gather_tp(gu[le, :f], 0, g)
-                yield un, _gather_tp(gu[le, f:], 0, g)
-                yield dnn, _gather_tp(dn[le], 1, g)
+                yield gn, _gather_tp(gu[le, :f], 0, eg)
+                yield un, _gather_tp(gu[le, f:], 0, eg)
+                yield dnn, _gather_tp(dn[le], 1, eg)
         else:
             gu = params[pre + "mlp.gate_up"].data
             f = gu.shape[0] // 2

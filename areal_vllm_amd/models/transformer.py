@@ -214,12 +214,20 @@ class MoE(nn.Module):
     """Top-k routed experts (Mixtral / Qwen-MoE). Tokens are sorted by expert and every expert runs its
     fused gate|up and down GEMMs on a contiguous slab (grouped GEMM by expert-sorted dispatch; the
     reference uses grouped_gemm at ``realhf/impl/model/modules/moe/experts.py:195-210``). With expert
-    parallelism (``ep_group``) each rank owns n_experts/ep experts and tokens travel by all-to-all."""
+    parallelism (``ep_group``) each rank owns n_experts/ep experts and tokens travel by all-to-all.
 
-    def __init__(self, cfg: ModelConfig, tp_size, dtype, device, ep_size: int = 1, ep_rank: int = 0):
+    `tp_size` is the EXPERT tensor-parallel size: how many ranks split every expert's intermediate dimension.
+    `token_shard` (expert tensor parallel size 1 inside a larger attention tp group, Megatron's
+    ``expert_tensor_parallel_size``, ``areal/api/alloc_mode.py:35-214``): experts are whole, and since the layer's
+    input is replicated over the tp group each tp rank routes only its slice of the tokens - the tp ranks act as
+    additional expert-parallel / expert-data-parallel ranks, and the result is all-gathered."""
+
+    def __init__(self, cfg: ModelConfig, tp_size, dtype, device, ep_size: int = 1, ep_rank: int = 0,
+                 token_shard: bool = False):
         super().__init__()
         self.cfg = cfg
         self.ep_size, self.ep_rank = ep_size, ep_rank
+        self.token_shard = token_shard
         assert cfg.n_experts % ep_size == 0
         self.n_local = cfg.n_experts // ep_size
         f = cfg.moe_intermediate_size // tp_size
@@ -236,18 +244,37 @@ class MoE(nn.Module):
         return ops.grouped_gemm(h, self.down, counts)
 
     def forward(self, x, tp_group, ep_group=None):
+        if not self.token_shard:
+            x = _AllReduceBwd.apply(x, tp_group)
+            return _AllReduceFwd.apply(self._route(x, self.router, ep_group, x.shape[0], 1.0), tp_group)
+        from ..parallel import tensor_parallel as tpar
+
+        # tokens split over the tp group (zero rows pad the last slice), whole experts, result re-assembled; the
+        # router sees only this rank's slice, so its gradient is summed over the group
+        T, n = x.shape[0], tpar._size(tp_group)
+        pad = (-T) % n
+        xs = tpar.ScatterToSP.apply(F.pad(x, (0, 0, 0, pad)) if pad else x, tp_group)
+        c = xs.shape[0]
+        r = torch.distributed.get_rank(tp_group) if n > 1 else 0
+        valid = max(0, min(c, T - r * c))
+        out = self._route(xs, _AllReduceBwd.apply(self.router, tp_group), ep_group, valid, 1.0 / n)
+        return tpar.GatherForReplicatedUse.apply(out, tp_group)[:T]
+
+    def _route(self, x, router, ep_group, n_valid: int, aux_scale: float):
+        """Route the rows of `x` (the first `n_valid` are real tokens) to their experts and combine the outputs."""
         cfg = self.cfg
         T, H = x.shape
-        x = _AllReduceBwd.apply(x, tp_group)
-        logits = F.linear(x, self.router).float()
+        logits = F.linear(x, router).float()
         probs = torch.softmax(logits, -1)
         topv, topi = torch.topk(probs, cfg.n_experts_per_tok, -1)
         if cfg.norm_topk_prob:
             topv = topv / topv.sum(-1, keepdim=True)
         if cfg.router_aux_loss_coef > 0 and self.training:
+            ti, pr = topi[:n_valid], probs[:n_valid]
             frac = torch.zeros(cfg.n_experts, device=x.device).index_add_(
-                0, topi.reshape(-1), torch.ones(topi.numel(), device=x.device)) / max(1, topi.numel())
-            self.aux_loss = cfg.router_aux_loss_coef * cfg.n_experts * (frac * probs.mean(0)).sum()
+                0, ti.reshape(-1), torch.ones(ti.numel(), device=x.device)) / max(1, ti.numel())
+            mean_p = pr.mean(0) if n_valid > 0 else probs.sum(0) * 0.0
+            self.aux_loss = aux_scale * cfg.router_aux_loss_coef * cfg.n_experts * (frac * mean_p).sum()
         flat_e = topi.reshape(-1)
         order = torch.argsort(flat_e, stable=True)
         tok = order // cfg.n_experts_per_tok
@@ -260,8 +287,7 @@ class MoE(nn.Module):
         else:
             ys = self._experts(xs, counts.tolist())
         w = topv.reshape(-1)[order].to(ys.dtype).unsqueeze(-1)
-        out = torch.zeros_like(x).index_add_(0, tok, ys * w)
-        return _AllReduceFwd.apply(out, tp_group)
+        return torch.zeros_like(x).index_add_(0, tok, ys * w)
 
 
 def add_norm(cfg: ModelConfig, h, weight, bias, residual):
@@ -275,9 +301,10 @@ def add_norm(cfg: ModelConfig, h, weight, bias, residual):
 
 
 class Block(nn.Module):
-    def __init__(self, cfg: ModelConfig, tp_size, dtype, device, ep_size=1, ep_rank=0):
+    def __init__(self, cfg: ModelConfig, tp_size, dtype, device, ep_size=1, ep_rank=0, etp_size=None):
         super().__init__()
         self.cfg = cfg
+        etp_size = tp_size if etp_size is None else etp_size
         self.ln1 = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
         self.attn = Attention(cfg, tp_size, dtype, device)
         self.ln2 = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
@@ -285,7 +312,7 @@ class Block(nn.Module):
             self.ln1_bias = nn.Parameter(torch.zeros(cfg.hidden_size, dtype=dtype, device=device))
             self.ln2_bias = nn.Parameter(torch.zeros(cfg.hidden_size, dtype=dtype, device=device))
         if cfg.n_experts > 0:
-            self.mlp = MoE(cfg, tp_size, dtype, device, ep_size, ep_rank)
+            self.mlp = MoE(cfg, etp_size, dtype, device, ep_size, ep_rank, token_shard=etp_size != tp_size)
         elif cfg.mlp_gated:
             self.mlp = MLP(cfg.hidden_size, cfg.intermediate_size, tp_size, dtype, device, cfg.hidden_act)
         else:
@@ -313,8 +340,16 @@ class Transformer(nn.Module):
                  tp_group=None, layer_range: Optional[Tuple[int, int]] = None, has_embed: bool = True,
                  has_head: bool = True, ep_size: int = 1, ep_rank: int = 0, ep_group=None,
                  gradient_checkpointing: bool = False, sequence_parallel: bool = False,
-                 vocab_parallel: bool = False, layer_chunks: Optional[List[Tuple[int, int]]] = None):
+                 vocab_parallel: bool = False, layer_chunks: Optional[List[Tuple[int, int]]] = None,
+                 etp_size: Optional[int] = None):
         super().__init__()
+        # expert tensor parallelism: the routed experts are split over `etp_size` ranks - the whole tp group
+        # (default) or 1 (whole experts, tokens split over the tp group instead, see MoE)
+        etp_size = tp_size if etp_size is None or cfg.n_experts == 0 else int(etp_size)
+        assert etp_size in (1, tp_size), "expert tensor parallel size is the tensor parallel size or 1"
+        self.etp_size = etp_size
+        self.etp_rank = tp_rank if etp_size == tp_size else 0
+        self.etp_group = tp_group if etp_size == tp_size else None
         # vocab-parallel: the token embedding and the LM head hold only this tp rank's vocabulary rows
         # (`vocab_range`); lookups are summed over the group and the loss merges per-shard softmax statistics
         self.vocab_parallel = bool(vocab_parallel) and tp_size > 1
@@ -352,7 +387,7 @@ class Transformer(nn.Module):
                 self.pos_embed = nn.Parameter(torch.empty(cfg.max_position_embeddings, cfg.hidden_size, dtype=dtype,
                                                           device=device))
         self.layers = nn.ModuleList(
-            [Block(cfg, tp_size, dtype, device, ep_size, ep_rank) for _ in self.layer_ids]
+            [Block(cfg, tp_size, dtype, device, ep_size, ep_rank, etp_size) for _ in self.layer_ids]
         )
         if has_head:
             self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))

@@ -33,6 +33,9 @@ class ProcessGrid:
         self.strategy = strategy
         self.tp, self.cp, self.dp, self.pp = strategy.tp_size, strategy.cp_size, strategy.dp_size, strategy.pp_size
         self.ep = strategy.ep_size
+        # expert tensor parallel size: the ranks one expert is split over - the tp group (default), or 1: whole
+        # experts, and the tp ranks join the expert-parallel / expert-data-parallel dimensions instead
+        self.etp = int(getattr(strategy, "etp_size", None) or self.tp) if self.ep > 1 else self.tp
         self.vpp = max(1, int(getattr(strategy, "virtual_pipeline_parallel_size", None) or 1))
         self.links: Dict[str, Optional[dist.ProcessGroup]] = {}
         self.world = self.tp * self.cp * self.dp * self.pp
@@ -104,7 +107,21 @@ class ProcessGrid:
                                       for d in rng(self.dp) for c in rng(self.cp) for t in rng(self.tp)])
         if self.pp > 1 and self.vpp > 1:
             self._build_pipeline_links()
-        if self.ep > 1:
+        if self.ep > 1 and self.etp != self.tp:
+            # Whole experts: per pipeline stage the dp x tp ranks (tp fastest, the order of the rank grid) are
+            # cut into consecutive expert-parallel groups of `ep` ranks; ranks at the same position of different
+            # groups hold the same experts (expert data parallel). Order "etp-ep-edp-pp" of the reference's
+            # Megatron set-up (``areal/experimental/megatron_engine.py:158-179``) with etp = 1.
+            assert self.etp == 1 and self.cp == 1, "expert tensor parallel size must be the tp size or 1 (and cp 1)"
+            S = self.dp * self.tp
+            assert S % self.ep == 0 and (self.ep % self.tp == 0 or self.tp % self.ep == 0), \
+                "with whole experts the expert parallel size must divide dp x tp and be a multiple or a divisor of tp"
+            Rs = lambda p, s: R(p, s // self.tp, 0, s % self.tp)  # noqa: E731
+            self._new_group("ep", [[Rs(p, b * self.ep + e) for e in rng(self.ep)]
+                                   for p in rng(self.pp) for b in rng(S // self.ep)])
+            self._new_group("edp", [[Rs(p, b * self.ep + e) for b in rng(S // self.ep)]
+                                    for p in rng(self.pp) for e in rng(self.ep)])
+        elif self.ep > 1:
             assert self.dp % self.ep == 0, "expert parallel size must divide the data parallel size"
             edp = self.dp // self.ep
             self._new_group("ep", [[R(p, e0 * self.ep + e, c, t) for e in rng(self.ep)]
@@ -154,8 +171,18 @@ class ProcessGrid:
         if c is None:
             return -1
         return {"tp": c.tp, "cp": c.cp, "dp": c.dp, "pp": c.pp, "dp_cp": c.dp * self.cp + c.cp,
-                "world": self.local_index, "ep": c.dp % max(1, self.ep),
+                "world": self.local_index, "ep": self.expert_slot() % max(1, self.ep),
                 "mp": (c.pp * self.cp + c.cp) * self.tp + c.tp}[name]
+
+    def expert_slot(self) -> int:
+        """Position of this rank in the expert grid of its pipeline stage: `slot % ep` is its expert-parallel rank
+        (which experts it holds), `slot // ep` its expert-data-parallel replica (cp aside)."""
+        c = self.coord
+        return c.dp * self.tp + c.tp if self.etp != self.tp else c.dp
+
+    def holds_first_expert_replica(self) -> bool:
+        """One rank per distinct expert shard: the checkpoint writers of the routed experts."""
+        return self.coord.cp == 0 and self.expert_slot() < self.ep
 
     def is_dp_head(self) -> bool:
         c = self.coord

@@ -243,6 +243,25 @@ def test_expert_parallel_matches_single_process():
     _compare(ref, out, atol=5e-5)
 
 
+@pytest.mark.parametrize("name,world,kw", [
+    ("tp2ep2etp1", 2, dict(tensor_parallel_size=2, expert_parallel_size=2, expert_tensor_parallel_size=1)),
+    ("dp2tp2ep2etp1", 4, dict(data_parallel_size=2, tensor_parallel_size=2, expert_parallel_size=2,
+                              expert_tensor_parallel_size=1)),
+    ("dp2tp2ep4etp1", 4, dict(data_parallel_size=2, tensor_parallel_size=2, expert_parallel_size=4,
+                              expert_tensor_parallel_size=1)),
+])
+def test_whole_experts_inside_a_tensor_parallel_group_match_single_process(name, world, kw):
+    """Expert tensor parallel size 1 under attention tp 2: experts are not split, every tp rank routes its slice of
+    the tokens, the expert-parallel groups run over (dp x tp) ranks. Same weights after two steps as one process;
+    the hf and the sharded checkpoints (each expert set written once) round-trip."""
+    d = tempfile.mkdtemp(prefix="areal_etp_")
+    init, ref, out = (os.path.join(d, x) for x in ("init", "ref", name))
+    _run(1, {}, None, init, preset_name="tiny-moe")
+    _run(1, {}, init, ref, preset_name="tiny-moe")
+    _run(world, kw, init, out, preset_name="tiny-moe")
+    _compare(ref, out, atol=5e-5)
+
+
 def test_qk_norm_weights_under_tensor_parallel():
     """Per-head q/k norm weights are replicated over tp but every rank only sees its own heads: their
     gradients must be summed over the tp group or the replicas drift apart."""
