@@ -37,16 +37,17 @@ PROMPT_TYPES: Dict[str, str] = {
 
 def evaluate_benchmark(model_path: str, data_file: str, out_dir: str, n_sampling: int, max_gen_tokens: int,
                        temperature: float, top_p: float, template: str, device: Optional[str] = None,
-                       cf_files: Optional[Dict[str, str]] = None) -> Dict[str, float]:
+                       cf_files: Optional[Dict[str, str]] = None, data_name: Optional[str] = None) -> Dict[str, float]:
     os.makedirs(out_dir, exist_ok=True)
     greedy = evaluate_checkpoint(model_path, data_file, n_sampling=1, max_new_tokens=max_gen_tokens, greedy=True,
-                                 prompt_template=template, output=os.path.join(out_dir, "greedy.json"), device=device)
+                                 prompt_template=template, output=os.path.join(out_dir, "greedy.json"), device=device,
+                                 data_name=data_name)
     out = dict(greedy_acc=100.0 * greedy["mean@1"], greedy_length=greedy["avg_gen_tokens"])
     if n_sampling > 1:
         sampled_path = os.path.join(out_dir, f"sampled_n{n_sampling}.json")
         s = evaluate_checkpoint(model_path, data_file, n_sampling=n_sampling, max_new_tokens=max_gen_tokens,
                                 temperature=temperature, top_p=top_p, prompt_template=template, output=sampled_path,
-                                device=device)
+                                device=device, data_name=data_name)
         out["sample_length"] = s["avg_gen_tokens"]
         out["sample_pass@1"] = 100.0 * s[f"mean@{n_sampling}"]
         for k in (8, 16, 32):
@@ -87,6 +88,9 @@ def main(argv=None):
     p.add_argument("--top-p", type=float, default=0.95)
     p.add_argument("--prompt-type", default="r1-distilled-qwen", choices=sorted(PROMPT_TYPES))
     p.add_argument("--overwrite", action="store_true")
+    p.add_argument("--raw-format", action="store_true",
+                   help="the test.jsonl files are the benchmarks' published files (fields per data set, see "
+                        "evaluation/benchmarks.py), not rows with prompt / solutions")
     p.add_argument("--device", default=None)
     p.add_argument("--cf-cache-file", default=None)
     p.add_argument("--cf-metadata-path", default=None)
@@ -107,7 +111,8 @@ def main(argv=None):
             results[name] = evaluate_benchmark(
                 a.model_path, os.path.join(a.data_dir, name, "test.jsonl"), os.path.join(base, name), a.n_sampling,
                 a.max_gen_tokens, a.temperature, a.top_p, PROMPT_TYPES[a.prompt_type], a.device,
-                cf if name.startswith("codeforces") else None)
+                cf if name.startswith("codeforces") else None,
+                data_name=name if a.raw_format else None)
         with open(result_path, "w") as f:
             json.dump(results, f, indent=2)
     print(format_table(results))

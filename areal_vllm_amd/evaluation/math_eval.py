@@ -37,6 +37,12 @@ def _score(rows: List[Dict], answers: List[List[str]]) -> List[List[int]]:
         qid = str(r.get("query_id", r.get("id")))
         if r.get("task", "math") == "code":
             out.append([int(x) for x in code_verify(id2info, [extract_code(a) or "" for a in ans], [qid] * len(ans))])
+        elif r.get("choices"):  # multiple choice: compare the option letter
+            from .benchmarks import score_choice
+            from ..reward.math_parser import last_boxed_content
+
+            truth = last_boxed_content(r["solutions"][0]) or ""
+            out.append([int(score_choice(a, truth)) for a in ans])
         else:
             out.append([int(x) for x in parse_lines_in_parallel(id2info, ans, [qid] * len(ans), max_workers=4)])
     return out
@@ -53,15 +59,23 @@ def _majority(answers: List[str], correct: List[int]) -> int:
 def evaluate_checkpoint(model_path: str, data_path: str, n_sampling: int = 1, max_new_tokens: int = 2048,
                         temperature: float = 0.6, top_p: float = 1.0, greedy: bool = False, seed: int = 1,
                         prompt_template: str = "{prompt}", output: Optional[str] = None, device: Optional[str] = None,
-                        max_running: int = 256, kv_cache_gb: Optional[float] = None) -> Dict[str, float]:
+                        max_running: int = 256, kv_cache_gb: Optional[float] = None,
+                        data_name: Optional[str] = None) -> Dict[str, float]:
+    """`data_name`: the benchmark whose raw file format `data_path` is in (see ``benchmarks.FORMATS``); None =
+    rows already in evaluator shape."""
     import torch
 
     from ..api.cli_args import InferenceServerConfig
     from ..inference.engine import NativeInferenceEngine
     from ..utils.hf_utils import load_hf_tokenizer
 
-    with open(data_path) as f:
-        rows = [json.loads(l) for l in f if l.strip()]
+    if data_name:
+        from .benchmarks import load_benchmark
+
+        rows = load_benchmark(data_path, data_name)
+    else:
+        with open(data_path) as f:
+            rows = [json.loads(l) for l in f if l.strip()]
     tok = load_hf_tokenizer(model_path)
     dev = torch.device(device) if device else None
     cfg = InferenceServerConfig(model_path=model_path, random_seed=seed, max_running_requests=max_running,
@@ -108,9 +122,10 @@ def main(argv=None):
     p.add_argument("--prompt-template", default="{prompt}")
     p.add_argument("--output", default=None)
     p.add_argument("--device", default=None)
+    p.add_argument("--data-name", default=None, help="raw benchmark format of --data (gsm8k, math_500, aqua, ...)")
     a = p.parse_args(argv)
     m = evaluate_checkpoint(a.model, a.data, a.n_sampling, a.max_new_tokens, a.temperature, a.top_p, a.greedy, a.seed,
-                            a.prompt_template, a.output, a.device)
+                            a.prompt_template, a.output, a.device, data_name=a.data_name)
     print(json.dumps(m))
 
 

@@ -62,3 +62,60 @@ def test_math_eval_and_aggregate_on_cpu(tmp_path, monkeypatch):
                                      "--n-sampling", "2", "--max-gen-tokens", "6", "--prompt-type", "plain",
                                      "--output-path", str(tmp_path / "out")])
     assert again == res
+
+
+def test_benchmark_formats_normalise_to_evaluator_rows(tmp_path):
+    """Raw records in the field layouts of the public test sets (synthetic rows of those shapes) come out as
+    {query_id, prompt, solutions} rows that the reward parser scores; multiple-choice sets score by letter."""
+    from areal_vllm_amd.evaluation import benchmarks as B
+    from areal_vllm_amd.reward.math_parser import math_equal, extract_answer, last_boxed_content
+
+    raw = {
+        "gsm8k": dict(question="Tom has 3 apples and buys 4. How many?", answer="3 + 4 = 7\n#### 7"),
+        "math_500": dict(problem="Compute $\\frac12+\\frac12$.", solution="We add: $\\boxed{1}$", unique_id="t/1"),
+        "svamp": dict(Body="There are 5 birds", Question="2 fly away. How many stay?", Equation="5-2", Answer=3.0),
+        "asdiv": dict(body="A box holds 12 eggs.", question="How many in 3 boxes?", formula="12*3", answer="36 (eggs)"),
+        "mawps": dict(input="7 plus 8?", target=15.0),
+        "tabmwp": dict(table_title="Fruit", table="apple | 3\npear | 1/2", question="pears?", choices=None,
+                       answer="1/2", ans_type="decimal_number", solution="read it"),
+        "carp_en": dict(content="Area of a 2 cm square?", steps="2*2", answer="4 cm^2"),
+        "mmlu_stem": dict(question="2+2?", choices=[3, 4, 5, 6], answer=1),
+        "sat_math": dict(question="x+1=3, x?", options="A) 1 B) 2 C) 3 D) 4", Answer="B"),
+        "aqua": dict(question="Half of 43?", options=["A)21", "B)21.5", "C)22", "D)20", "E)23"], correct="B"),
+        "gaokao_math_qa": dict(question="1+1=?", options={"A": "1", "B": "2"}, label="B"),
+        "gaokao2023en": dict(question="Solve x^2=4, x>0.", answer="$2$"),
+        "gaokao2024_mix": dict(question="Pick.", choice_answer="C", answer=""),
+        "olympiadbench": dict(question="Find n.", final_answer=["$12$"]),
+        "aime24": dict(problem="Find the remainder.", answer="204"),
+        "train_amc_aime": dict(prompt="What is 6*7?", final_answer="42"),
+    }
+    rows = {k: B.normalise_row(v, k, 5) for k, v in raw.items()}
+    truth = {k: last_boxed_content(r["solutions"][0]) for k, r in rows.items()}
+    assert truth["gsm8k"] == "7" and truth["math_500"] == "1" and truth["svamp"] == "3" and truth["asdiv"] == "36"
+    assert truth["mawps"] == "15" and truth["tabmwp"] == "\\frac{1}{2}" and truth["olympiadbench"] == "12"
+    assert truth["carp_en"] == "4cm^2"  # units are kept for this set
+    assert truth["mmlu_stem"] == "B" and truth["aqua"] == "B" and truth["gaokao2024_mix"] == "C"
+    assert rows["math_500"]["query_id"] == "t/1" and rows["gsm8k"]["query_id"] == "5"
+    assert rows["svamp"]["prompt"] == "There are 5 birds. 2 fly away. How many stay?"
+    assert rows["mmlu_stem"]["prompt"].endswith("Answer Choices: (A) 3 (B) 4 (C) 5 (D) 6")
+    assert rows["sat_math"]["prompt"].endswith("Answer Choices: (A) 1 (B) 2 (C) 3 (D) 4")
+    assert rows["aqua"]["prompt"].endswith("Answer Choices: (A) 21 (B) 21.5 (C) 22 (D) 20 (E) 23")
+    assert "选项: (A) 1 (B) 2" in rows["gaokao_math_qa"]["prompt"]
+    assert rows["tabmwp"]["prompt"].startswith('Read the following table regarding "Fruit" and answer')
+    assert B.normalise_row(dict(question="Is 7 prime?", answer="yes"), "aime24")["prompt"].endswith("(Yes or No)")
+    with pytest.raises(KeyError):
+        B.normalise_row({}, "no_such_set")
+    # the normalised truth is what the scorer accepts
+    assert math_equal(extract_answer("so the answer is \\boxed{0.5}"), truth["tabmwp"])
+    assert math_equal(extract_answer("\\boxed{7.0}"), truth["gsm8k"])
+    assert B.score_choice("I think (A) is wrong, so the answer is \\boxed{B}", truth["aqua"])
+    assert B.score_choice("The answer is (B).", "B") and not B.score_choice("Answer: C", "B")
+    # files: duplicates dropped, start / limit applied
+    d = tmp_path / "gsm8k"
+    d.mkdir()
+    recs = [dict(raw["gsm8k"], idx=i % 3) for i in range(5)]
+    (d / "test.jsonl").write_text("\n".join(json.dumps(r) for r in recs))
+    assert [r["query_id"] for r in B.load_benchmark(str(tmp_path), "gsm8k")] == ["0", "1", "2"]
+    assert [r["query_id"] for r in B.load_benchmark(str(tmp_path), "gsm8k", start=1, limit=1)] == ["1"]
+    p = B.few_shot_prompt("2+2?", [("1+1?", "1+1=2. The answer is 2")], instruction="Solve.")
+    assert p == "Solve.\n\nQuestion: 1+1?\nAnswer: 1+1=2. The answer is 2\n\nQuestion: 2+2?\nAnswer:"
