@@ -130,8 +130,6 @@ class NativeInferenceEngine:
         self.model.requires_grad_(False)
         self.model.eval()
         self.model.flatten()
-        import os
-
         if load_weights and cfg.model_path and os.path.isdir(cfg.model_path):
             hf_io.load_hf_weights(self.model, cfg.model_path)
         elif self.tp_size > 1:
@@ -163,6 +161,20 @@ class NativeInferenceEngine:
                                   use_graph=not cfg.disable_cuda_graph, seed=int(cfg.random_seed),
                                   buckets=cfg.cuda_graph_bs)
         self.num_pages = num_pages
+        if (self.tp_size > 1 and self.device.type == "cuda" and not cfg.disable_custom_all_reduce
+                and self.tp_size <= 8 and mc.n_experts == 0 and self.dtype == torch.bfloat16
+                and os.environ.get("AREAL_CUSTOM_ALL_REDUCE", "1") != "0"):
+            # decode activations [batch, hidden] go through the peer-memory kernel; all ranks of one server share a
+            # node (tp_worker starts them there), which is what mapping each other's memory needs
+            from ..ops.ipc_allreduce import IpcAllReduce
+
+            ar = IpcAllReduce(self.tp_group, self.device, min(max_running, 512) * mc.hidden_size)
+            if ar.self_check():
+                self.runner.ipc_ar = ar
+                logger.info(f"tensor-parallel all-reduce of <= {ar.cap} elements over peer memory")
+            else:
+                ar.close()
+                logger.warning("peer-memory all-reduce failed its self-check on this machine: using the group's collective")
         self._free_penalty_slots = list(range(max_running - 1, -1, -1))
         if not self.is_leader:
             return self  # followers execute the leader's plans in `run_follower`

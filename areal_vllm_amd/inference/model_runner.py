@@ -65,6 +65,7 @@ class ModelRunner:
                    for _ in model.layers]
         self.rope = model.rope(self.device)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.ipc_ar = None  # peer-memory all-reduce of the tp group (ops/ipc_allreduce.py), set by the engine
         self.graphs: Dict[int, Any] = {}
         self.static: Dict[int, Dict[str, torch.Tensor]] = {}
         self._graph_pool = None
@@ -157,15 +158,25 @@ class ModelRunner:
         attn = attn_fn(blk, qkv)
         h = F.linear(attn.reshape(attn.shape[0], -1), blk.attn.o)
         if self.model.tp_size > 1:
-            torch.distributed.all_reduce(h, group=self.model.tp_group)
+            self._tp_all_reduce(h)
         x, residual = ops.rmsnorm(h, blk.ln2, cfg.rms_norm_eps, residual, cfg.gemma_norm)
         if cfg.n_experts > 0:
             h = blk.mlp(x, None, self.model.ep_group)
         else:
             h = F.linear(ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act), blk.mlp.down)
         if self.model.tp_size > 1:
-            torch.distributed.all_reduce(h, group=self.model.tp_group)
+            self._tp_all_reduce(h)
         return h, residual
+
+    def _tp_all_reduce(self, h: torch.Tensor):
+        """Sum the partial outputs of a row-parallel projection over the tp group, in place: decode-sized
+        messages through the peer-memory kernel (`ipc_ar`, set by the engine when the ranks share a node), the
+        rest - prefill activations, CPU runs - through the group's collective."""
+        ar = self.ipc_ar
+        if ar is not None and ar.fits(h):
+            ar.all_reduce_(h)
+        else:
+            torch.distributed.all_reduce(h, group=self.model.tp_group)
 
     def _sync_tokens(self, tok: torch.Tensor, lp: torch.Tensor):
         """Tensor-parallel ranks sample from identical logits with identical Philox keys; broadcasting the

@@ -41,7 +41,8 @@ def build_tp_engine(args, cfg: InferenceServerConfig, rank: int, init_addr: str,
     if use_gpu:
         dev = torch.device("cuda", (int(args.base_gpu_id) + rank) % torch.cuda.device_count())
         torch.cuda.set_device(dev)
-        backend = "cpu:gloo,cuda:nccl"
+        # AREAL_TP_BACKEND=gloo: rehearsal of a server's ranks on ONE GPU (RCCL cannot host two ranks on a device)
+        backend = os.environ.get("AREAL_TP_BACKEND") or "cpu:gloo,cuda:nccl"
     else:
         dev = torch.device("cpu")
         backend = "gloo"

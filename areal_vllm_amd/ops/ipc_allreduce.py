@@ -1,0 +1,107 @@
+"""One-shot all-reduce over peer-mapped memory (``csrc/hip/ipc_allreduce.hip``) for decode-sized messages.
+
+A tensor-parallel decode step all-reduces ``[batch, hidden]`` bf16 twice per layer: a few hundred KB to ~2 MB, far
+below the size at which a ring collective reaches link bandwidth, so its cost is launch + protocol latency. Here every
+rank maps the staging regions of its peers once (hipIpc handles exchanged through the group's host backend) and one
+kernel per call copies the input into the rank's own region, signals the peers with flags in THEIR memory, and sums
+all regions with direct loads over xGMI - no communicator, capturable in a hipGraph, bitwise identical results on
+every rank (fixed summation order). Larger messages (prefill) stay on RCCL.
+
+Role in the reference: the custom all-reduce inside its serving engines (``disable_custom_all_reduce``,
+``areal/api/cli_args.py:398-454``).
+"""
+import ctypes
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+MAX_RANKS = 8
+
+
+class IpcAllReduce:
+    def __init__(self, group, device: torch.device, max_elems: int):
+        assert device.type == "cuda"
+        self.group, self.device = group, device
+        self.n, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        assert 2 <= self.n <= MAX_RANKS, "peer-memory all-reduce serves 2..8 ranks of one node"
+        self.cap = (int(max_elems) + 7) // 8 * 8
+        lib = L.lib()
+        lib.areal_ipc_allreduce_region_bytes.restype = ctypes.c_long
+        self.nbytes = int(lib.areal_ipc_allreduce_region_bytes(ctypes.c_long(self.cap)))
+        with torch.cuda.device(device):
+            p = ctypes.c_void_p(0)
+            L.check(lib.areal_ipc_alloc(ctypes.c_long(self.nbytes), ctypes.byref(p)), "ipc_alloc")
+            self._ptr = p.value
+            zeros = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
+            L.check(lib.areal_memcpy_d2d_async(p, ctypes.c_void_p(zeros.data_ptr()), ctypes.c_long(self.nbytes),
+                                               L.stream_ptr()), "memcpy_d2d_async")
+            torch.cuda.current_stream().synchronize()
+            handle = (ctypes.c_ubyte * 64)()
+            off, size = ctypes.c_long(0), ctypes.c_long(0)
+            L.check(lib.areal_ipc_export(p, handle, ctypes.byref(off), ctypes.byref(size)), "ipc_export")
+            assert off.value == 0
+            descs: List = [None] * self.n
+            dist.all_gather_object(descs, dict(handle=bytes(handle).hex(), nbytes=self.nbytes, cap=self.cap), group=group)
+            assert all(d["cap"] == self.cap for d in descs), "ranks disagree on the staging capacity"
+            self._mapped = []
+            bases = (ctypes.c_void_p * MAX_RANKS)()
+            for r, d in enumerate(descs):
+                if r == self.rank:
+                    bases[r] = self._ptr
+                    continue
+                raw = (ctypes.c_ubyte * 64).from_buffer_copy(bytes.fromhex(d["handle"]))
+                base = ctypes.c_void_p(0)
+                L.check(lib.areal_ipc_open(raw, ctypes.byref(base)), "ipc_open")
+                self._mapped.append(base.value)
+                bases[r] = base.value
+            for r in range(self.n, MAX_RANKS):
+                bases[r] = self._ptr
+            self._bases = bases
+        dist.barrier(group=group)  # nobody signals a peer whose region is not zeroed and mapped yet
+
+    def fits(self, x: torch.Tensor) -> bool:
+        return (x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous() and x.numel() <= self.cap
+                and x.data_ptr() % 16 == 0)
+
+    def all_reduce_(self, x: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the group on the current stream. Every rank must call it with the same shape, in the
+        same order relative to its other calls."""
+        assert self.fits(x), "message does not fit the staging region (bf16, contiguous, <= capacity)"
+        L.check(L.lib().areal_ipc_allreduce(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()),
+                                            ctypes.c_long(x.numel()), self._bases, ctypes.c_int(self.n),
+                                            ctypes.c_int(self.rank), ctypes.c_long(self.cap), L.stream_ptr()),
+                "ipc_allreduce")
+        return x
+
+    def self_check(self) -> bool:
+        """Collective: reduce known values twice (both staging slots) and agree on whether every rank got the right
+        sums. A caller falls back to the group's ordinary collective when this says no."""
+        ok = True
+        for rep in range(2):
+            x = torch.full((min(self.cap, 4096 + 8 * rep),), float(self.rank + 1), dtype=torch.bfloat16,
+                           device=self.device)
+            self.all_reduce_(x)
+            ok = ok and bool((x.float() == self.n * (self.n + 1) / 2).all().item())
+        ok = ok and not self.error()
+        votes: List = [None] * self.n
+        dist.all_gather_object(votes, ok, group=self.group)
+        return all(votes)
+
+    def error(self) -> bool:
+        """True if a call gave up waiting for a peer (its result is then garbage). Synchronises the stream."""
+        word = torch.empty(1, dtype=torch.int32, device=self.device)
+        off = 2 * self.cap * 2 + 2 * MAX_RANKS * 128 * 4 + 8
+        L.check(L.lib().areal_memcpy_d2d_async(ctypes.c_void_p(word.data_ptr()), ctypes.c_void_p(self._ptr + off),
+                                               ctypes.c_long(4), L.stream_ptr()), "memcpy_d2d_async")
+        return bool(word.item())
+
+    def close(self):
+        for b in self._mapped:
+            L.lib().areal_ipc_close(ctypes.c_void_p(b))
+        self._mapped = []
+        if self._ptr:
+            L.lib().areal_ipc_free(ctypes.c_void_p(self._ptr))
+            self._ptr = 0

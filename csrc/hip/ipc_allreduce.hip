@@ -1,0 +1,133 @@
+// One-shot all-reduce over peer-mapped memory for decode-sized messages (tensor-parallel serving).
+//
+// Every rank owns one exported region  [ data slot 0 | data slot 1 | flags[2][8][MAX_BLOCKS] | state ]  and maps the
+// regions of its peers (hipIpc handles: xGMI loads between GPUs of a node, plain local memory when two processes share a
+// GPU). A call with sequence number s uses slot s & 1. Workgroup b of every rank
+//   1. copies chunk b of its input into its own slot,
+//   2. publishes s in flags[slot][my rank][b] of EVERY peer (release, system scope),
+//   3. waits until all peers have published s in its own flags[slot][*][b] (acquire, bounded spin),
+//   4. sums chunk b of all ranks' slots in rank order in fp32 - the same order everywhere, so all ranks get the same bits.
+// No workgroup needs another workgroup of its own grid, so there is no grid-wide barrier; double buffering replaces the
+// closing barrier: slot s & 1 is rewritten by call s + 2, which starts after this rank's call s + 1 has seen every peer's
+// flag s + 1, i.e. after every peer has finished call s (stream order on the peer). The sequence number lives in device
+// memory and is advanced by the last workgroup to finish, so a captured graph replays correctly.
+// A peer that never arrives makes the spin give up after a few seconds and raises the region's error word instead of hanging
+// the device. Role in the reference: the custom all-reduce of its serving engines (`disable_custom_all_reduce`,
+// areal/api/cli_args.py:398-454).
+#include "common.hpp"
+
+namespace {
+constexpr int AR_MAX_RANKS = 8;
+constexpr int AR_MAX_BLOCKS = 128;
+constexpr int AR_THREADS = 512;
+
+struct ArPeers {
+  const bf16_t* data[AR_MAX_RANKS];  // base of every rank's two data slots (own rank included)
+  int* flags[AR_MAX_RANKS];          // base of every rank's flag table
+};
+
+// state: [0] sequence number of the last completed call, [1] finished-workgroup ticket, [2] error word
+__global__ __launch_bounds__(AR_THREADS) void ipc_allreduce_kernel(ArPeers peers, bf16_t* my_data, int* my_flags,
+                                                                  unsigned* state, const bf16_t* __restrict__ in,
+                                                                  bf16_t* __restrict__ out, long n, long cap, int nranks,
+                                                                  int rank) {
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const unsigned seq = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int slot = (int)(seq & 1u);
+  // chunk of this workgroup, in 8-element (16-byte) vectors
+  const long nvec = (n + 7) >> 3;
+  const long per = (nvec + gridDim.x - 1) / gridDim.x;
+  const long v0 = (long)b * per, v1 = v0 + per < nvec ? v0 + per : nvec;
+  bf16_t* mine = my_data + (long)slot * cap;
+  for (long v = v0 + tid; v < v1; v += AR_THREADS) {
+    const long e = v << 3;
+    bf16x8 x;
+    if (e + 8 <= n) {
+      x = ld8(in + e);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = e + j < n ? in[e + j] : (bf16_t)0.f;
+    }
+    *reinterpret_cast<bf16x8*>(mine + e) = x;  // cap is a multiple of 8: the padded tail stays inside the slot
+  }
+  __threadfence_system();
+  __syncthreads();
+  const int fidx = (slot * AR_MAX_RANKS) * AR_MAX_BLOCKS + b;
+  if (tid < nranks)
+    __hip_atomic_store(peers.flags[tid] + fidx + rank * AR_MAX_BLOCKS, (int)seq, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  if (tid < nranks) {
+    const int* f = my_flags + fidx + tid * AR_MAX_BLOCKS;
+    long spins = 0;
+    while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (int)seq) < 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if (++spins > (1L << 21)) {  // the peer is gone: report, do not hang
+        atomicExch(&state[2], 1u);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  for (long v = v0 + tid; v < v1; v += AR_THREADS) {
+    const long e = v << 3;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int p = 0; p < nranks; ++p) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(peers.data[p] + (long)slot * cap + e);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += bf2f(x[j]);
+    }
+    if (e + 8 <= n) {
+      bf16x8 y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = f2bf(acc[j]);
+      *reinterpret_cast<bf16x8*>(out + e) = y;
+    } else {
+      for (int j = 0; j < 8 && e + j < n; ++j) out[e + j] = f2bf(acc[j]);
+    }
+  }
+  // the last workgroup to finish advances the sequence number (every workgroup has read it by then)
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const unsigned t = atomicAdd(&state[1], 1u);
+    if (t == gridDim.x - 1) {
+      atomicExch(&state[1], 0u);
+      __hip_atomic_store(&state[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+}  // namespace
+
+extern "C" long areal_ipc_allreduce_region_bytes(long cap_elems) {
+  return 2 * cap_elems * (long)sizeof(bf16_t) + 2L * AR_MAX_RANKS * AR_MAX_BLOCKS * (long)sizeof(int) + 64;
+}
+
+// `peer_bases[r]`: address at which rank r's region is mapped in this process (own region: its own address). `in` and
+// `out` may be the same tensor. in / out must be 16-byte aligned; cap_elems a multiple of 8 and >= n.
+extern "C" int areal_ipc_allreduce(const void* in, void* out, long n, void* const* peer_bases, int nranks, int rank,
+                                   long cap_elems, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (nranks < 1 || nranks > AR_MAX_RANKS || rank < 0 || rank >= nranks) return -1;
+  if (cap_elems % 8 != 0 || n > cap_elems) return -2;
+  if (((uintptr_t)in | (uintptr_t)out) % 16 != 0) return -3;
+  ArPeers peers;
+  const long data_bytes = 2 * cap_elems * (long)sizeof(bf16_t);
+  for (int r = 0; r < AR_MAX_RANKS; ++r) {
+    char* base = (char*)peer_bases[r < nranks ? r : rank];
+    peers.data[r] = (const bf16_t*)base;
+    peers.flags[r] = (int*)(base + data_bytes);
+  }
+  char* mine = (char*)peer_bases[rank];
+  int* my_flags = (int*)(mine + data_bytes);
+  unsigned* state = (unsigned*)(mine + data_bytes + 2L * AR_MAX_RANKS * AR_MAX_BLOCKS * sizeof(int));
+  const long nvec = (n + 7) / 8;
+  long blocks = (nvec + AR_THREADS * 2 - 1) / (AR_THREADS * 2);  // >= 2 vectors per thread before a second workgroup
+  if (blocks < 1) blocks = 1;
+  if (blocks > AR_MAX_BLOCKS) blocks = AR_MAX_BLOCKS;
+  hipLaunchKernelGGL(ipc_allreduce_kernel, dim3((unsigned)blocks), dim3(AR_THREADS), 0, st, peers, (bf16_t*)mine, my_flags,
+                     state, (const bf16_t*)in, (bf16_t*)out, n, cap_elems, nranks, rank);
+  return (int)hipGetLastError();
+}

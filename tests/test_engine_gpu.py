@@ -621,3 +621,60 @@ def test_zero3_engine_follows_zero1_on_the_device(engine):
         ref.destroy()
     finally:
         z.destroy()
+
+
+def _tp_gpu_worker(rank, port, out_path, custom_ar):
+    import argparse
+
+    # plan-by-plan decode: the host backend runs collectives on device tensors on its own worker threads, and with a
+    # continuation launched before the previous plan is read they end up waiting for each other (observed as a hang
+    # of both ranks in the continuation's first collective); RCCL, the production backend, is stream-ordered
+    os.environ.update(GLOO_SOCKET_IFNAME="lo", AREAL_TP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      AREAL_CUSTOM_ALL_REDUCE="1" if custom_ar else "0", AREAL_PIPELINE_DECODE="0")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from areal_vllm_amd.api.cli_args import InferenceServerConfig
+    from areal_vllm_amd.inference.tp_worker import build_tp_engine
+
+    cfg = InferenceServerConfig(model_path="tiny", dtype="bfloat16", context_length=256, max_running_requests=8,
+                                num_continuous_decode_steps=2, random_seed=7, disable_cuda_graph=True)
+    args = argparse.Namespace(tp_size=2, base_gpu_id=0, device="cuda", num_pages=64, kv_cache_gb=None)
+    eng = build_tp_engine(args, cfg, rank, f"127.0.0.1:{port}", initialize=False)
+    eng.initialize(load_weights=False)
+    assert (eng.runner.ipc_ar is not None) == custom_ar
+    if rank > 0:
+        eng.run_follower()
+        return
+    prompts = [[5, 6, 7, 8, 9], [11, 12, 13], [100, 200, 300, 400, 17, 18, 19]]
+    res = eng.generate_blocking(prompts, max_new_tokens=12, greedy=True)
+    torch.save([(r.output_tokens, r.output_logprobs) for r in res], out_path)
+    eng.destroy()
+
+
+def test_tp2_serving_on_one_gpu_with_peer_memory_all_reduce(tmp_path):
+    """Two tensor-parallel ranks of one server share this GPU (host-backend group, since RCCL needs a device per
+    rank): with the peer-memory all-reduce between them the engine generates exactly what it generates with the
+    group's own all-reduce (for two ranks both round fp32(a) + fp32(b) once)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    outs = []
+    for custom in (True, False):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"out{int(custom)}.pt")
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_tp_gpu_worker, args=(r, port, out, custom)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(200)
+        alive = [p for p in procs if p.is_alive()]
+        for p in alive:
+            p.kill()
+        assert not alive and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        outs.append(torch.load(out, weights_only=True))
+    for (ta, la), (tb, lb) in zip(*outs):
+        assert len(ta) == 12 and ta == tb
+        assert la == pytest.approx(lb, abs=1e-6)

@@ -846,3 +846,87 @@ def test_splitk_rope_cache_write_matches_unfused(Hq, Hkv, D):
     _close(q, qkv[:, :Hq], 2e-2, 1e-2, "q")
     _close(kc, kc2, 2e-2, 1e-2, "k cache")
     _close(vc, vc2, 2e-2, 1e-2, "v cache")
+
+
+def _ipc_allreduce_worker(rank, world, port, out_dir):
+    import os
+    import sys
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+
+    from areal_vllm_amd.ops.ipc_allreduce import IpcAllReduce
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ar = IpcAllReduce(dist.group.WORLD, dev, 256 * 1536)
+    assert ar.self_check()
+    results = []
+    sizes = [8, 1000, 1536 * 3 + 5, 64 * 1536, 256 * 1536]
+
+    def inputs(n, call):
+        g = torch.Generator().manual_seed(1000 * call + n)
+        return [torch.randn(n, generator=g).bfloat16() for _ in range(world)]
+
+    call = 0
+    for rep in range(3):  # repeated use of both staging slots
+        for n in sizes:
+            xs = inputs(n, call)
+            x = xs[rank].to(dev)
+            ar.all_reduce_(x)
+            want = torch.stack([t.float() for t in xs]).sum(0).bfloat16()
+            got = x.cpu()
+            assert torch.equal(got, want), (rank, n, (got.float() - want.float()).abs().max())
+            results.append(got)
+            call += 1
+    # a captured graph replays the collective: the sequence number lives in device memory
+    buf = torch.zeros(64 * 1536, dtype=torch.bfloat16, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ar.all_reduce_(buf)  # warm-up launch outside the capture (both ranks: keeps the call sequences aligned)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ar.all_reduce_(buf)
+        ar.all_reduce_(buf)
+    for rep in range(3):
+        buf.fill_(float(rank + 1 + rep))
+        graph.replay()
+        torch.cuda.synchronize()
+        total = sum(r + 1 + rep for r in range(world))
+        assert torch.equal(buf.cpu(), torch.full_like(buf.cpu(), float(total * world))), (rank, rep, buf[:4])
+    assert not ar.error()
+    torch.save(results, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    ar.close()
+    dist.destroy_process_group()
+
+
+def test_peer_memory_all_reduce_between_two_processes(tmp_path):
+    """Two processes on this GPU map each other's staging regions and all-reduce bf16 messages of decode sizes
+    with the one-shot kernel: exact fp32-ordered sums, identical bits on both ranks, graph replay."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_ipc_allreduce_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    a, b = (torch.load(tmp_path / f"r{r}.pt", weights_only=True) for r in range(2))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
