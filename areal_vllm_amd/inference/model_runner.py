@@ -65,6 +65,7 @@ class ModelRunner:
                    for _ in model.layers]
         self.rope = model.rope(self.device)
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._gloo_group = None  # lazily: is the tp group a host backend (one-GPU rehearsal)
         self.ipc_ar = None  # peer-memory all-reduce of the tp group (ops/ipc_allreduce.py), set by the engine
         self.graphs: Dict[int, Any] = {}
         self.static: Dict[int, Dict[str, torch.Tensor]] = {}
@@ -175,8 +176,22 @@ class ModelRunner:
         ar = self.ipc_ar
         if ar is not None and ar.fits(h):
             ar.all_reduce_(h)
+        elif self._host_staged(h):
+            t = h.cpu()
+            torch.distributed.all_reduce(t, group=self.model.tp_group)
+            h.copy_(t)
         else:
             torch.distributed.all_reduce(h, group=self.model.tp_group)
+
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        """A host-backend (gloo) group asked to move device tensors - the one-GPU rehearsal of a server's ranks:
+        stage through host memory here. The backend's own device path copies on private streams and worker
+        threads, and two ranks sharing one GPU were seen to wait on each other inside it."""
+        if not t.is_cuda:
+            return False
+        if self._gloo_group is None:
+            self._gloo_group = torch.distributed.get_backend(self.model.tp_group) == "gloo"
+        return self._gloo_group
 
     def _sync_tokens(self, tok: torch.Tensor, lp: torch.Tensor):
         """Tensor-parallel ranks sample from identical logits with identical Philox keys; broadcasting the
@@ -186,6 +201,13 @@ class ModelRunner:
             import torch.distributed as dist
 
             src = dist.get_global_rank(self.model.tp_group, 0) if self.model.tp_group is not None else 0
+            if self._host_staged(tok):
+                th, lh = tok.cpu(), lp.cpu()
+                dist.broadcast(th, src=src, group=self.model.tp_group)
+                dist.broadcast(lh, src=src, group=self.model.tp_group)
+                tok.copy_(th)
+                lp.copy_(lh)
+                return
             dist.broadcast(tok, src=src, group=self.model.tp_group)
             dist.broadcast(lp, src=src, group=self.model.tp_group)
 
