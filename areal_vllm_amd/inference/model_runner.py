@@ -86,6 +86,8 @@ class ModelRunner:
         if fused_decode is None:
             fused_decode = self.device.type == "cuda" and os.environ.get("AREAL_FUSED_DECODE", "1") != "0"
         self.fused_decode = bool(fused_decode) and fusable
+        # qkv projection with bias + RoPE + KV-cache write in its epilogue (head sizes that are multiples of 64)
+        self.fused_qkv_rope = cfg.head_dim % 64 == 0 and os.environ.get("AREAL_FUSED_QKV_ROPE", "1") != "0"
 
     # ------------------------------------------------------------------- vision-language requests
     def _placeholder_mask(self, prompt_ids: List[int], grid_thw: torch.Tensor):
@@ -344,7 +346,8 @@ class ModelRunner:
     def _decode_layers_fused(self, st: Dict[str, torch.Tensor], h: torch.Tensor, rope_pos: torch.Tensor):
         """All decoder layers of one decode step on the fused path -> final-normed hidden states [Bp, H].
 
-        Per layer: qkv GEMM (split-K slabs) -> slab sum + bias + RoPE + KV-cache write -> paged attention ->
+        Per layer: qkv GEMM with bias + RoPE + KV-cache write in its epilogue (smaller batches: split-K slabs ->
+        slab sum + bias + RoPE + KV-cache write) -> paged attention ->
         o GEMM (slabs) -> slab sum + residual + RMSNorm -> gate|up GEMM with SwiGLU epilogue -> down GEMM
         (slabs) -> slab sum + residual + the NEXT layer's RMSNorm."""
         from ..ops import decode_gemm as dg
@@ -357,9 +360,13 @@ class ModelRunner:
         x, residual = ops.rmsnorm(h, layers[0].ln1, eps, None, gemma)
         for li, blk in enumerate(layers):
             kc, vc = self.kv[li]
-            slab = dg.dgemm(x, blk.attn.qkv, epilogue=dg.EPI_SLAB)
-            q = dg.splitk_rope_cache_write(slab, slab.shape[0], blk.attn.qkv_bias, rope_pos, st["slots"], self.rope,
-                                           kc, vc, hq, hkv, D, dtype=self.dtype)
+            if self.fused_qkv_rope and Bp >= dg.QKV_ROPE_MIN_ROWS:
+                q = dg.dgemm_qkv_rope(x, blk.attn.qkv, blk.attn.qkv_bias, rope_pos, st["slots"], self.rope, kc, vc,
+                                      hq, hkv, D)
+            else:
+                slab = dg.dgemm(x, blk.attn.qkv, epilogue=dg.EPI_SLAB)
+                q = dg.splitk_rope_cache_write(slab, slab.shape[0], blk.attn.qkv_bias, rope_pos, st["slots"],
+                                               self.rope, kc, vc, hq, hkv, D, dtype=self.dtype)
             attn = ops.paged_attention_decode(q, kc, vc, st["block_tables"], st["context_lens"], nsplit=st["nsplit"],
                                               workspace=st["ws"])
             slab = dg.dgemm(attn.view(Bp, hq * D), blk.attn.o, epilogue=dg.EPI_SLAB)

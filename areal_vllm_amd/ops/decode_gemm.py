@@ -1,8 +1,8 @@
 """Decode-batch GEMMs (M = 32 ... 512 rows) and the row kernels fused onto them (``csrc/hip/decode_gemm.hip``).
 
-One decoder layer of a decode step becomes seven launches instead of ten:
+One decoder layer of a decode step becomes six launches instead of ten:
 
-    x1 (normalised)  --dgemm split-K-->  qkv slabs  --splitk_rope_cache_write-->  q (rotated), paged K/V
+    x1 (normalised)  --dgemm_qkv_rope (bias + RoPE + KV-cache write in the epilogue)-->  q (rotated), paged K/V
     paged attention  --dgemm split-K-->  o slabs    --splitk_residual_rmsnorm-->  residual, x2
     x2  --dgemm + SwiGLU epilogue-->  act  --dgemm split-K-->  down slabs  --splitk_residual_rmsnorm--> residual, x1'
 
@@ -24,7 +24,7 @@ EPI_BF16, EPI_SLAB, EPI_SWIGLU = 0, 1, 2
 
 # cfg id -> (rows per block, weight columns per block, threads); must match areal_dgemm_block_shape
 DG_CONFIGS = {0: (256, 64, 512), 1: (256, 128, 512), 2: (128, 128, 256), 3: (128, 64, 256), 4: (64, 128, 256),
-              5: (256, 64, 256), 6: (256, 128, 512), 7: (256, 128, 256), 8: (64, 64, 128)}
+              5: (256, 64, 256), 6: (256, 128, 512), 7: (256, 128, 256), 8: (64, 64, 128), 9: (32, 64, 64)}
 N_CU = 256
 
 
@@ -202,4 +202,53 @@ def splitk_rope_cache_write(slab: torch.Tensor, n_split: int, bias: Optional[tor
         L.ptr(slab), L.c_int(n_split), L.ptr(bias), L.ptr(positions), L.ptr(slots), L.ptr(table.cos), L.ptr(table.sin),
         L.ptr(q_out), L.ptr(kcache), L.ptr(vcache), L.c_int(T), L.c_int(n_q_heads), L.c_int(n_kv_heads),
         L.c_int(head_dim), L.c_int(table.max_pos), L.c_int(int(do_rope)), L.stream_ptr()), "splitk_rope_cache_write")
+    return q_out
+
+
+# (cfg, stages, loader_waves, nt) of the fused qkv projection by batch rows, from ``tools/dgemm_probe.py --layers qkv_rope``
+# (profiles/dgemm_probe_qkv_rope_s12.log): 32-row tiles up to 256 rows, 64-row tiles above; four dedicated loader waves
+QKV_ROPE_CONFIG = {"small": (9, 4, 4, True), "large": (8, 4, 4, True)}
+# Below this many rows the split-K GEMM + row kernel pair is as fast or faster: a block of the fused kernel walks
+# all of K (24 steps of ~0.4 us at K = 1536), split-K blocks an eighth of it. Stand-alone 12.1 vs 14.0 us at 256
+# rows and 13.5 vs 17.1 us at 384; inside the captured decode step the difference is within noise at 256 rows
+# and 1 % of the step at 384 (profiles/decode_probe_fused_qkv_s12.log).
+QKV_ROPE_MIN_ROWS = 320
+
+
+def dgemm_qkv_rope(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], positions, slots, table, kcache,
+                   vcache, n_q_heads: int, n_kv_heads: int, head_dim: int, q_out: Optional[torch.Tensor] = None,
+                   do_rope: bool = True, cfg: Optional[int] = None, stages: Optional[int] = None,
+                   loader_waves: Optional[int] = None, nt: Optional[bool] = None) -> torch.Tensor:
+    """The packed q|k|v projection of a decode step in ONE launch: ``x @ w.T + bias`` rounded to bf16, q / k
+    rotated, k / v written into the paged caches at ``slots`` (rows with slot < 0 write nothing); returns the
+    rotated q ``[T, Hq, D]``. Replaces a split-K GEMM plus ``splitk_rope_cache_write`` (one launch and the fp32
+    slab round trip less per layer)."""
+    T, K = x.shape
+    Nq = (n_q_heads + 2 * n_kv_heads) * head_dim
+    assert w.shape == (Nq, K)
+    if q_out is None:
+        q_out = torch.empty(T, n_q_heads, head_dim, dtype=x.dtype, device=x.device)
+    if not L.use_hip(x) or head_dim % 64 != 0:
+        from .attention import rope_and_cache_write_
+
+        qkv = F.linear(x, w, bias).view(T, n_q_heads + 2 * n_kv_heads, head_dim).contiguous()
+        rope_and_cache_write_(qkv, positions, slots, table, kcache, vcache, n_q_heads, n_kv_heads, do_rope)
+        q_out.copy_(qkv[:, :n_q_heads])
+        return q_out
+    if cfg is None:
+        cfg, st_, lw_, nt_ = QKV_ROPE_CONFIG["small" if T <= 256 else "large"]
+        stages = st_ if stages is None else stages
+        loader_waves = lw_ if loader_waves is None else loader_waves
+        nt = nt_ if nt is None else nt
+    stages = min(4 if stages is None else stages, (160 * 1024) // stage_bytes(cfg), 8)
+    if stages in (5, 7):
+        stages -= 1
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.stride(1) == 1 and w.is_contiguous()
+    assert positions.dtype == torch.int32 and slots.dtype == torch.int64 and q_out.is_contiguous()
+    assert positions.numel() >= T and slots.numel() >= T
+    L.check(L.lib().areal_dgemm_qkv_rope(
+        L.ptr(x), L.c_int64(x.stride(0)), L.ptr(w), L.ptr(bias), L.ptr(positions), L.ptr(slots), L.ptr(table.cos),
+        L.ptr(table.sin), L.ptr(q_out), L.ptr(kcache), L.ptr(vcache), L.c_int(T), L.c_int(K), L.c_int(n_q_heads),
+        L.c_int(n_kv_heads), L.c_int(head_dim), L.c_int(table.max_pos), L.c_int(int(do_rope)), L.c_int(cfg),
+        L.c_int(stages), L.c_int(int(loader_waves or 0)), L.c_int(int(bool(nt))), L.stream_ptr()), "dgemm_qkv_rope")
     return q_out

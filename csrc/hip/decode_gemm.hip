@@ -28,7 +28,7 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-enum { DG_BF16 = 0, DG_SLAB = 1, DG_SWIGLU = 2 };
+enum { DG_BF16 = 0, DG_SLAB = 1, DG_SWIGLU = 2, DG_ROPE = 3 };
 
 struct DGArgs {
   const bf16_t* X;
@@ -39,11 +39,36 @@ struct DGArgs {
   long ys;
   int M, N, K, k_per_split;
   int nt;  // non-temporal weight loads (each weight byte is read once per launch)
+  // DG_ROPE: W = the packed q|k|v projection, heads of D columns. Rotary tables [max_pos, D/2] fp32, position and
+  // KV slot per row; q goes to q_out [M, Hq, D], k / v into the paged caches (K [P, Hkv, 32, D], V [P, Hkv, D, 32])
+  const int* pos;
+  const int64_t* slots;
+  const float* cos_t;
+  const float* sin_t;
+  bf16_t* q_out;
+  bf16_t* kcache;
+  bf16_t* vcache;
+  int Hq, Hkv, D, max_pos, do_rope;
 };
 
 template <int N>
 DEVINL void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Wait until at most `keep` staged tiles (IPW loads each, issued after the one needed now) are still in flight.
+template <int IPW>
+DEVINL void wait_tiles(int keep) {
+  constexpr int C = 63;  // largest count the instruction encodes; a smaller count only waits for more
+  switch (keep) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<(IPW < C ? IPW : C)>(); break;
+    case 2: wait_vmcnt<(2 * IPW < C ? 2 * IPW : C)>(); break;
+    case 3: wait_vmcnt<(3 * IPW < C ? 3 * IPW : C)>(); break;
+    case 4: wait_vmcnt<(4 * IPW < C ? 4 * IPW : C)>(); break;
+    case 5: wait_vmcnt<(5 * IPW < C ? 5 * IPW : C)>(); break;
+    default: wait_vmcnt<(6 * IPW < C ? 6 * IPW : C)>(); break;
+  }
 }
 
 DEVINL float silu_f(float x) { return x / (1.f + __expf(-x)); }
@@ -58,7 +83,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void dgemm_kernel(const DGArgs
   constexpr int NLOAD = LW > 0 ? LW : NW;  // waves that stage
   constexpr int NINST = (BM + BN) / 8, IPW = NINST / NLOAD;
   static_assert(NINST % NLOAD == 0, "staging pieces must divide evenly over the loading waves");
-  static_assert(EPI != DG_SWIGLU || TN % 2 == 0, "SwiGLU needs gate and up tiles in one wave");
+  static_assert((EPI != DG_SWIGLU && EPI != DG_ROPE) || TN % 2 == 0, "paired column tiles need both halves in one wave");
+  constexpr bool PAIRED = EPI == DG_SWIGLU || EPI == DG_ROPE;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -74,10 +100,17 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void dgemm_kernel(const DGArgs
   const int k_end = min(a.K, k_begin + a.k_per_split);
   const int nsteps = (k_end - k_begin) >> 6;
   const int F = a.N >> 1;  // SwiGLU: number of gate columns
+  const int half = a.D >> 1;  // RoPE: a head's rotation partner of column d is column d + D/2
 
-  // global column of LDS weight-tile row `wr`
+  // global column of LDS weight-tile row `wr`. Paired epilogues put the two columns an output element needs
+  // into the same lane: tile rows [0, BN/2) are gate columns (first halves of heads), rows [BN/2, BN) the
+  // matching up columns (second halves).
   auto wcol = [&](int wr) -> int {
     if (EPI == DG_SWIGLU) return wr < BN / 2 ? ct * (BN / 2) + wr : F + ct * (BN / 2) + (wr - BN / 2);
+    if (EPI == DG_ROPE) {
+      const int i = ct * (BN / 2) + (wr < BN / 2 ? wr : wr - BN / 2);
+      return (i / half) * a.D + (i % half) + (wr < BN / 2 ? 0 : half);
+    }
     return ct * BN + wr;
   };
 
@@ -119,7 +152,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void dgemm_kernel(const DGArgs
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     int base;
-    if (EPI == DG_SWIGLU) {
+    if (PAIRED) {
       constexpr int HT = TN / 2 > 0 ? TN / 2 : 1;
       base = tn < HT ? (wn * HT + tn) * 32 : BN / 2 + (wn * HT + (tn - HT)) * 32;
     } else {
@@ -147,9 +180,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void dgemm_kernel(const DGArgs
   for (int t = 0; t < nsteps; ++t) {
     if (is_loader) {
       const int ahead = nsteps - 1 - t;  // tiles issued after tile t that may stay in flight
-      if (STAGES >= 4 && ahead >= 2) wait_vmcnt<2 * IPW>();
-      else if (STAGES >= 3 && ahead >= 1) wait_vmcnt<IPW>();
-      else wait_vmcnt<0>();
+      constexpr int KEEP = STAGES - 2 < 6 ? STAGES - 2 : 6;
+      wait_tiles<IPW>(ahead < KEEP ? ahead : KEEP);
     }
     __builtin_amdgcn_s_barrier();
     if (is_loader && t + STAGES - 1 < nsteps) issue((t + STAGES - 1) % STAGES, t + STAGES - 1);
@@ -179,7 +211,70 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void dgemm_kernel(const DGArgs
   for (int tm = 0; tm < TM; ++tm) {
     const int m = m0 + (wm * TM + tm) * 32 + r;
     if (m >= a.M) continue;
-    if (EPI == DG_SWIGLU) {
+    if (EPI == DG_ROPE) {
+      constexpr int HT = TN / 2 > 0 ? TN / 2 : 1;
+      int p = a.pos[m];
+      p = p < 0 ? 0 : (p >= a.max_pos ? a.max_pos - 1 : p);
+      const int64_t slot = a.slots ? a.slots[m] : -1;
+      const int64_t page = slot >= 0 ? slot / 32 : 0;
+      const int off = slot >= 0 ? (int)(slot % 32) : 0;
+#pragma unroll
+      for (int tn = 0; tn < HT; ++tn) {
+        const int i0 = ct * (BN / 2) + (wn * HT + tn) * 32;  // index among the first-half columns of all heads
+        const int head = i0 / half, dbase = i0 % half;       // uniform over the wave: 32 divides D/2
+        if (head >= a.Hq + 2 * a.Hkv) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d0 = dbase + 8 * g + 4 * h;
+          float lo[4], hi[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lo[j] = acc[tn][tm][4 * g + j];
+            hi[j] = acc[tn + HT][tm][4 * g + j];
+          }
+          if (a.bias) {
+            const bf16x4 bl = *reinterpret_cast<const bf16x4*>(a.bias + head * a.D + d0);
+            const bf16x4 bh = *reinterpret_cast<const bf16x4*>(a.bias + head * a.D + half + d0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { lo[j] += bf2f(bl[j]); hi[j] += bf2f(bh[j]); }
+          }
+          // the unfused path carries the projection as a bf16 tensor before rotating it
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { lo[j] = bf2f(f2bf(lo[j])); hi[j] = bf2f(f2bf(hi[j])); }
+          bf16x4 olo, ohi;
+          if (a.do_rope && head < a.Hq + a.Hkv) {
+            const f32x4 c = *reinterpret_cast<const f32x4*>(a.cos_t + (size_t)p * half + d0);
+            const f32x4 sn = *reinterpret_cast<const f32x4*>(a.sin_t + (size_t)p * half + d0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              olo[j] = f2bf(lo[j] * c[j] - hi[j] * sn[j]);
+              ohi[j] = f2bf(hi[j] * c[j] + lo[j] * sn[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { olo[j] = f2bf(lo[j]); ohi[j] = f2bf(hi[j]); }
+          }
+          if (head < a.Hq) {
+            bf16_t* qd = a.q_out + ((size_t)m * a.Hq + head) * a.D + d0;
+            *reinterpret_cast<bf16x4*>(qd) = olo;
+            *reinterpret_cast<bf16x4*>(qd + half) = ohi;
+          } else if (slot >= 0) {
+            if (head < a.Hq + a.Hkv) {
+              bf16_t* kd = a.kcache + (((size_t)page * a.Hkv + (head - a.Hq)) * 32 + off) * a.D + d0;
+              *reinterpret_cast<bf16x4*>(kd) = olo;
+              *reinterpret_cast<bf16x4*>(kd + half) = ohi;
+            } else {
+              bf16_t* vd = a.vcache + (((size_t)page * a.Hkv + (head - a.Hq - a.Hkv)) * a.D + d0) * 32 + off;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                vd[(size_t)j * 32] = olo[j];
+                vd[(size_t)(half + j) * 32] = ohi[j];
+              }
+            }
+          }
+        }
+      }
+    } else if (EPI == DG_SWIGLU) {
       constexpr int HT = TN / 2 > 0 ? TN / 2 : 1;
       bf16_t* yrow = (bf16_t*)a.Y + (size_t)m * a.ys;
 #pragma unroll
@@ -246,8 +341,8 @@ int launch_cfg(const DGArgs& a, int ksplit, hipStream_t st) {
       attr_set = true;
     }
   }
-  const int ncols = (EPI == DG_SWIGLU) ? a.N / 2 : a.N;
-  constexpr int cols_per_tile = (EPI == DG_SWIGLU) ? BN / 2 : BN;
+  const int ncols = (EPI == DG_SWIGLU || EPI == DG_ROPE) ? a.N / 2 : a.N;
+  constexpr int cols_per_tile = (EPI == DG_SWIGLU || EPI == DG_ROPE) ? BN / 2 : BN;
   dim3 grid(ksplit, (ncols + cols_per_tile - 1) / cols_per_tile, (a.M + BM - 1) / BM);
   hipLaunchKernelGGL(kern, grid, dim3(64 * (WM * WN + LW)), lds, st, a);
   return (int)hipGetLastError();
@@ -281,12 +376,34 @@ int launch_stages(const DGArgs& a, int stages, int epi, int ksplit, int lw, hipS
   return -22;
 }
 
+template <int TM, int TN, int WM, int WN>
+int launch_rope(const DGArgs& a, int stages, int lw, hipStream_t st) {
+  if (lw == 0) {
+    switch (stages) {
+      case 2: return launch_cfg<TM, TN, WM, WN, 2, DG_ROPE, 0>(a, 1, st);
+      case 3: return launch_cfg<TM, TN, WM, WN, 3, DG_ROPE, 0>(a, 1, st);
+      case 4: return launch_cfg<TM, TN, WM, WN, 4, DG_ROPE, 0>(a, 1, st);
+      case 6: return launch_cfg<TM, TN, WM, WN, 6, DG_ROPE, 0>(a, 1, st);
+      case 8: return launch_cfg<TM, TN, WM, WN, 8, DG_ROPE, 0>(a, 1, st);
+    }
+  } else if (lw == 4) {
+    switch (stages) {
+      case 2: return launch_cfg<TM, TN, WM, WN, 2, DG_ROPE, 4>(a, 1, st);
+      case 3: return launch_cfg<TM, TN, WM, WN, 3, DG_ROPE, 4>(a, 1, st);
+      case 4: return launch_cfg<TM, TN, WM, WN, 4, DG_ROPE, 4>(a, 1, st);
+      case 6: return launch_cfg<TM, TN, WM, WN, 6, DG_ROPE, 4>(a, 1, st);
+      case 8: return launch_cfg<TM, TN, WM, WN, 8, DG_ROPE, 4>(a, 1, st);
+    }
+  }
+  return -22;
+}
+
 }  // namespace
 
 // Tile configurations (rows x columns per block, waves): see DG_CONFIGS in ops/decode_gemm.py.
 extern "C" int areal_dgemm_block_shape(int cfg, int* bm, int* bn, int* threads) {
   static const int tab[][4] = {{1, 2, 8, 1}, {2, 2, 4, 2}, {2, 2, 2, 2}, {1, 2, 4, 1}, {1, 2, 2, 2},
-                               {2, 2, 4, 1}, {1, 4, 8, 1}, {2, 4, 4, 1}, {1, 2, 2, 1}};
+                               {2, 2, 4, 1}, {1, 4, 8, 1}, {2, 4, 4, 1}, {1, 2, 2, 1}, {1, 2, 1, 1}};
   if (cfg < 0 || cfg >= (int)(sizeof(tab) / sizeof(tab[0]))) return -1;
   *bm = 32 * tab[cfg][0] * tab[cfg][2];
   *bn = 32 * tab[cfg][1] * tab[cfg][3];
@@ -311,6 +428,8 @@ extern "C" int areal_dgemm(const void* X, long xs, const void* W, const void* bi
   DGArgs a;
   a.X = (const bf16_t*)X; a.xs = xs; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.Y = Y; a.ys = ys;
   a.M = M; a.N = N; a.K = K; a.k_per_split = kps; a.nt = nt;
+  a.pos = nullptr; a.slots = nullptr; a.cos_t = a.sin_t = nullptr; a.q_out = a.kcache = a.vcache = nullptr;
+  a.Hq = a.Hkv = 0; a.D = 2; a.max_pos = 0; a.do_rope = 0;
   switch (cfg) {
     case 0: return launch_stages<1, 2, 8, 1>(a, stages, epilogue, ksplit, loader_waves, st);
     case 1: return launch_stages<2, 2, 4, 2>(a, stages, epilogue, ksplit, loader_waves, st);
@@ -321,6 +440,35 @@ extern "C" int areal_dgemm(const void* X, long xs, const void* W, const void* bi
     case 6: return launch_stages<1, 4, 8, 1>(a, stages, epilogue, ksplit, loader_waves, st);
     case 7: return launch_stages<2, 4, 4, 1>(a, stages, epilogue, ksplit, loader_waves, st);
     case 8: return launch_stages<1, 2, 2, 1>(a, stages, epilogue, ksplit, loader_waves, st);
+    case 9: return launch_stages<1, 2, 1, 1>(a, stages, epilogue, ksplit, loader_waves, st);
+  }
+  return -6;
+}
+
+// The packed q|k|v projection of a decode step in one launch: Y = X W^T (+bias) rounded to bf16, q and k rotated
+// (half-split rotary layout), q written to q_out [M, Hq, D], k / v scattered into the paged caches at slots[m]
+// (rows with slot < 0 write no K/V). A block's column tile is BN/2 first-half columns of a head and their BN/2
+// rotation partners, so the rotation stays inside a lane. Configurations 3 (128x64), 4 (64x128), 8 (64x64),
+// 9 (32x64); D/2 must be a multiple of the half tile (32, for configuration 4: 64).
+extern "C" int areal_dgemm_qkv_rope(const void* X, long xs, const void* W, const void* bias, const int* pos,
+                                    const int64_t* slots, const float* cos_t, const float* sin_t, void* q_out,
+                                    void* kcache, void* vcache, int M, int K, int Hq, int Hkv, int D, int max_pos,
+                                    int do_rope, int cfg, int stages, int loader_waves, int nt, hipStream_t st) {
+  if (M <= 0) return 0;
+  const int N = (Hq + 2 * Hkv) * D;
+  if (K % 64 != 0 || xs % 8 != 0 || D % 64 != 0) return -1;
+  if (cfg == 4 && (D / 2) % 64 != 0) return -2;
+  DGArgs a;
+  a.X = (const bf16_t*)X; a.xs = xs; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.Y = nullptr; a.ys = 0;
+  a.M = M; a.N = N; a.K = K; a.k_per_split = K; a.nt = nt;
+  a.pos = pos; a.slots = slots; a.cos_t = cos_t; a.sin_t = sin_t; a.q_out = (bf16_t*)q_out;
+  a.kcache = (bf16_t*)kcache; a.vcache = (bf16_t*)vcache; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_pos = max_pos;
+  a.do_rope = do_rope;
+  switch (cfg) {
+    case 3: return launch_rope<1, 2, 4, 1>(a, stages, loader_waves, st);
+    case 4: return launch_rope<1, 2, 2, 2>(a, stages, loader_waves, st);
+    case 8: return launch_rope<1, 2, 2, 1>(a, stages, loader_waves, st);
+    case 9: return launch_rope<1, 2, 1, 1>(a, stages, loader_waves, st);
   }
   return -6;
 }

@@ -120,13 +120,17 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
   l += __shfl_xor(l, 32, 64);
 
   // combine the 4 waves through LDS: per wave [16 q][D] fp32 O + [16] m + [16] l
-  float* so = smem;                 // [4][16][D]
-  float* sm = smem + 4 * 16 * D;    // [4][16]
+  // Rows are DP = D + 4 floats apart: with a stride of D floats the 16 q rows of a store fall on the same banks
+  // (a 16-way conflict); 4 floats of padding move each row by one 16-byte slot, and each lane stores its 4
+  // consecutive values as one 16-byte write. Only the G real q rows are stored.
+  constexpr int DP = D + 4;
+  float* so = smem;                 // [4][16][DP]
+  float* sm = smem + 4 * 16 * DP;   // [4][16]
   float* sl = sm + 4 * 16;          // [4][16]
+  if (col < G) {
 #pragma unroll
-  for (int i = 0; i < DB; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) so[(wid * 16 + col) * D + i * 16 + 4 * c + r] = o[i][r];
+    for (int i = 0; i < DB; ++i) *reinterpret_cast<f32x4*>(so + (wid * 16 + col) * DP + i * 16 + 4 * c) = o[i];
+  }
   if (c == 0) { sm[wid * 16 + col] = m; sl[wid * 16 + col] = l; }
   __syncthreads();
   // thread t handles (q = t / (D/8)... ) : 256 threads cover G*D elements in a strided loop
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void paged_decode_kernel(
     for (int w = 0; w < 4; ++w) {
       const float mw = sm[w * 16 + qq];
       const float f = (mw == -INFINITY) ? 0.f : fast_exp2(mw - mm);
-      acc += so[(w * 16 + qq) * D + d] * f;
+      acc += so[(w * 16 + qq) * DP + d] * f;
       ll += sl[w * 16 + qq] * f;
     }
     const int head = h * G + qq;
@@ -183,7 +187,7 @@ extern "C" int areal_paged_decode(const void* q, const void* kcache, const void*
   if (D != 128 && D != 64) return -2;
   if (nsplit < 1 || (nsplit > 1 && (!part_o || !part_ml))) return -3;
   const float scale_log2 = softmax_scale * 1.4426950408889634f;
-  const size_t lds = (size_t)(4 * 16 * D + 2 * 4 * 16) * sizeof(float);
+  const size_t lds = (size_t)(4 * 16 * (D + 4) + 2 * 4 * 16) * sizeof(float);
   dim3 grid(B, Hkv, nsplit), block(256);
   if (D == 128)
     hipLaunchKernelGGL(paged_decode_kernel<128>, grid, block, lds, st, (const bf16_t*)q,

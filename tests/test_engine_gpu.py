@@ -519,7 +519,7 @@ def test_decoupled_server_process_with_disk_weight_updates(tmp_path, transport):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [64, 200])
+@pytest.mark.parametrize("B", [64, 200, 330])
 def test_fused_decode_path_matches_library_path(B):
     """Decode steps through the fused layer path (decode GEMMs + slab row kernels, inside a captured graph)
     against the library-GEMM path on the same weights and KV cache: same greedy tokens except where the two

@@ -848,6 +848,38 @@ def test_splitk_rope_cache_write_matches_unfused(Hq, Hkv, D):
     _close(vc, vc2, 2e-2, 1e-2, "v cache")
 
 
+@pytest.mark.parametrize("Hq,Hkv,D,K", [(12, 2, 128, 1536), (28, 4, 128, 3584), (16, 2, 64, 896)])
+@pytest.mark.parametrize("cfg,lw", [(None, None), (9, 0), (9, 4), (8, 0), (8, 4), (3, 4), (4, 0)])
+@pytest.mark.parametrize("T", [75, 256])
+def test_dgemm_qkv_rope_matches_unfused(Hq, Hkv, D, K, cfg, lw, T):
+    """The qkv projection with bias + RoPE + KV-cache write in its epilogue against an fp32 GEMM of the same
+    bf16 inputs followed by the stand-alone RoPE / cache-write kernel."""
+    if cfg == 4 and D < 128:
+        pytest.skip("64-column half tiles need D >= 128")
+    torch.manual_seed(3)
+    P = 40
+    Nq = (Hq + 2 * Hkv) * D
+    x = torch.randn(T, K, device=DEV).bfloat16()
+    w = (torch.randn(Nq, K, device=DEV) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(Nq, device=DEV).bfloat16()
+    pos = torch.randint(0, 900, (T,), device=DEV, dtype=torch.int32)
+    slots = torch.randperm(P * 32, device=DEV)[:T].long()
+    slots[3] = -1
+    table = NA.RotaryTable(D, 1024, 1e4, DEV)
+    kc, vc = A.alloc_kv_cache(P, Hkv, D, torch.bfloat16, DEV)
+    kc2, vc2 = A.alloc_kv_cache(P, Hkv, D, torch.bfloat16, DEV)
+    for stages in ((None,) if cfg is None else (2, 4, 8)):
+        kc.zero_(), vc.zero_()
+        q = DG.dgemm_qkv_rope(x, w, bias, pos, slots, table, kc, vc, Hq, Hkv, D, cfg=cfg, stages=stages,
+                              loader_waves=lw, nt=bool(lw))
+        qkv = (x.float() @ w.float().t() + bias.float()).bfloat16().view(T, Hq + 2 * Hkv, D).contiguous()
+        kc2.zero_(), vc2.zero_()
+        A.rope_and_cache_write_(qkv, pos, slots, table, kc2, vc2, Hq, Hkv)
+        _close(q, qkv[:, :Hq], 3e-2, 2e-2, f"q cfg={cfg} stages={stages}")
+        _close(kc, kc2, 3e-2, 2e-2, f"k cache cfg={cfg} stages={stages}")
+        _close(vc, vc2, 3e-2, 2e-2, f"v cache cfg={cfg} stages={stages}")
+
+
 def _ipc_allreduce_worker(rank, world, port, out_dir):
     import os
     import sys

@@ -46,6 +46,55 @@ def timeit(fn, n_copies, iters):
     return e0.elapsed_time(e1) * 1e3 / (iters * n_copies)  # us
 
 
+def probe_qkv_rope(cfg, ms, iters, dev, g):
+    """The qkv projection + bias + RoPE + KV-cache write: split-K GEMM followed by the slab row kernel (two
+    launches) against the GEMM with that work in its epilogue (one launch), per tile configuration."""
+    from areal_vllm_amd.ops import attention as A
+    from areal_vllm_amd.ops.norm_act import RotaryTable
+
+    H, D, hq, hkv = cfg.hidden_size, cfg.head_dim, cfg.n_q_heads, cfg.n_kv_heads
+    nq = (hq + 2 * hkv) * D
+    n_copies = max(2, int(320e6 // (nq * H * 2)) + 1)
+    W = (torch.randn(n_copies, nq, H, device=dev, generator=g) * 0.03).to(torch.bfloat16)
+    bias = torch.randn(nq, device=dev, generator=g).to(torch.bfloat16)
+    table = RotaryTable(D, 4096, 1e6, dev)
+    for M in ms:
+        X = torch.randn(n_copies, M, H, device=dev, generator=g).to(torch.bfloat16)
+        pages = (M * 4 + 31) // 32 + 1
+        kc, vc = A.alloc_kv_cache(pages, hkv, D, torch.bfloat16, dev)
+        pos = torch.randint(0, 4000, (M,), device=dev, dtype=torch.int32)
+        slots = (torch.arange(M, device=dev) * 4).long()
+        q = torch.empty(M, hq, D, dtype=torch.bfloat16, device=dev)
+        c0, s0, k0, lw0, nt0 = dg.pick_config(M, nq, H, dg.EPI_SLAB)
+        slab = torch.empty(k0, M, nq, dtype=torch.float32, device=dev)
+
+        def two(c):
+            dg.dgemm(X[c], W[c], epilogue=dg.EPI_SLAB, out=slab)
+            dg.splitk_rope_cache_write(slab, k0, bias, pos, slots, table, kc, vc, hq, hkv, D, q_out=q)
+
+        t2 = timeit(two, n_copies, iters)
+        rows = []
+        for cid in (9, 8, 3, 4):
+            for stages in (3, 4, 6, 8):
+                if stages * dg.stage_bytes(cid) > 160 * 1024:
+                    continue
+                for lw, nt in ((0, False), (0, True), (4, False), (4, True)):
+                    bm, bn, _ = dg.DG_CONFIGS[cid]
+                    if lw and ((bm + bn) // 8) % lw:
+                        continue
+                    fn = lambda c: dg.dgemm_qkv_rope(X[c], W[c], bias, pos, slots, table, kc, vc, hq, hkv, D, q_out=q,
+                                                     cfg=cid, stages=stages, loader_waves=lw, nt=nt)
+                    rows.append((timeit(fn, n_copies, iters), cid, stages, lw, int(nt)))
+        rows.sort()
+        td = timeit(lambda c: dg.dgemm_qkv_rope(X[c], W[c], bias, pos, slots, table, kc, vc, hq, hkv, D, q_out=q),
+                    n_copies, iters)
+        print(f"qkv_rope N={nq} K={H} M={M:4d}: split-K GEMM (cfg {c0}, ksplit {k0}) + row kernel {t2:6.1f} us; "
+              f"fused default {td:6.1f} us; best fused:", flush=True)
+        for t, cid, st, lw, nt in rows[:5]:
+            bm, bn, thr = dg.DG_CONFIGS[cid]
+            print(f"      {t:7.1f} us  cfg {cid} ({bm}x{bn}, {thr}+{64 * lw} thr) stages {st} nt {nt}", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="qwen2-1.5b")
@@ -64,7 +113,9 @@ def main():
     shapes = {"qkv": (nq, H, dg.EPI_SLAB), "o": (H, cfg.n_q_heads * D, dg.EPI_SLAB),
               "gate_up": (2 * cfg.intermediate_size, H, dg.EPI_SWIGLU), "down": (H, cfg.intermediate_size, dg.EPI_SLAB)}
     g = torch.Generator(device=dev).manual_seed(0)
-    for name in args.layers.split(","):
+    if "qkv_rope" in args.layers.split(","):
+        probe_qkv_rope(cfg, [int(x) for x in args.m.split(",")], args.iters, dev, g)
+    for name in [n for n in args.layers.split(",") if n != "qkv_rope"]:
         N, K, epi = shapes[name]
         n_copies = args.copies or max(2, int(320e6 // (N * K * 2)) + 1)
         W = (torch.randn(n_copies, N, K, device=dev, generator=g) * 0.03).to(torch.bfloat16)
