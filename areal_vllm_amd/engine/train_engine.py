@@ -608,6 +608,29 @@ class NativeTrainEngine(TrainEngine):
             out[b, : s.shape[0]] = s
         return out
 
+    @torch.no_grad()
+    def generate(self, prompts: List[List[int]], gconfig=None, n_micro_batches: Optional[int] = None, **kw):
+        """Generate with the weights this trainer holds, through its own pipeline stages and tensor-parallel
+        ranks (``parallel/pipeline_generate.py``). Every rank of a model-parallel replica passes the same
+        prompts and receives the same list of sequences; data-parallel replicas generate for their own prompts.
+        `gconfig`: a ``GenerationHyperparameters``; keyword arguments override its fields. Reference:
+        ``realhf/impl/model/backend/pipe_runner.py:420-646`` (pipelined generation of the legacy trainer)."""
+        from ..parallel.pipeline_generate import PipelineGenerator
+
+        assert self.zero3 is None and self.grid.cp == 1, "generation through the trainer needs resident, " \
+            "unsharded-by-context weights (ZeRO-1, cp = 1)"
+        self.train(False)
+        if getattr(self, "_generator", None) is None:
+            self._generator = PipelineGenerator(self.model, self.grid, self.device,
+                                                seed=1 + 7919 * self.data_parallel_rank)
+        args = {}
+        if gconfig is not None:
+            args = dict(max_new_tokens=gconfig.max_new_tokens, min_new_tokens=gconfig.min_new_tokens,
+                        temperature=gconfig.temperature, top_p=gconfig.top_p, top_k=gconfig.top_k,
+                        greedy=gconfig.greedy, stop_token_ids=list(gconfig.stop_token_ids or []))
+        args.update(kw)
+        return self._generator.generate(prompts, n_micro_batches=n_micro_batches, **args)
+
     # ----------------------------------------------------------------------- save / load
     def _save_sharded(self, meta: SaveLoadMeta):
         """Distributed checkpoint: every (pp, tp) shard writes its own slice of the flat buffer - no

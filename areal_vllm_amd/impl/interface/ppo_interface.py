@@ -101,13 +101,14 @@ class PPOActorInterface(ModelInterface):
     @torch.no_grad()
     def generate(self, model: Model, data: SequenceSample, mb_spec) -> Optional[SequenceSample]:
         """Synchronous PPO: answers come from a rollout engine living in this worker, fed with the
-        trainer's current weights by one device copy of the flat parameter buffer."""
+        trainer's current weights by one device copy of the flat parameter buffer; a tensor- / pipeline-parallel
+        trainer generates through its own shards and stages instead."""
         from ...inference.engine import NativeInferenceEngine
 
         eng = model.module
-        assert eng.grid.tp == 1 and eng.grid.pp == 1, "in-worker generation needs a tp=pp=1 layout"
         g = self.gconfig
-        if self._gen_engine is None:
+        model_parallel = eng.grid.tp > 1 or eng.grid.pp > 1
+        if self._gen_engine is None and not model_parallel:
             prompt_max = 2048
             srv = InferenceServerConfig(model_path="", dtype=eng.config.dtype, random_seed=1 + eng.grid.global_rank,
                                         context_length=prompt_max + g.max_new_tokens + 64, max_running_requests=256,
@@ -117,7 +118,8 @@ class PPOActorInterface(ModelInterface):
                 num_pages=None if eng.device.type == "cuda" else 1024,
                 kv_cache_gb=8.0 if eng.device.type == "cuda" else None)
             self._gen_engine.initialize(load_weights=False)
-        self._gen_engine.load_weights_from_trainer(eng.model, version=model.version.global_step)
+        if not model_parallel:
+            self._gen_engine.load_weights_from_trainer(eng.model, version=model.version.global_step)
         prompts = [p.data["packed_prompts"].tolist() for p in data.unpack()]
         best_of = self.generation_size is not None and self.generation_size > self.group_size
         n = self.generation_size if best_of else g.n_samples
@@ -126,9 +128,15 @@ class PPOActorInterface(ModelInterface):
         for t in (mc.eos_token_id, mc.pad_token_id):
             if t is not None and t not in stops:
                 stops.append(int(t))
-        res = self._gen_engine.generate_blocking(
-            [p for p in prompts for _ in range(n)], max_new_tokens=g.max_new_tokens, min_new_tokens=g.min_new_tokens,
-            temperature=g.temperature, top_p=g.top_p, top_k=g.top_k, greedy=g.greedy, stop_token_ids=stops)
+        if model_parallel:
+            # a tensor- / pipeline-parallel trainer generates through its own stages and shards
+            # (parallel/pipeline_generate.py; reference: realhf/impl/model/backend/pipe_runner.py:420-646)
+            res = eng.generate([p for p in prompts for _ in range(n)], g, stop_token_ids=stops)
+        else:
+            res = self._gen_engine.generate_blocking(
+                [p for p in prompts for _ in range(n)], max_new_tokens=g.max_new_tokens,
+                min_new_tokens=g.min_new_tokens, temperature=g.temperature, top_p=g.top_p, top_k=g.top_k,
+                greedy=g.greedy, stop_token_ids=stops)
         ids, pmask, lps, no_eos, sl = [], [], [], [], []
         for i, p in enumerate(prompts):
             group = res[i * n:(i + 1) * n]

@@ -299,6 +299,32 @@ def test_rollout_logprobs_match_trainer_recompute():
         actor.destroy()
 
 
+def test_trainer_generates_through_its_own_model_on_gpu(engine):
+    """`generate` of the train engine (the pipelined generator with one stage: varlen prefill + paged decode on the
+    trainer's weights): the log-probs it reports for its samples are what the trainer's forward recomputes."""
+    gen = torch.Generator().manual_seed(9)
+    V = engine.model_config.vocab_size
+    prompts = [torch.randint(2, V, (n,), generator=gen).tolist() for n in (7, 40, 33, 90, 130, 17)]
+    res = engine.generate(prompts, None, max_new_tokens=48, temperature=1.0, n_micro_batches=2)
+    assert all(len(r.output_tokens) == 48 for r in res)
+    lens = [len(p) + 48 for p in prompts]
+    S = max(lens)
+    ids = torch.zeros(len(prompts), S, dtype=torch.long)
+    am = torch.zeros(len(prompts), S, dtype=torch.bool)
+    behav = torch.zeros(len(prompts), S)
+    gm = torch.zeros(len(prompts), S, dtype=torch.bool)
+    for i, (p, r) in enumerate(zip(prompts, res)):
+        ids[i, :lens[i]] = torch.tensor(p + r.output_tokens)
+        am[i, :lens[i]] = True
+        behav[i, len(p) - 1:lens[i] - 1] = torch.tensor(r.output_logprobs)  # position t scores token t+1
+        gm[i, len(p) - 1:lens[i] - 1] = True
+    dev = engine.device
+    batch = dict(input_ids=ids.to(dev), attention_mask=am.to(dev))
+    prox = engine.forward(batch, post_hook=_logp_hook).float().cpu()
+    diff = (prox - behav).abs()[gm]
+    assert float(diff.mean()) < 0.02 and float(diff.max()) < 0.25, (float(diff.mean()), float(diff.max()))
+
+
 def test_weight_update_interrupts_running_generation():
     """Requests in flight when new weights arrive are aborted, re-issued by the client with their partial
     output, and finish with tokens tagged by both weight versions."""

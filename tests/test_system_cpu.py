@@ -327,6 +327,37 @@ def test_sync_ppo_generation_replica_is_fed_by_parameter_reallocation(tmp_path, 
     assert logs.count("re-allocation actor@0 -> actor@1 verified") >= 2 * 3, logs[-2000:]
 
 
+@pytest.mark.slow
+def test_sync_ppo_pipeline_parallel_actor_generates_through_its_stages(tmp_path):
+    """No separate generation copy: the p2 actor generates through its own two stages (tokens ring back from the
+    last stage to the first), then trains on what it generated."""
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters, OptimizerConfig
+    from areal_vllm_amd.apps.main import main_start
+    from areal_vllm_amd.experiments.common import ModelTrainEvalConfig
+    from areal_vllm_amd.experiments.ppo_math_exp import PPOHyperparameters, PPOMATHExperiment
+    from areal_vllm_amd.system.system_api import DatasetAbstraction, ExperimentSaveEvalControl
+
+    root = str(tmp_path)
+    rng = random.Random(0)
+    rows = [dict(query_id=str(i), input_ids=[rng.randint(2, 400) for _ in range(rng.randint(3, 10))], task="math",
+                 solutions=["\\boxed{1}"]) for i in range(16)]
+    p = os.path.join(root, "data.jsonl")
+    with open(p, "w") as f:
+        f.write("\n".join(json.dumps(r) for r in rows))
+    actor = ModelTrainEvalConfig(path="tiny", init_from_scratch=True, dtype="float32", backend="native_train",
+                                 optimizer=OptimizerConfig(lr=1e-3, lr_scheduler_type="constant",
+                                                           warmup_steps_proportion=0.0))
+    ppo = PPOHyperparameters(gen=GenerationHyperparameters(max_new_tokens=8), ppo_n_minibatches=1)
+    e = PPOMATHExperiment(experiment_name="t-ppo", trial_name="ppgen", actor=actor, ppo=ppo, layout="p2",
+                          dataset=DatasetAbstraction("math_code_prompt", args=dict(dataset_path=p)),
+                          reward_args=dict(dataset_path=p), train_bs_n_seqs=4, group_size=2, device="cpu", fileroot=root,
+                          exp_ctrl=ExperimentSaveEvalControl(total_train_epochs=1, benchmark_steps=2))
+    main_start(e, "t-ppo", "ppgen", fileroot=root, platform="cpu", timeout=400)
+    st = _stats(root, "t-ppo", "ppgen")
+    assert len(st) == 2 and all(s["actor_train/update_successful"] == 1.0 for s in st)
+    assert all("actor_gen/time" in s for s in st)
+
+
 class _FakeRay:
     """Stand-in for the `ray` module (not installed here): tasks are spawned processes, resources a fixed dict."""
 
