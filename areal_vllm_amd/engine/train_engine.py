@@ -374,6 +374,7 @@ class NativeTrainEngine(TrainEngine):
         self.initialized = False
 
     def train(self, mode: bool = True):
+        self.onload()  # every compute entry point passes through here: a parked model comes back first
         self._training = mode
         if self.model is not None:
             self.model.train(mode)
@@ -631,6 +632,49 @@ class NativeTrainEngine(TrainEngine):
         args.update(kw)
         return self._generator.generate(prompts, n_micro_batches=n_micro_batches, **args)
 
+    # ------------------------------------------------------------------- offload / onload
+    def offload(self) -> int:
+        """Park this model in pinned host memory while it is idle: the flat parameter buffer(s), the optimizer's
+        fp32 master / moment shards (copied out) and the fp32 gradient buffer(s) (dropped: zeroed before their
+        next use anyway). Returns the device bytes freed. Any later call that needs the model brings it back
+        (`onload`). Role of the reference's offload hook (``realhf/system/model_worker.py``, ``OffloadHook`` in
+        ``realhf/api/core/dfg.py``)."""
+        from ..utils.offload import ParkedStorages
+
+        if self.zero3 is not None:
+            return 0  # ZeRO-3 keeps shards only and has its own host-resident optimizer option
+        if getattr(self, "_parked", None) is None:
+            self._parked = ParkedStorages()
+        if self._parked.parked:
+            return 0
+        tensors, keep = [], []
+        for fp in (self.model.flat, self.model.flat_experts):
+            if fp is None:
+                continue
+            tensors += [fp.flat, fp.main_grad]
+            keep += [True, False]
+        for opt in (self.optimizer, self.expert_optimizer):
+            if opt is None:
+                continue
+            tensors += [opt.master, opt.m, opt.v]
+            keep += [True, True, True]
+        freed = self._parked.park(tensors, keep)
+        if self.device.type == "cuda":
+            torch.cuda.empty_cache()
+        logger.info(f"offloaded {freed / 2**30:.2f} GiB to host memory")
+        return freed
+
+    def onload(self) -> int:
+        parked = getattr(self, "_parked", None)
+        if parked is None or not parked.parked:
+            return 0
+        return parked.unpark()
+
+    @property
+    def offloaded(self) -> bool:
+        parked = getattr(self, "_parked", None)
+        return parked is not None and parked.parked
+
     # ----------------------------------------------------------------------- save / load
     def _save_sharded(self, meta: SaveLoadMeta):
         """Distributed checkpoint: every (pp, tp) shard writes its own slice of the flat buffer - no
@@ -757,6 +801,7 @@ class NativeTrainEngine(TrainEngine):
         return f"experts-pp{g.coord.pp}-tp{g.coord.tp if g.etp == g.tp else 0}-ep{g.rank_in('ep')}.safetensors"
 
     def save(self, meta: SaveLoadMeta):
+        self.onload()
         if meta.weight_format in ("dcp", "naive_distributed"):
             return self._save_sharded(meta)
         if meta.weight_format != "hf":
@@ -802,6 +847,7 @@ class NativeTrainEngine(TrainEngine):
             dist.barrier(group=self.grid.group("world"))
 
     def load(self, meta: SaveLoadMeta):
+        self.onload()
         if meta.weight_format in ("dcp", "naive_distributed"):
             self._load_sharded(meta)
         elif meta.weight_format == "hf":
@@ -861,6 +907,7 @@ class NativeTrainEngine(TrainEngine):
         self._local_rollout_engine = engine
 
     def upload_weights(self, meta: WeightUpdateMeta):
+        self.onload()
         if meta.type == "inproc":
             # Colocated: the data-parallel head of every replica hosts a rollout engine with the FULL model.
             eng = self._local_rollout_engine

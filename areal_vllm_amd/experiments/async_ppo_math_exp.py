@@ -16,7 +16,8 @@ from ..system.gserver_manager import GserverManagerConfig
 from ..system.system_api import (DatasetAbstraction, Experiment, ExperimentConfig, ExperimentSaveEvalControl,
                                  ExperimentScheduling, RolloutWorkerConfig, Scheduling, TasksGroup,
                                  register_experiment)
-from .common import resolve_allocation_mode, ModelTrainEvalConfig, parse_layout, symmetric_model_workers
+from .common import (attach_offload_hooks, resolve_allocation_mode, ModelTrainEvalConfig, parse_layout,
+                     symmetric_model_workers)
 from .ppo_math_exp import PPOHyperparameters, ppo_rpcs
 
 
@@ -79,6 +80,7 @@ class AsyncPPOMATHExperiment(Experiment):
         self.ppo.gen.n_samples = self.group_size
         rpcs = ppo_rpcs(self.ppo, self.group_size, self.train_bs_n_seqs, self.mb_spec, with_gen=False,
                         with_reward_mfc=False)
+        attach_offload_hooks(rpcs, self._models())
         stream = DatasetAbstraction("puller_stream", args=dict(dataset_size=self.dataset_size or self.train_bs_n_seqs))
         workers = symmetric_model_workers(
             self._models(), parse_layout(self.layout), self.experiment_name, self.trial_name, self.device, self.fileroot,

@@ -23,6 +23,19 @@ class ModelTrainEvalConfig:
     backend: str = "native_train"  # native_train | inference | mock_train | null
     optimizer: OptimizerConfig = dataclasses.field(default_factory=OptimizerConfig)
     tokenizer_path: Optional[str] = None
+    # park the model's weights and optimizer state in pinned host memory whenever no function call runs on it
+    # (off by default: 288 GB per GPU hold an actor, a reference copy and a critic side by side)
+    offload: bool = False
+
+
+def attach_offload_hooks(rpcs, models: Dict[str, "ModelTrainEvalConfig"]) -> None:
+    """Every model function call on a role configured with `offload` gets the offload post-hook."""
+    from ..system.dfg import OffloadHook
+
+    for rpc in rpcs:
+        m = models.get(rpc.model_name.role)
+        if m is not None and m.offload and rpc.model_name.replica_id == 0:
+            rpc.add_post_hook(OffloadHook())
 
 
 def parse_layout(s: str) -> ParallelStrategy:

@@ -10,7 +10,8 @@ from ..api.cli_args import GenerationHyperparameters, MicroBatchSpec
 from ..system.dfg import MFCDef, ModelInterfaceAbstraction, ModelInterfaceType, ModelName
 from ..system.system_api import (DatasetAbstraction, Experiment, ExperimentConfig, ExperimentSaveEvalControl,
                                  ExperimentScheduling, Scheduling, TasksGroup, register_experiment)
-from .common import resolve_allocation_mode, ModelTrainEvalConfig, parse_layout, symmetric_model_workers
+from .common import (attach_offload_hooks, resolve_allocation_mode, ModelTrainEvalConfig, parse_layout,
+                     symmetric_model_workers)
 
 
 @dataclasses.dataclass
@@ -141,6 +142,7 @@ class PPOMATHExperiment(Experiment):
             replicas = {gen_model: (dataclasses.replace(self.actor, backend="inference"), parse_layout(self.gen_layout))}
         rpcs = ppo_rpcs(self.ppo, self.group_size, self.train_bs_n_seqs, self.mb_spec, with_gen=True,
                         with_reward_mfc=True, reward_args=self.reward_args, gen_model=gen_model)
+        attach_offload_hooks(rpcs, self._models())
         workers = symmetric_model_workers(
             self._models(), parse_layout(self.layout), self.experiment_name, self.trial_name, self.device, self.fileroot,
             f"{self.fileroot}/param_realloc/{self.experiment_name}/{self.trial_name}", self.seed, [self.dataset],

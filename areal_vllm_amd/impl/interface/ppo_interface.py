@@ -106,6 +106,7 @@ class PPOActorInterface(ModelInterface):
         from ...inference.engine import NativeInferenceEngine
 
         eng = model.module
+        eng.onload()
         g = self.gconfig
         model_parallel = eng.grid.tp > 1 or eng.grid.pp > 1
         if self._gen_engine is None and not model_parallel:

@@ -14,7 +14,7 @@ reference model with d2t2. The worker serves the master's requests in arrival or
 
 and, around them, the hooks ``data_transfer`` (execute a redistribution plan), ``param_realloc`` (publish
 new weights for the generation servers: HF checkpoint under the realloc root + a version bump in
-name_resolve) and ``offload``. Behaviour of ``realhf/system/model_worker.py:101-1610``.
+name_resolve) and ``offload`` (park an idle model in pinned host memory). Behaviour of ``realhf/system/model_worker.py:101-1610``.
 """
 import dataclasses
 import os
@@ -322,6 +322,9 @@ class ModelWorker(Worker):
         if src_model is None and dst_model is None:
             return
         eng = (src_model or dst_model).module
+        for m_ in (src_model, dst_model):  # a parked model comes back before its buffer is read or written
+            if m_ is not None and hasattr(m_.module, "onload"):
+                m_.module.onload()
         mc = eng.model_config
         key = (source, target)
         plans = self.__dict__.setdefault("_realloc_plans", {})
@@ -383,6 +386,17 @@ class ModelWorker(Worker):
         itf = next(self.interfaces[r.name] for r in self.rpcs.values() if r.model_name == data["model_name"])
         return itf.evaluate(model, loader)
 
+    def _hook_offload(self, hd: Dict[str, Any]):
+        """Post-hook of a model function call on a model configured with `offload`: park its weights (and
+        optimizer state) in pinned host memory until the next call that needs them; the engine brings them back
+        by itself. Models without that ability (null / mock backends) ignore the hook."""
+        model = self.models.get(hd["model_name"])
+        eng = getattr(model, "module", None)
+        if eng is not None and hasattr(eng, "offload"):
+            freed = eng.offload()
+            if freed:
+                logger.info(f"{hd['model_name']}: {freed / 2**30:.2f} GiB parked in host memory")
+
     def _dispatch(self, p: Payload) -> Any:
         h = p.handle_name
         if h == "empty":
@@ -423,8 +437,6 @@ class ModelWorker(Worker):
                 getattr(self, f"_hook_{hook}")(hd)
             res = self._dispatch(p)
             for hook, hd in zip(p.post_hooks, p.post_hook_data):
-                if hook == "offload":
-                    continue  # 288 GB of HBM: idle models stay resident
                 getattr(self, f"_hook_{hook}")(hd)
         except Exception as e:
             logger.error(f"request {p.handle_name} failed: {traceback.format_exc()}")

@@ -325,6 +325,21 @@ def test_trainer_generates_through_its_own_model_on_gpu(engine):
     assert float(diff.mean()) < 0.02 and float(diff.max()) < 0.25, (float(diff.mean()), float(diff.max()))
 
 
+def test_offload_frees_device_memory_and_restores_the_model(engine):
+    """The train engine parks its flat buffers and optimizer shards in pinned host memory: device memory drops by
+    their size, and the next forward (which brings them back) gives the same log-probs."""
+    batch = _batch(engine.model_config.vocab_size, [257, 64, 300, 129], seed=11)
+    a = engine.forward(batch, post_hook=_logp_hook).float()
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated()
+    freed = engine.offload()
+    assert engine.offloaded and freed > 0
+    assert torch.cuda.memory_allocated() <= before - freed + (1 << 20)
+    b = engine.forward(batch, post_hook=_logp_hook).float()
+    assert not engine.offloaded and torch.equal(a, b)
+    assert torch.cuda.memory_allocated() >= before - (64 << 20)
+
+
 def test_weight_update_interrupts_running_generation():
     """Requests in flight when new weights arrive are aborted, re-issued by the client with their partial
     output, and finish with tokens tagged by both weight versions."""

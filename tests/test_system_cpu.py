@@ -190,7 +190,11 @@ def test_sync_ppo_experiment_with_reference_and_critic(tmp_path):
         f.write("\n".join(json.dumps(r) for r in rows))
     ppo = PPOHyperparameters(gen=GenerationHyperparameters(max_new_tokens=8), ppo_n_minibatches=2, kl_ctl=0.1,
                              use_decoupled_loss=True, disable_value=False)
-    e = PPOMATHExperiment(experiment_name="t-ppo", trial_name="sync", actor=_actor(), ppo=ppo, layout="d2",
+    import dataclasses
+
+    # the reference copy is parked in host memory between its calls (offload post-hook), the critic stays resident
+    ref = dataclasses.replace(_actor(), backend="inference", offload=True)
+    e = PPOMATHExperiment(experiment_name="t-ppo", trial_name="sync", actor=_actor(), ref=ref, ppo=ppo, layout="d2",
                           dataset=DatasetAbstraction("math_code_prompt", args=dict(dataset_path=p)),
                           reward_args=dict(dataset_path=p), train_bs_n_seqs=4, group_size=2, device="cpu", fileroot=root,
                           exp_ctrl=ExperimentSaveEvalControl(total_train_epochs=1, benchmark_steps=3))
@@ -204,6 +208,13 @@ def test_sync_ppo_experiment_with_reference_and_critic(tmp_path):
         assert s["actor_train/head_offpolicyness"] == 0.0  # synchronous: always on-policy
         assert s["actor_train/update_successful"] == 1.0 and s["critic_train/update_successful"] == 1.0
     assert st[-1]["critic_train/grad_norm"] > 0
+    logs = ""
+    for base, _, files in os.walk(os.path.join(root, "logs")):
+        for fn in files:
+            if fn.startswith("model_worker"):
+                with open(os.path.join(base, fn), errors="ignore") as f:
+                    logs += f.read()
+    assert logs.count("ref@0") and logs.count("parked in host memory") >= 2 * 3, logs[-1500:]  # 2 workers x 3 steps
 
 
 @pytest.mark.slow

@@ -723,3 +723,70 @@ def test_slurm_client_pins_the_allocation_with_hostfile_and_multiprog(tmp_path):
     assert open(f"{d}/generation_server.hostfile").read().split() == ["gpu02"] * 4
     with pytest.raises(su.SlurmResourceNotEnoughException):
         c.render_allocated("one_more", "x", 1, gpu=1)
+
+
+def test_engine_offload_parks_weights_and_optimizer_state_and_training_resumes(tmp_path):
+    """`offload` frees the flat parameter / gradient / optimizer storages (contents parked in host memory), the
+    next call brings them back, and training continues exactly as without the round trip."""
+    import torch
+
+    from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
+    from areal_vllm_amd.api.io_struct import FinetuneSpec
+    from areal_vllm_amd.engine.train_engine import NativeTrainEngine
+
+    def make():
+        cfg = TrainEngineConfig(experiment_name="t", trial_name="off", path="tiny", init_from_scratch=True,
+                                dtype="float32", optimizer=OptimizerConfig(lr=1e-2, lr_scheduler_type="constant",
+                                                                           warmup_steps_proportion=0.0),
+                                mb_spec=MicroBatchSpec())
+        e = NativeTrainEngine(cfg)
+        e.create_process_group()
+        e.initialize(None, FinetuneSpec(1, 8, 4))
+        return e
+
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(2, 500, (3, 12), generator=g)
+    batch = dict(input_ids=ids, attention_mask=torch.ones_like(ids, dtype=torch.bool),
+                 loss_mask=torch.ones_like(ids, dtype=torch.bool))
+
+    def loss(proxy, mb):
+        return -proxy.logprobs(torch.roll(mb["input_ids"], -1, 0)).mean()
+
+    w = lambda mb: float(mb["input_ids"].numel())  # noqa: E731
+    a = make()
+    try:
+        a.train_batch(batch, loss, w)
+        before = a.model.flat.flat.clone()
+        full = a.model.flat.flat.untyped_storage().size()
+        freed = a.offload()
+        assert a.offloaded and freed >= full * 2  # parameters + fp32 gradients + optimizer shards
+        assert a.model.flat.flat.untyped_storage().size() == 0 and a.optimizer.m.untyped_storage().size() == 0
+        assert a.offload() == 0  # idempotent
+        s1 = a.train_batch(batch, loss, w)  # comes back by itself
+        assert not a.offloaded and a.model.flat.flat.untyped_storage().size() == full
+        after_a = a.model.flat.flat.clone()
+        assert not torch.equal(before, after_a)
+    finally:
+        a.destroy()
+    b = make()
+    try:
+        b.train_batch(batch, loss, w)
+        assert torch.equal(b.model.flat.flat, before)
+        s2 = b.train_batch(batch, loss, w)
+        assert torch.equal(b.model.flat.flat, after_a) and s1["grad_norm"] == s2["grad_norm"]
+    finally:
+        b.destroy()
+
+
+def test_offload_hooks_are_attached_to_roles_configured_with_offload():
+    from areal_vllm_amd.experiments.common import ModelTrainEvalConfig
+    from areal_vllm_amd.experiments.ppo_math_exp import PPOHyperparameters, PPOMATHExperiment
+    from areal_vllm_amd.system.dfg import OffloadHook
+
+    ppo = PPOHyperparameters(kl_ctl=0.1, disable_value=True)
+    e = PPOMATHExperiment(actor=ModelTrainEvalConfig(path="tiny", init_from_scratch=True),
+                          ref=ModelTrainEvalConfig(path="tiny", init_from_scratch=True, backend="inference", offload=True),
+                          ppo=ppo, layout="d1", device="cpu")
+    cfg = e.initial_setup()
+    hooked = {r.name for r in cfg.model_rpcs if any(isinstance(h, OffloadHook) for h in r._post_hooks)}
+    assert hooked == {"ref_inf"}
