@@ -54,8 +54,12 @@ nodes=( $(scontrol show hostnames $SLURM_JOB_NODELIST) )
 head_node=${{nodes[0]}}
 head_node_ip=$(srun --overlap --nodes=1 --ntasks=1 -w "$head_node" hostname --ip-address | awk '{{print $1}}')
 export AREAL_HEAD_NODE_IP=$head_node_ip
+pids=()
 {srun_lines}
-wait
+# the job fails when any of its steps fails (a bare `wait` would report success)
+rc=0
+for p in "${{pids[@]}}"; do wait "$p" || rc=$?; done
+exit $rc
 """
 
 
@@ -66,7 +70,7 @@ def build_srun_line(cmd: str, env: Dict[str, str], *, nodes: int, ntasks: int, c
         binds = f"--bind {mount}" if mount else ""
         cmd = f"apptainer exec --rocm --no-home --writable-tmpfs {binds} {image} {cmd}"
     return (f"srun {srun_args} --nodes={nodes} --ntasks={ntasks} --export={shlex.quote(exports)} "
-            f"bash -c {shlex.quote(cmd)} &")
+            f"bash -c {shlex.quote(cmd)} &\npids+=($!)")
 
 
 class SlurmLauncher:
@@ -219,7 +223,13 @@ def slurm_main(config: BaseExperimentConfig, run_id: int = 0, entry_argv: Option
                             env=get_env_vars(config.cluster.cluster_name, lc.inference_server_env_vars),
                             image=sl.inference_server_image)
         if am.type_ != AllocationType.LLM_SERVER_ONLY:
-            addrs = wait_llm_server_addrs(config.experiment_name, config.trial_name, n_servers) if n_servers else []
+            def servers_alive():
+                info = launcher.find("llm_server")
+                if info.state in (JobState.FAILED, JobState.CANCELLED, JobState.NOT_FOUND, JobState.COMPLETED):
+                    raise JobException(launcher.run_name, "llm_server", info.host, JobState.FAILED)
+
+            addrs = wait_llm_server_addrs(config.experiment_name, config.trial_name, n_servers,
+                                          check=servers_alive) if n_servers else []
             world = 1 if am.type_ == AllocationType.DECOUPLED_EVAL else am.train.world_size
             n_nodes = max(1, world // per_node)
             gpn = min(per_node, world) if am.type_ != AllocationType.DECOUPLED_EVAL else 0

@@ -97,10 +97,17 @@ def visible_devices() -> List[str]:
 
 
 def wait_llm_server_addrs(experiment_name: str, trial_name: str, n_rollout_servers: int,
-                          timeout: float = 600.0) -> List[str]:
+                          timeout: float = 600.0, check=None, check_interval: float = 5.0) -> List[str]:
+    """Addresses of the rollout servers once all of them have registered. `check()` runs every
+    `check_interval` seconds while waiting and should raise when the servers can no longer come up (their job
+    failed): the caller then fails at once instead of after `timeout`."""
     key = names.gen_servers(experiment_name, trial_name)
     start = time.perf_counter()
+    last_check = start
     while True:
+        if check is not None and time.perf_counter() - last_check >= check_interval:
+            last_check = time.perf_counter()
+            check()
         addrs = name_resolve.get_subtree(key)
         if len(addrs) >= n_rollout_servers:
             logger.info(f"Found {len(addrs)} rollout servers: {', '.join(sorted(addrs))}")
