@@ -36,9 +36,14 @@ except ImportError:  # pragma: no cover
 
 
 def run_func(file_path: str, function_name: str, env: Optional[Dict[str, str]], *args, **kwargs):
-    """Import `file_path` as a module and call `function_name` (executed inside a Ray worker)."""
+    """Import `file_path` - a script path, or the dotted name of an installed module (modules of this package
+    use relative imports and cannot be loaded from their file path) - and call `function_name` (executed inside a
+    Ray worker)."""
     if env:
         os.environ.update(env)
+    if not file_path.endswith(".py"):
+        module = importlib.import_module(file_path)
+        return getattr(module, function_name)(*args, **kwargs)
     module_name = os.path.splitext(os.path.basename(file_path))[0]
     spec = importlib.util.spec_from_file_location(module_name, file_path)
     module = importlib.util.module_from_spec(spec)
@@ -86,6 +91,13 @@ class RayLauncher:
             ).remote(file_path, func_name, env, *list_args[i])
             self.jobs[f"{job_name}:{i}"] = ref
 
+    def check_running(self, job_name: str):
+        """Raise if a task of `job_name` has ended (servers are meant to run until they are cancelled)."""
+        refs = [v for k, v in self.jobs.items() if k.split(":")[0] == job_name]
+        done, _ = ray.wait(refs, num_returns=1, timeout=0) if refs else ([], [])
+        if done:
+            raise JobException(self.run_name, job_name, "ray", JobState.FAILED)
+
     def stop(self, job_name: str, force: bool = False):
         for k in [k for k in self.jobs if k.split(":")[0] == job_name]:
             ray.cancel(self.jobs.pop(k), force=force)
@@ -129,14 +141,14 @@ def ray_main(config: BaseExperimentConfig, run_id: int = 0, entry_argv: Optional
             nodes = max(1, am.gen.world_size // per_node)
             gpn = min(per_node, am.gen.world_size)
             n_servers = am.gen.dp_size
-            wrapper = os.path.join(os.path.dirname(__file__), "server_wrapper.py")
-            launcher.submit_array("llm_server", wrapper, "main", count=nodes, nodes=nodes, gpus_per_task=gpn,
+            launcher.submit_array("llm_server", "areal_vllm_amd.launcher.server_wrapper", "main", count=nodes, nodes=nodes, gpus_per_task=gpn,
                                   cpus_per_task=lc.inference_server_cpus_per_gpu * gpn,
                                   mem_per_task=lc.inference_server_mem_per_gpu * gpn,
                                   list_args=[[entry_argv[1:]] for _ in range(nodes)],
                                   env_vars=get_env_vars(config.cluster.cluster_name, lc.inference_server_env_vars))
         if am.type_ != AllocationType.LLM_SERVER_ONLY:
-            addrs = wait_llm_server_addrs(config.experiment_name, config.trial_name, n_servers) if n_servers else []
+            addrs = wait_llm_server_addrs(config.experiment_name, config.trial_name, n_servers,
+                                          check=lambda: launcher.check_running("llm_server")) if n_servers else []
             world = 1 if am.type_ == AllocationType.DECOUPLED_EVAL else am.train.world_size
             nodes = max(1, world // per_node)
 

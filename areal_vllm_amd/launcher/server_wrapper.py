@@ -85,26 +85,44 @@ class ServerWrapper:
         self.config.random_seed = base_seed
         return out
 
-    def launch_one(self, cmd: str, host: str, port: int, node_rank: int) -> subprocess.Popen:
-        p = subprocess.Popen(cmd.split(), start_new_session=True)
+    def register_when_healthy(self, p: subprocess.Popen, host: str, port: int, node_rank: int):
         wait_for_server(f"http://{host}:{port}", p)
         if node_rank == 0:
             name_resolve.add_subentry(names.gen_servers(self.experiment_name, self.trial_name), f"{host}:{port}")
         logger.info(f"rollout server launched at http://{host}:{port}")
-        return p
 
     def run(self) -> int:
+        """Start the servers and watch them until one exits or this process is told to stop. The servers run in
+        sessions of their own, so nothing reaches them by itself when the wrapper's job is cancelled (`scancel`,
+        a cancelled Ray task, the local launcher's SIGTERM): every way out of here stops them."""
+        import signal
+        import threading
+
+        def on_signal(signum, _frame):
+            raise KeyboardInterrupt(f"signal {signum}")
+
+        if threading.current_thread() is threading.main_thread():
+            for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                signal.signal(sig, on_signal)
         plan = self.plan()
-        with ThreadPoolExecutor(max_workers=max(1, len(plan))) as ex:
-            self.processes = list(ex.map(lambda a: self.launch_one(*a), plan))
-        while True:
-            for i, p in enumerate(self.processes):
-                rc = p.poll()
-                if rc is not None:
-                    logger.error(f"rollout server {plan[i][1]}:{plan[i][2]} exited with code {rc}; stopping the others")
-                    self.stop()
-                    return rc if rc != 0 else 1
-            time.sleep(1)
+        try:
+            for a in plan:  # started one after another here so that an interrupt finds every process in the list
+                self.processes.append(subprocess.Popen(a[0].split(), start_new_session=True))
+            with ThreadPoolExecutor(max_workers=max(1, len(plan))) as ex:
+                list(ex.map(lambda ap: self.register_when_healthy(ap[1], *ap[0][1:]), zip(plan, self.processes)))
+            while True:
+                for i, p in enumerate(self.processes):
+                    rc = p.poll()
+                    if rc is not None:
+                        logger.error(f"rollout server {plan[i][1]}:{plan[i][2]} exited with code {rc}; "
+                                     "stopping the others")
+                        return rc if rc != 0 else 1
+                time.sleep(1)
+        except KeyboardInterrupt as e:
+            logger.info(f"server wrapper interrupted ({e}); stopping {len(self.processes)} rollout server(s)")
+            return 0
+        finally:
+            self.stop()
 
     def stop(self):
         for p in self.processes:

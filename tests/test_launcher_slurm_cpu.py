@@ -16,6 +16,50 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _run_to_files(cmd, env, outdir, timeout):
+    """Run `cmd` with its output in files (not pipes: processes it leaves behind would keep a pipe open and the
+    call waiting); returns (returncode, combined text)."""
+    os.makedirs(outdir, exist_ok=True)
+    path = os.path.join(outdir, "launcher.out")
+    with open(path, "w") as f:
+        p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=f, stderr=subprocess.STDOUT, start_new_session=True)
+        try:
+            rc = p.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, 9)
+            rc = -9
+    return rc, open(path, errors="ignore").read()
+
+
+def _leftover_processes(marker):
+    """Processes whose command line mentions `marker` (the run's private directory)."""
+    import psutil
+
+    out = []
+    for pr in psutil.process_iter(["pid", "cmdline"]):
+        try:
+            if any(marker in a for a in (pr.info["cmdline"] or [])) and pr.pid != os.getpid():
+                out.append(pr)
+        except (psutil.NoSuchProcess, psutil.AccessDenied):
+            pass
+    return out
+
+
+def _assert_nothing_left(marker):
+    import time
+
+    deadline = time.time() + 30
+    while time.time() < deadline and _leftover_processes(marker):
+        time.sleep(0.5)
+    left = _leftover_processes(marker)
+    for pr in left:
+        try:
+            pr.kill()
+        except Exception:
+            pass
+    assert not left, [pr.info["cmdline"] for pr in left]
+
 _COMMON = r'''
 import os, sys, signal, subprocess, json
 D = os.environ["FAKE_SLURM_DIR"]
@@ -163,24 +207,16 @@ def test_decoupled_experiment_runs_as_two_slurm_jobs(fake_slurm):
            "--config", os.path.join(ROOT, "examples/synthetic/toy_grpo.yaml"), f"cluster.fileroot={root}",
            f"cluster.name_resolve.nfs_record_root={root}/nr", "trial_name=slurm", "allocation_mode=native:d1+native:d1",
            "async_training=true", "total_train_epochs=1", "rollout_weight_update=disk", "cluster.n_gpus_per_node=1"]
-    try:
-        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
-    finally:  # whatever happened, no job of the stand-in cluster outlives the test
-        state = os.path.join(fake_slurm, "state")
-        for fn in os.listdir(state) if os.path.isdir(state) else []:
-            if fn.endswith(".pid"):
-                try:
-                    os.killpg(int(open(os.path.join(state, fn)).read()), 9)
-                except OSError:
-                    pass
+    rc, out = _run_to_files(cmd, env, fake_slurm, timeout=300)
     logs = os.path.join(root, "logs", getpass.getuser(), "toy-grpo", "slurm")
     tail = ""
     for fn in ("trainer.log", "llm_server.log"):
         if os.path.exists(os.path.join(logs, fn)):
             tail += f"\n--- {fn}\n" + open(os.path.join(logs, fn), errors="ignore").read()[-2000:]
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:] + tail
+    assert rc == 0, out[-3000:] + tail
     assert "Training completes" in open(os.path.join(logs, "trainer.log"), errors="ignore").read()
     state = os.path.join(fake_slurm, "state")
     assert sorted(f for f in os.listdir(state) if f.endswith(".pid")) == ["101.pid", "102.pid"]
     assert open(os.path.join(state, "102.rc")).read().strip() == "0"  # the trainer job
     assert os.path.exists(os.path.join(state, "101.cancelled"))  # servers are cancelled once the trainer is done
+    _assert_nothing_left(root)  # ... and the cancelled job took its rollout server (a session of its own) with it
