@@ -21,6 +21,8 @@
 //
 // This is the role SGLang's decode GEMMs + elementwise kernels play for the reference
 // (areal/api/cli_args.py:398-454 configures that server).
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace {
@@ -495,10 +497,11 @@ DEVINL f32x4 slab_sum4(const float* __restrict__ p, size_t stride, int S) {
 }
 
 // s = bf16(sum_k slab[k] [+ bias] [+ res]); res_out = s; y = rmsnorm(s) * w (when w != null, else y = s).
-// One 256-thread block per row (M blocks in flight, every thread owns up to MAXC float4 chunks of the row);
-// N % 4 == 0, N <= 4 * 256 * MAXC.
-template <int MAXC>
-__global__ __launch_bounds__(256) void splitk_residual_rmsnorm_kernel(
+// One block of THREADS threads per row (M blocks in flight, every thread owns up to MAXC float4 chunks of the row:
+// rows of up to 2048 elements get one chunk per thread, so that all of a thread's loads are in flight at once);
+// N % 4 == 0, N <= 4 * THREADS * MAXC.
+template <int MAXC, int THREADS>
+__global__ __launch_bounds__(THREADS) void splitk_residual_rmsnorm_kernel(
     const float* __restrict__ slab, int S, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
     const bf16_t* __restrict__ w, bf16_t* __restrict__ res_out, bf16_t* __restrict__ y, int M, int N, float eps,
     int gemma) {
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(256) void splitk_residual_rmsnorm_kernel(
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
-    const int c = threadIdx.x + i * 256;
+    const int c = threadIdx.x + i * THREADS;
     if (c < nchunk) {
       f32x4 s = slab_sum4(slab + (size_t)row * N + c * 4, stride, S);
       if (bias) {
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256) void splitk_residual_rmsnorm_kernel(
     if (y && y != res_out) {
 #pragma unroll
       for (int i = 0; i < MAXC; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = threadIdx.x + i * THREADS;
         if (c < nchunk) {
           bf16x4 o;
 #pragma unroll
@@ -550,13 +553,19 @@ __global__ __launch_bounds__(256) void splitk_residual_rmsnorm_kernel(
     }
     return;
   }
+  bf16x4 wv[MAXC];  // loaded before the reduction's barriers, not after them
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) {
+    const int c = threadIdx.x + i * THREADS;
+    if (c < nchunk) wv[i] = *reinterpret_cast<const bf16x4*>(w + c * 4);
+  }
   ss = block_sum(ss, red);
   const float rstd = rsqrtf(ss / (float)N + eps);
 #pragma unroll
   for (int i = 0; i < MAXC; ++i) {
-    const int c = threadIdx.x + i * 256;
+    const int c = threadIdx.x + i * THREADS;
     if (c < nchunk) {
-      const bf16x4 ww = *reinterpret_cast<const bf16x4*>(w + c * 4);
+      const bf16x4 ww = wv[i];
       bf16x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = f2bf(v[i][j] * rstd * (bf2f(ww[j]) + (gemma ? 1.f : 0.f)));
@@ -570,23 +579,26 @@ extern "C" int areal_splitk_residual_rmsnorm(const float* slab, int S, const voi
                                              int gemma, hipStream_t st) {
   if (M <= 0) return 0;
   if (N % 4 != 0 || N > 4 * 256 * 16 || S < 1) return -1;
-  const int maxc = (N / 4 + 255) / 256;
-  dim3 grid(M), block(256);
-#define LAUNCH(MC)                                                                                          \
-  hipLaunchKernelGGL(splitk_residual_rmsnorm_kernel<MC>, grid, block, 0, st, slab, S, (const bf16_t*)bias,  \
+  const int nchunk = N / 4;
+  dim3 grid(M);
+#define LAUNCH(MC, TH)                                                                                          \
+  hipLaunchKernelGGL((splitk_residual_rmsnorm_kernel<MC, TH>), grid, dim3(TH), 0, st, slab, S, (const bf16_t*)bias, \
                      (const bf16_t*)res, (const bf16_t*)w, (bf16_t*)res_out, (bf16_t*)y, M, N, eps, gemma)
-  if (maxc <= 2) LAUNCH(2);
-  else if (maxc <= 4) LAUNCH(4);
-  else if (maxc <= 8) LAUNCH(8);
-  else LAUNCH(16);
+  if (nchunk <= 256) LAUNCH(1, 256);
+  else if (nchunk <= 384) LAUNCH(1, 384);
+  else if (nchunk <= 512) LAUNCH(1, 512);
+  else if (nchunk <= 1024) LAUNCH(2, 512);
+  else if (nchunk <= 2048) LAUNCH(4, 512);
+  else LAUNCH(16, 256);
 #undef LAUNCH
   return (int)hipGetLastError();
 }
 
 // qkv = bf16(sum_k slab[k] + bias), laid out [T, Hq + 2 Hkv, D]: rotate q and k (half-split layout), write q to
 // q_out [T, Hq, D] (bf16), k / v into the paged caches at slots[t] (K [P, Hkv, 32, D], V [P, Hkv, D, 32]).
-// One block per token: the summed row is staged in LDS (fp32, Nq floats), then rotated / scattered from there.
-__global__ __launch_bounds__(256) void splitk_rope_cache_write_kernel(
+// One block per token (256 .. 1024 threads by row length): the summed row is staged in LDS (fp32, Nq floats), then
+// rotated / scattered from there.
+__global__ __launch_bounds__(1024) void splitk_rope_cache_write_kernel(
     const float* __restrict__ slab, int S, const bf16_t* __restrict__ bias, const int* __restrict__ pos,
     const int64_t* __restrict__ slots, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
     bf16_t* __restrict__ q_out, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, int T, int Hq, int Hkv,
@@ -597,6 +609,19 @@ __global__ __launch_bounds__(256) void splitk_rope_cache_write_kernel(
   const int lph = half >> 3;
   const int Nq = (Hq + 2 * Hkv) * D;
   const size_t stride = (size_t)T * Nq;
+  // Position, slot and this thread's first rotary-table rows are requested before the slab sum, so that their
+  // latency (a dependent pos -> table chain) runs under the slab loads instead of after the barrier.
+  int p = pos[t];
+  p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+  const int64_t slot = slots ? slots[t] : -1;
+  const int nrot = (Hq + Hkv) * lph;
+  f32x4 c_pre[2], s_pre[2];
+  if (do_rope && (int)threadIdx.x < nrot) {
+    const int sub0 = threadIdx.x % lph;
+    const f32x4* cp4 = reinterpret_cast<const f32x4*>(cos_t + (size_t)p * half + sub0 * 8);
+    const f32x4* sp4 = reinterpret_cast<const f32x4*>(sin_t + (size_t)p * half + sub0 * 8);
+    c_pre[0] = cp4[0]; c_pre[1] = cp4[1]; s_pre[0] = sp4[0]; s_pre[1] = sp4[1];
+  }
   for (int c = threadIdx.x; c < (Nq >> 2); c += blockDim.x) {
     f32x4 s = slab_sum4(slab + (size_t)t * Nq + c * 4, stride, S);
     if (bias) {
@@ -610,24 +635,34 @@ __global__ __launch_bounds__(256) void splitk_rope_cache_write_kernel(
     *reinterpret_cast<f32x4*>(rowbuf + c * 4) = s;
   }
   __syncthreads();
-  int p = pos[t];
-  p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
-  const int64_t slot = slots ? slots[t] : -1;
   const int64_t page = slot >= 0 ? slot / 32 : 0;
   const int off = slot >= 0 ? (int)(slot % 32) : 0;
-  const int nrot = (Hq + Hkv) * lph;
   for (int i = threadIdx.x; i < nrot; i += blockDim.x) {
     const int head = i / lph, sub = i % lph;
-    const float* lo = rowbuf + head * D + sub * 8;
-    const float* hi = lo + half;
+    // 16-byte LDS / global reads: dword reads at this 32-byte lane stride would be 8-way bank conflicts
+    const f32x4* lo4 = reinterpret_cast<const f32x4*>(rowbuf + head * D + sub * 8);
+    const f32x4* hi4 = reinterpret_cast<const f32x4*>(rowbuf + head * D + sub * 8 + half);
+    float lo[8], hi[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const f32x4 a = lo4[q], b = hi4[q];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lo[4 * q + j] = a[j]; hi[4 * q + j] = b[j]; }
+    }
     bf16x8 olo, ohi;
     if (do_rope) {
-      const float* cp = cos_t + (size_t)p * half + sub * 8;
-      const float* sp = sin_t + (size_t)p * half + sub * 8;
+      const bool first = i == (int)threadIdx.x;  // the rows requested up front
+      const f32x4* cp4 = reinterpret_cast<const f32x4*>(cos_t + (size_t)p * half + sub * 8);
+      const f32x4* sp4 = reinterpret_cast<const f32x4*>(sin_t + (size_t)p * half + sub * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        olo[j] = f2bf(lo[j] * cp[j] - hi[j] * sp[j]);
-        ohi[j] = f2bf(hi[j] * cp[j] + lo[j] * sp[j]);
+      for (int q = 0; q < 2; ++q) {
+        f32x4 c, sn;
+        if (first) { c = c_pre[q]; sn = s_pre[q]; } else { c = cp4[q]; sn = sp4[q]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          olo[4 * q + j] = f2bf(lo[4 * q + j] * c[j] - hi[4 * q + j] * sn[j]);
+          ohi[4 * q + j] = f2bf(hi[4 * q + j] * c[j] + lo[4 * q + j] * sn[j]);
+        }
       }
     } else {
 #pragma unroll
@@ -660,7 +695,10 @@ extern "C" int areal_splitk_rope_cache_write(const float* slab, int S, const voi
   if (T <= 0) return 0;
   const size_t lds = (size_t)(Hq + 2 * Hkv) * D * sizeof(float);
   if (D % 16 != 0 || S < 1 || lds > 64 * 1024) return -1;
-  hipLaunchKernelGGL(splitk_rope_cache_write_kernel, dim3(T), dim3(256), lds, st, slab, S, (const bf16_t*)bias, pos,
+  // one float4 chunk of the summed row per thread where the row allows it: all of a thread's slab loads are in
+  // flight at once (a second pass over the row would wait for the first one's loads)
+  const int threads = std::min(1024, std::max(256, (((Hq + 2 * Hkv) * D / 4 + 63) / 64) * 64));
+  hipLaunchKernelGGL(splitk_rope_cache_write_kernel, dim3(T), dim3(threads), lds, st, slab, S, (const bf16_t*)bias, pos,
                      slots, cos_t, sin_t, (bf16_t*)q_out, (bf16_t*)kcache, (bf16_t*)vcache, T, Hq, Hkv, D, max_pos,
                      do_rope);
   return (int)hipGetLastError();
