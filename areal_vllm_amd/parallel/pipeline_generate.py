@@ -206,7 +206,7 @@ class PipelineGenerator:
         finished = [torch.zeros(mb["b"], dtype=torch.bool, device=dev) for mb in mbs] if self.last else None
         n_generated = 1
         for t in range(1, max_new_tokens):
-            if self.last and (t % check_interval == 0 or self.pp == 1):
+            if self.last and t % check_interval == 0:
                 for mb, fin in zip(mbs, finished):
                     if t > min_new_tokens and stops.numel():
                         # tokens 0 .. t-1 exist; those at index >= min_new_tokens may stop the sequence
@@ -215,7 +215,7 @@ class PipelineGenerator:
                 done.fill_(int(all(bool(f.all()) for f in finished)))
             if self.pp > 1 and t % check_interval == 0:
                 dist.broadcast(done, src=last_rank, group=self.grid.group("pp"))
-            if (self.pp == 1 or t % check_interval == 0) and int(done):
+            if t % check_interval == 0 and int(done):  # the only host synchronisation of the decode loop
                 break
             for mb in mbs:
                 b = mb["b"]
