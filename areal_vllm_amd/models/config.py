@@ -252,6 +252,10 @@ PRESETS: Dict[str, Dict[str, Any]] = {
     "tiny-qknorm": dict(family="qwen3", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=4, n_kv_heads=2,
                         head_dim=64, intermediate_size=512, tie_word_embeddings=False, qkv_bias=False, qk_norm=True,
                         rope_theta=1e4, max_position_embeddings=4096, eos_token_id=1, pad_token_id=0),
+    "tiny-gemma": dict(family="gemma", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
+                       head_dim=256, intermediate_size=512, tie_word_embeddings=True, qkv_bias=False,
+                       hidden_act="gelu_pytorch_tanh", gemma_norm=True, rope_theta=1e4, max_position_embeddings=4096,
+                       eos_token_id=1, pad_token_id=0),
     "tiny-gpt2": dict(family="gpt2", vocab_size=512, hidden_size=128, n_layers=2, n_q_heads=2, n_kv_heads=2,
                       head_dim=64, intermediate_size=512, tie_word_embeddings=True, qkv_bias=True,
                       hidden_act="gelu_tanh", norm_type="layer", pos_embed="learned", mlp_gated=False,

@@ -23,11 +23,12 @@ DEVINL f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// grid: (B, Hkv, nsplit); block: 256 threads = 4 waves. D = 128 or 64 (template).
+// grid: (B, Hkv, nsplit); block: 256 threads = 4 waves. D = 64, 128 or 256 (template; 256 holds a page's 32 KiB of
+// K and V fragments in registers and runs one workgroup per SIMD set instead of two).
 // q: [B, Hq, D]; out: [B, Hq, D] when nsplit == 1 else partials.
 // part_o: [B, Hq, nsplit, D] fp32, part_ml: [B, Hq, nsplit, 2] (m in log2 units, l).
 template <int D>
-__global__ __launch_bounds__(256, 2) void paged_decode_kernel(
+__global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void paged_decode_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kcache,
     const bf16_t* __restrict__ vcache, const int* __restrict__ block_tables,
     const int* __restrict__ context_lens, bf16_t* __restrict__ out, float* __restrict__ part_o,
@@ -184,12 +185,22 @@ extern "C" int areal_paged_decode(const void* q, const void* kcache, const void*
                                   hipStream_t st) {
   if (B == 0) return 0;
   if (Hq % Hkv != 0 || Hq / Hkv > 16) return -1;
-  if (D != 128 && D != 64) return -2;
+  if (D != 128 && D != 64 && D != 256) return -2;
   if (nsplit < 1 || (nsplit > 1 && (!part_o || !part_ml))) return -3;
   const float scale_log2 = softmax_scale * 1.4426950408889634f;
   const size_t lds = (size_t)(4 * 16 * (D + 4) + 2 * 4 * 16) * sizeof(float);
   dim3 grid(B, Hkv, nsplit), block(256);
-  if (D == 128)
+  if (D == 256) {
+    static bool attr_set = false;  // 67 KiB of dynamic LDS: above the default limit
+    if (!attr_set) {
+      HIP_RET(hipFuncSetAttribute((const void*)paged_decode_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(paged_decode_kernel<256>, grid, block, lds, st, (const bf16_t*)q,
+                       (const bf16_t*)kcache, (const bf16_t*)vcache, block_tables, context_lens,
+                       (bf16_t*)out, part_o, part_ml, Hq, Hkv, max_pages, scale_log2, q_stride);
+  } else if (D == 128)
     hipLaunchKernelGGL(paged_decode_kernel<128>, grid, block, lds, st, (const bf16_t*)q,
                        (const bf16_t*)kcache, (const bf16_t*)vcache, block_tables, context_lens,
                        (bf16_t*)out, part_o, part_ml, Hq, Hkv, max_pages, scale_log2, q_stride);

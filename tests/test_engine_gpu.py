@@ -340,6 +340,39 @@ def test_offload_frees_device_memory_and_restores_the_model(engine):
     assert torch.cuda.memory_allocated() >= before - (64 << 20)
 
 
+def test_gemma_family_rolls_out_with_head_size_256():
+    """Gemma layout (head size 256, GeGLU, (1 + w) norms, scaled embeddings) through the rollout engine: paged
+    decode attention at D = 256 and the library-attention prefill score the samples like the trainer does."""
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters
+    from areal_vllm_amd.workflow.rlvr import RLVRWorkflow
+
+    actor, eng, ro, meta, dev = _rollout_pair(model="tiny-gemma", decode_steps=4, pages=256)
+    try:
+        assert actor.model_config.head_dim == 256 and actor.model_config.gemma_norm
+        torch.manual_seed(0)
+        with torch.no_grad():
+            actor.model.flat.flat.normal_(0, 0.05)  # norms included: (1 + w) with w != 0
+        actor.upload_weights(meta)
+        g = GenerationHyperparameters(n_samples=2, max_new_tokens=64, temperature=1.0, stop_token_ids=[1])
+        wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: 0.0, g, reward_in_process=True)
+        gen = torch.Generator().manual_seed(5)
+        prompts = [dict(input_ids=torch.randint(2, 500, (n,), generator=gen).tolist()) for n in (7, 40, 33, 90)]
+        batch = ro.rollout_batch(prompts, workflow=wf)
+        batch = {k: v.to(dev) if torch.is_tensor(v) else v for k, v in batch.items()}
+        lm = batch["loss_mask"].bool()
+        assert int(lm.sum()) > 8 * 20
+        prox = actor.compute_logp(batch)
+        behav = torch.roll(batch["logprobs"], -1, 1)
+        m = torch.roll(lm, -1, 1)
+        m[:, -1] = False
+        diff = (prox.float() - behav.float()).abs()[m]
+        assert float(diff.mean()) < 0.03 and float(diff.max()) < 0.3, (float(diff.mean()), float(diff.max()))
+    finally:
+        ro.destroy()
+        eng.destroy()
+        actor.destroy()
+
+
 def test_weight_update_interrupts_running_generation():
     """Requests in flight when new weights arrive are aborted, re-issued by the client with their partial
     output, and finish with tokens tagged by both weight versions."""

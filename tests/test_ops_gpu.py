@@ -294,7 +294,7 @@ def test_flash_attn_long_context_q_shorter_than_k_bwd(lq, lk):
     _close_long(v.grad, dv, "dv")
 
 
-@pytest.mark.parametrize("Hq,Hkv,D", [(12, 2, 128), (28, 4, 128), (8, 8, 128), (16, 2, 64)])
+@pytest.mark.parametrize("Hq,Hkv,D", [(12, 2, 128), (28, 4, 128), (8, 8, 128), (16, 2, 64), (8, 1, 256), (16, 16, 256)])
 @pytest.mark.parametrize("nsplit", [1, 4])
 def test_paged_decode_and_cache_write(Hq, Hkv, D, nsplit):
     torch.manual_seed(5)
