@@ -86,6 +86,7 @@ class ModelRunner:
         if fused_decode is None:
             fused_decode = self.device.type == "cuda" and os.environ.get("AREAL_FUSED_DECODE", "1") != "0"
         self.fused_decode = bool(fused_decode) and fusable
+        self._gate_up_choice: Dict[int, bool] = {}  # batch bucket -> fused gate|up GEMM wins (timed once)
         # qkv projection with bias + RoPE + KV-cache write in its epilogue (head sizes that are multiples of 64)
         self.fused_qkv_rope = cfg.head_dim % 64 == 0 and os.environ.get("AREAL_FUSED_QKV_ROPE", "1") != "0"
 
@@ -340,8 +341,47 @@ class ModelRunner:
         return st
 
     FUSED_MIN_BATCH = 48
-    # above this many rows the widest GEMM (gate|up) is faster in the library; the other three stay fused
-    FUSED_GATE_UP_MAX_BATCH = 384
+
+    def _gate_up_fused(self, Bp: int) -> bool:
+        """Does the widest GEMM of the layer (gate|up with the SwiGLU epilogue) beat the library GEMM followed by
+        the activation kernel at this batch bucket? Depends on the model's shapes (Qwen2-1.5B: fused up to 384 rows;
+        Qwen2.5-7B: only up to ~128), so it is timed once per bucket on the model's own weights, rotating over
+        the layers so that neither arm streams from a warm cache. The other three GEMMs stay fused either way."""
+        if Bp in self._gate_up_choice:
+            return self._gate_up_choice[Bp]
+        from ..ops import decode_gemm as dg
+
+        forced = os.environ.get("AREAL_FUSED_GATE_UP")
+        if forced is not None or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            self._gate_up_choice[Bp] = forced != "0" if forced is not None else True
+            return self._gate_up_choice[Bp]
+        layers = self.model.layers
+        x = torch.randn(Bp, self.cfg.hidden_size, device=self.device, dtype=self.dtype)
+
+        def fused(i):
+            return dg.dgemm(x, layers[i % len(layers)].mlp.gate_up, epilogue=dg.EPI_SWIGLU)
+
+        def library(i):
+            blk = layers[i % len(layers)]
+            return ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)
+
+        times = []
+        for fn in (fused, library):
+            for i in range(2):
+                fn(i)
+            torch.cuda.synchronize(self.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = max(8, len(layers))
+            e0.record()
+            for i in range(n):
+                fn(i)
+            e1.record()
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) / n)
+        self._gate_up_choice[Bp] = times[0] <= times[1]
+        logger.info(f"decode batch bucket {Bp}: gate|up GEMM fused {times[0] * 1e3:.1f} us vs library + activation "
+                    f"{times[1] * 1e3:.1f} us -> {'fused' if self._gate_up_choice[Bp] else 'library'}")
+        return self._gate_up_choice[Bp]
 
     def _decode_layers_fused(self, st: Dict[str, torch.Tensor], h: torch.Tensor, rope_pos: torch.Tensor):
         """All decoder layers of one decode step on the fused path -> final-normed hidden states [Bp, H].
@@ -357,6 +397,7 @@ class ModelRunner:
         Bp, H = h.shape
         eps, gemma = cfg.rms_norm_eps, cfg.gemma_norm
         layers = self.model.layers
+        gate_up_fused = self._gate_up_fused(Bp)
         x, residual = ops.rmsnorm(h, layers[0].ln1, eps, None, gemma)
         for li, blk in enumerate(layers):
             kc, vc = self.kv[li]
@@ -372,7 +413,7 @@ class ModelRunner:
             slab = dg.dgemm(attn.view(Bp, hq * D), blk.attn.o, epilogue=dg.EPI_SLAB)
             x, residual = dg.splitk_residual_rmsnorm(slab, slab.shape[0], Bp, H, residual=residual, weight=blk.ln2,
                                                      eps=eps, gemma=gemma, dtype=self.dtype)
-            if Bp <= self.FUSED_GATE_UP_MAX_BATCH:
+            if gate_up_fused:
                 act = dg.dgemm(x, blk.mlp.gate_up, epilogue=dg.EPI_SWIGLU)
             else:
                 act = ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)
