@@ -110,7 +110,8 @@ def main():
     cfg = preset(args.model)
     H, D = cfg.hidden_size, cfg.head_dim
     nq = (cfg.n_q_heads + 2 * cfg.n_kv_heads) * D
-    shapes = {"qkv": (nq, H, dg.EPI_SLAB), "o": (H, cfg.n_q_heads * D, dg.EPI_SLAB),
+    shapes = {"lm_head": (cfg.vocab_size // 32 * 32, H, dg.EPI_BF16),
+              "qkv": (nq, H, dg.EPI_SLAB), "o": (H, cfg.n_q_heads * D, dg.EPI_SLAB),
               "gate_up": (2 * cfg.intermediate_size, H, dg.EPI_SWIGLU), "down": (H, cfg.intermediate_size, dg.EPI_SLAB)}
     g = torch.Generator(device=dev).manual_seed(0)
     if "qkv_rope" in args.layers.split(","):
@@ -162,6 +163,10 @@ def main():
                             rows.append((t, cid, stages, ks, blocks, err / max(scale, 1e-6), lw, int(nt)))
                         del out
             rows.sort()
+            if not rows:
+                print(f"{name:8s} N={N:6d} K={K:6d} M={M:4d}  lib {t_lib:7.1f} us   (no tile configuration within the "
+                      f"64 .. 2048 workgroup range)", flush=True)
+                continue
             print(f"{name:8s} N={N:6d} K={K:6d} M={M:4d}  lib {t_lib:7.1f} us   "
                   f"W {N * K * 2 / 1e6:6.1f} MB -> best {N * K * 2 / rows[0][0] / 1e6:6.2f} TB/s, "
                   f"{2.0 * M * N * K / rows[0][0] / 1e6:7.1f} TFLOP/s", flush=True)
