@@ -161,6 +161,7 @@ class NativeInferenceEngine:
                                   use_graph=not cfg.disable_cuda_graph, seed=int(cfg.random_seed),
                                   buckets=cfg.cuda_graph_bs)
         self.num_pages = num_pages
+        self.runner.tune_decode_paths()
         if (self.tp_size > 1 and self.device.type == "cuda" and not cfg.disable_custom_all_reduce
                 and self.tp_size <= 8 and mc.n_experts == 0 and self.dtype == torch.bfloat16
                 and os.environ.get("AREAL_CUSTOM_ALL_REDUCE", "1") != "0"):
