@@ -40,21 +40,30 @@ logger = logging.getLogger("local-launcher")
 RECOVER_TIME_INTERVAL = 10  # seconds
 
 
+def _as_signal(sig: Optional[Union[str, int]]) -> int:
+    """None -> SIGKILL, "SIGTERM" / "TERM" -> its number, numbers pass through."""
+    if sig is None:
+        return int(signal_module.SIGKILL)
+    if isinstance(sig, str):
+        name = sig if sig.startswith("SIG") else "SIG" + sig
+        return int(getattr(signal_module, name))
+    return int(sig)
+
+
 def terminate_process_and_children(pid: int, signal: Optional[Union[str, int]] = None):
-    if signal is None:
-        signal = signal_module.SIGKILL
-    if isinstance(signal, str):
-        signal = getattr(signal_module, signal)
+    """Signal a process and everything it has started, deepest descendants first (a server wrapper's servers run in
+    sessions of their own, so the process group is not enough). Processes that are already gone are skipped."""
+    signum = _as_signal(signal)
     try:
-        parent = psutil.Process(pid)
-        for child in parent.children(recursive=True):
-            try:
-                child.send_signal(signal)
-            except psutil.NoSuchProcess:
-                pass
-        parent.send_signal(signal)
+        root = psutil.Process(pid)
+        family = root.children(recursive=True)[::-1] + [root]
     except psutil.NoSuchProcess:
-        pass
+        return
+    for proc in family:
+        try:
+            proc.send_signal(signum)
+        except psutil.NoSuchProcess:
+            continue
 
 
 class LocalLauncher:
