@@ -1,17 +1,21 @@
-"""One-shot all-reduce over peer-mapped memory (``csrc/hip/ipc_allreduce.hip``) for decode-sized messages.
+"""All-reduce over peer-mapped memory (``csrc/hip/ipc_allreduce.hip``) for decode-sized messages: one-shot for small
+ones, two-shot (reduce-scatter + all-gather) from a few hundred KB on groups of four or more ranks.
 
 A tensor-parallel decode step all-reduces ``[batch, hidden]`` bf16 twice per layer: a few hundred KB to ~2 MB, far
 below the size at which a ring collective reaches link bandwidth, so its cost is launch + protocol latency. Here every
 rank maps the staging regions of its peers once (hipIpc handles exchanged through the group's host backend) and one
 kernel per call copies the input into the rank's own region, signals the peers with flags in THEIR memory, and sums
 all regions with direct loads over xGMI - no communicator, capturable in a hipGraph, bitwise identical results on
-every rank (fixed summation order). Larger messages (prefill) stay on RCCL.
+every rank (fixed summation order). In the two-shot form a rank sums only its 1/n of every chunk and pushes the result
+into the peers' result slots: (n-1)/n of the message read and written per rank instead of (n-1) messages read, at the
+price of a second flag round trip. Messages beyond the staging capacity (prefill) stay on RCCL.
 
 Role in the reference: the custom all-reduce inside its serving engines (``disable_custom_all_reduce``,
 ``areal/api/cli_args.py:398-454``).
 """
 import ctypes
-from typing import List
+import os
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
@@ -19,6 +23,10 @@ import torch.distributed as dist
 from . import _lib as L
 
 MAX_RANKS = 8
+# two-shot from this many bytes on (groups of >= TWO_SHOT_MIN_RANKS ranks; with two or three ranks it moves as many
+# bytes over the links as one-shot and only adds a flag round trip)
+TWO_SHOT_MIN_BYTES = int(os.environ.get("AREAL_AR_TWO_SHOT_BYTES", 1 << 20))
+TWO_SHOT_MIN_RANKS = 4
 
 
 class IpcAllReduce:
@@ -33,7 +41,10 @@ class IpcAllReduce:
         self.nbytes = int(lib.areal_ipc_allreduce_region_bytes(ctypes.c_long(self.cap)))
         with torch.cuda.device(device):
             p = ctypes.c_void_p(0)
-            L.check(lib.areal_ipc_alloc(ctypes.c_long(self.nbytes), ctypes.byref(p)), "ipc_alloc")
+            # uncached: peers store into this region (flags, result slots) while this device's kernels read it
+            if lib.areal_ipc_alloc_uncached(ctypes.c_long(self.nbytes), ctypes.byref(p)) != 0:
+                p = ctypes.c_void_p(0)
+                L.check(lib.areal_ipc_alloc(ctypes.c_long(self.nbytes), ctypes.byref(p)), "ipc_alloc")
             self._ptr = p.value
             zeros = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
             L.check(lib.areal_memcpy_d2d_async(p, ctypes.c_void_p(zeros.data_ptr()), ctypes.c_long(self.nbytes),
@@ -66,13 +77,16 @@ class IpcAllReduce:
         return (x.dtype == torch.bfloat16 and x.is_cuda and x.is_contiguous() and x.numel() <= self.cap
                 and x.data_ptr() % 16 == 0)
 
-    def all_reduce_(self, x: torch.Tensor) -> torch.Tensor:
-        """In-place sum over the group on the current stream. Every rank must call it with the same shape, in the
-        same order relative to its other calls."""
+    def all_reduce_(self, x: torch.Tensor, two_shot: Optional[bool] = None) -> torch.Tensor:
+        """In-place sum over the group on the current stream. Every rank must call it with the same shape (and the
+        same `two_shot` choice: by default a function of size and group size only), in the same order relative to
+        its other calls."""
         assert self.fits(x), "message does not fit the staging region (bf16, contiguous, <= capacity)"
-        L.check(L.lib().areal_ipc_allreduce(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()),
-                                            ctypes.c_long(x.numel()), self._bases, ctypes.c_int(self.n),
-                                            ctypes.c_int(self.rank), ctypes.c_long(self.cap), L.stream_ptr()),
+        if two_shot is None:
+            two_shot = self.n >= TWO_SHOT_MIN_RANKS and x.numel() * 2 >= TWO_SHOT_MIN_BYTES
+        fn = L.lib().areal_ipc_allreduce_two_shot if two_shot else L.lib().areal_ipc_allreduce
+        L.check(fn(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_long(x.numel()), self._bases,
+                   ctypes.c_int(self.n), ctypes.c_int(self.rank), ctypes.c_long(self.cap), L.stream_ptr()),
                 "ipc_allreduce")
         return x
 
@@ -80,10 +94,10 @@ class IpcAllReduce:
         """Collective: reduce known values twice (both staging slots) and agree on whether every rank got the right
         sums. A caller falls back to the group's ordinary collective when this says no."""
         ok = True
-        for rep in range(2):
+        for rep in range(4):  # both kernels, both staging slots
             x = torch.full((min(self.cap, 4096 + 8 * rep),), float(self.rank + 1), dtype=torch.bfloat16,
                            device=self.device)
-            self.all_reduce_(x)
+            self.all_reduce_(x, two_shot=rep >= 2)
             ok = ok and bool((x.float() == self.n * (self.n + 1) / 2).all().item())
         ok = ok and not self.error()
         votes: List = [None] * self.n
@@ -93,7 +107,9 @@ class IpcAllReduce:
     def error(self) -> bool:
         """True if a call gave up waiting for a peer (its result is then garbage). Synchronises the stream."""
         word = torch.empty(1, dtype=torch.int32, device=self.device)
-        off = 2 * self.cap * 2 + 2 * MAX_RANKS * 128 * 4 + 8
+        lib = L.lib()
+        lib.areal_ipc_allreduce_state_offset.restype = ctypes.c_long
+        off = int(lib.areal_ipc_allreduce_state_offset(ctypes.c_long(self.cap))) + 8  # third state word
         L.check(L.lib().areal_memcpy_d2d_async(ctypes.c_void_p(word.data_ptr()), ctypes.c_void_p(self._ptr + off),
                                                ctypes.c_long(4), L.stream_ptr()), "memcpy_d2d_async")
         return bool(word.item())

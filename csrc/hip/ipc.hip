@@ -38,6 +38,14 @@ extern "C" int areal_ipc_alloc(long bytes, void** out) {
   return 0;
 }
 
+// The same, but uncached / fine-grained: memory that kernels of SEVERAL devices write while a kernel of this device
+// polls or reads it (flag tables and result slots of the peer-memory all-reduce). Lines of an ordinary allocation
+// may sit in this device's L2, which a peer's stores over xGMI do not pass through; uncached memory has no such copy.
+extern "C" int areal_ipc_alloc_uncached(long bytes, void** out) {
+  IPC_RET(hipExtMallocWithFlags(out, (size_t)bytes, hipDeviceMallocUncached));
+  return 0;
+}
+
 extern "C" int areal_ipc_free(void* p) {
   IPC_RET(hipFree(p));
   return 0;

@@ -905,11 +905,11 @@ def _ipc_allreduce_worker(rank, world, port, out_dir):
         return [torch.randn(n, generator=g).bfloat16() for _ in range(world)]
 
     call = 0
-    for rep in range(3):  # repeated use of both staging slots
+    for rep in range(4):  # repeated use of both staging slots; the two kernels interleaved on one sequence counter
         for n in sizes:
             xs = inputs(n, call)
             x = xs[rank].to(dev)
-            ar.all_reduce_(x)
+            ar.all_reduce_(x, two_shot=(rep + call) % 2 == 1)
             want = torch.stack([t.float() for t in xs]).sum(0).bfloat16()
             got = x.cpu()
             assert torch.equal(got, want), (rank, n, (got.float() - want.float()).abs().max())
@@ -926,7 +926,7 @@ def _ipc_allreduce_worker(rank, world, port, out_dir):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         ar.all_reduce_(buf)
-        ar.all_reduce_(buf)
+        ar.all_reduce_(buf, two_shot=True)
     for rep in range(3):
         buf.fill_(float(rank + 1 + rep))
         graph.replay()
@@ -940,9 +940,11 @@ def _ipc_allreduce_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_peer_memory_all_reduce_between_two_processes(tmp_path):
-    """Two processes on this GPU map each other's staging regions and all-reduce bf16 messages of decode sizes
-    with the one-shot kernel: exact fp32-ordered sums, identical bits on both ranks, graph replay."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_memory_all_reduce_between_processes(tmp_path, world):
+    """Processes on this GPU map each other's staging regions and all-reduce bf16 messages of decode sizes with the
+    one-shot and the two-shot kernel interleaved: exact fp32-ordered sums, identical bits on every rank, graph
+    replay."""
     import socket
 
     import torch.multiprocessing as mp
@@ -951,7 +953,7 @@ def test_peer_memory_all_reduce_between_two_processes(tmp_path):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_ipc_allreduce_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_ipc_allreduce_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -960,5 +962,6 @@ def test_peer_memory_all_reduce_between_two_processes(tmp_path):
     for p in alive:
         p.kill()
     assert not alive and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    a, b = (torch.load(tmp_path / f"r{r}.pt", weights_only=True) for r in range(2))
-    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    first, *others = (torch.load(tmp_path / f"r{r}.pt", weights_only=True) for r in range(world))
+    for other in others:
+        assert all(torch.equal(x, y) for x, y in zip(first, other))

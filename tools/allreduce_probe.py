@@ -3,7 +3,8 @@
     python tools/allreduce_probe.py [world=2]
 
 Starts `world` processes on GPU 0 (all that a one-GPU box allows: the peers' regions are then local memory, so the
-figure is protocol + kernel time without the xGMI hop) and times a captured graph of 64 back-to-back calls.
+figure is protocol + kernel time without the xGMI hop, with `world` kernels sharing one device) and times a captured
+graph of 64 back-to-back calls of the one-shot and of the two-shot kernel.
 """
 import os
 import socket
@@ -27,25 +28,27 @@ def worker(rank, world, port):
     ar = IpcAllReduce(dist.group.WORLD, dev, 512 * 8192)
     for rows, hidden in [(1, 1536), (64, 1536), (256, 1536), (256, 3584), (256, 5120), (512, 8192)]:
         x = torch.randn(rows, hidden, device=dev).bfloat16()
-        ar.all_reduce_(x)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(64):
-                ar.all_reduce_(x)
-        x.zero_()
-        dist.barrier()
-        g.replay()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t = time.perf_counter()
-        for _ in range(5):
+        took = {}
+        for two_shot in (False, True):
+            ar.all_reduce_(x, two_shot=two_shot)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(64):
+                    ar.all_reduce_(x, two_shot=two_shot)
+            x.zero_()
+            dist.barrier()
             g.replay()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t) / (5 * 64)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t = time.perf_counter()
+            for _ in range(5):
+                g.replay()
+            torch.cuda.synchronize()
+            took[two_shot] = (time.perf_counter() - t) / (5 * 64)
         if rank == 0:
-            print(f"{world} ranks  [{rows:4d}, {hidden:5d}] bf16 ({rows * hidden * 2 / 1024:8.1f} KiB): {dt * 1e6:7.1f} us per "
-                  f"all-reduce", flush=True)
+            print(f"{world} ranks  [{rows:4d}, {hidden:5d}] bf16 ({rows * hidden * 2 / 1024:8.1f} KiB): one-shot "
+                  f"{took[False] * 1e6:7.1f} us, two-shot {took[True] * 1e6:7.1f} us per all-reduce", flush=True)
     assert not ar.error()
     dist.barrier()
     ar.close()
