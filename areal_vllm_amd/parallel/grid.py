@@ -222,6 +222,12 @@ def init_distributed(backend: Optional[str] = None, timeout=DIST_TIMEOUT):
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    from ..utils import host_staged
+
+    if host_staged.maybe_install_from_env():  # one-GPU rehearsal of a multi-rank layout: host backend, staged copies
+        backend = "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     if backend == "nccl":
         local_rank = int(os.environ.get("LOCAL_RANK", str(rank % max(1, torch.cuda.device_count()))))
         torch.cuda.set_device(local_rank)

@@ -752,3 +752,132 @@ def test_tp2_serving_on_one_gpu_with_peer_memory_all_reduce(tmp_path):
     for (ta, la), (tb, lb) in zip(*outs):
         assert len(ta) == 12 and ta == tb
         assert la == pytest.approx(lb, abs=1e-6)
+
+
+# ------------------------------------------------------------------ multi-rank layouts on ONE GPU
+_LAYOUT_LENS = [257, 64, 300, 129, 33, 512, 77, 90]
+
+
+def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", AREAL_HOST_STAGED_COLLECTIVES="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from areal_vllm_amd.api.alloc_mode import ParallelStrategy
+    from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
+    from areal_vllm_amd.api.io_struct import FinetuneSpec, SaveLoadMeta
+    from areal_vllm_amd.engine.train_engine import NativeTrainEngine
+    from areal_vllm_amd.utils import host_staged
+
+    layout = dict(layout)
+    preset_name = layout.pop("_model", "small")
+    cfg = TrainEngineConfig(experiment_name="t", trial_name="lay", path=ckpt_in or preset_name, init_from_scratch=ckpt_in is None,
+                            dtype="bfloat16", gradient_checkpointing=False,
+                            optimizer=OptimizerConfig(lr=2e-3, weight_decay=0.0, gradient_clipping=1.0,
+                                                      warmup_steps_proportion=0.0, lr_scheduler_type="constant"),
+                            mb_spec=MicroBatchSpec(n_mbs=2, max_tokens_per_mb=2048))
+    layout = dict(layout)
+    cfg.native.sequence_parallel = seq_par
+    cfg.native.context_parallel_mode = layout.pop("_cp_mode", "ulysses")
+    cfg.native.zero_stage = layout.pop("_zero", 1)
+    eng = NativeTrainEngine(cfg)
+    eng.create_process_group(ParallelStrategy(**layout))
+    assert world == 1 or (host_staged.installed() and eng.device.type == "cuda")
+    eng.initialize(None, FinetuneSpec(1, 64, 8))
+    if ckpt_in is None:
+        eng.save(SaveLoadMeta(path=out_path, weight_format="hf", with_optim=False))
+        eng.destroy()
+        return
+    batch = _batch(eng.model_config.vocab_size, _LAYOUT_LENS, seed=21)
+    dp, dpr = eng.data_parallel_world_size, eng.data_parallel_rank
+    per = len(_LAYOUT_LENS) // dp
+    local = {k: v[dpr * per:(dpr + 1) * per] for k, v in batch.items()}
+    norms = []
+    for _ in range(2):
+        st = eng.train_batch(local, _sft_loss, _weight)
+        assert st["update_successful"] == 1.0
+        norms.append(st["grad_norm"])
+    ev = float(eng.eval_batch(local, _sft_loss, _weight))
+    fw = eng.forward(local, post_hook=_logp_hook).float().cpu()
+    if dp > 1 and eng.grid.pp == 1 and eng.zero3 is None and eng.expert_optimizer is None:
+        assert eng.optimizer.overlapped_buckets >= len(eng.optimizer.buckets)  # the bucketed reduce ran on the device
+    torch.save(dict(norms=norms, ev=ev, fw=fw, dpr=dpr), f"{out_path}.r{rank}")
+    eng.destroy()
+
+
+def _run_layout(world, layout, seq_par, ckpt_in, out_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_layout_worker, args=(r, world, port, layout, seq_par, ckpt_in, out_path))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(200)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive and all(p.exitcode == 0 for p in procs), (layout, [p.exitcode for p in procs])
+
+
+def test_two_rank_layouts_on_one_gpu_follow_the_single_process(tmp_path):
+    """Data- (ZeRO-1 and ZeRO-3), tensor- (vocab-parallel loss, with and without sequence parallelism), pipeline- and
+    context-parallel (Ulysses, zig-zag) trainers as TWO processes sharing this GPU - real HIP kernels on every rank's shard, collectives of a host-backend group
+    staged through host memory (RCCL cannot put two ranks on one device) - take the same two optimizer steps as the
+    single process, within bf16 noise."""
+    init = str(tmp_path / "init")
+    _run_layout(1, dict(), False, None, init)
+    ref_path = str(tmp_path / "ref")
+    _run_layout(1, dict(), False, init, ref_path)
+    ref = torch.load(ref_path + ".r0", weights_only=True)
+    for name, layout, sp in [("dp2", dict(data_parallel_size=2), False), ("tp2", dict(tensor_parallel_size=2), False),
+                             ("tp2sp", dict(tensor_parallel_size=2), True), ("pp2", dict(pipeline_parallel_size=2), False),
+                             ("cp2-ulysses", dict(context_parallel_size=2), False),
+                             ("cp2-zigzag", dict(context_parallel_size=2, _cp_mode="zigzag"), False),
+                             ("dp2-zero3", dict(data_parallel_size=2, _zero=3), False)]:
+        out = str(tmp_path / name)
+        _run_layout(2, layout, sp, init, out)
+        parts = [torch.load(f"{out}.r{r}", weights_only=True) for r in range(2)]
+        dp = layout.get("data_parallel_size", 1)
+        assert parts[0]["norms"] == pytest.approx(ref["norms"], rel=4e-2), (name, parts[0]["norms"], ref["norms"])
+        if dp == 1:
+            fw = parts[0]["fw"]
+            assert parts[0]["ev"] == pytest.approx(ref["ev"], abs=3e-2), name
+        else:
+            fw = torch.cat([p["fw"] for p in sorted(parts, key=lambda p: p["dpr"])])
+        S = min(fw.shape[1], ref["fw"].shape[1])
+        # position t scores token t + 1: the last position of a sequence scores whatever follows it in the pack
+        valid = torch.zeros(len(_LAYOUT_LENS), S, dtype=torch.bool)
+        for i, n in enumerate(_LAYOUT_LENS):
+            valid[i, :n - 1] = True
+        diff = (fw[:, :S] - ref["fw"][:, :S]).abs()[valid]
+        assert float(diff.mean()) < 0.03 and float(diff.max()) < 0.5, (name, float(diff.mean()), float(diff.max()))
+
+
+def test_expert_parallel_layout_on_one_gpu_follows_the_single_process(tmp_path):
+    """Mixture-of-experts trainer with the experts split over two expert-parallel ranks (two processes on this GPU:
+    grouped GEMM kernels on each rank's experts, token exchange through the staged all-to-all) against the single
+    process holding all experts."""
+    init = str(tmp_path / "init")
+    _run_layout(1, dict(_model="tiny-moe"), False, None, init)
+    ref_path = str(tmp_path / "ref")
+    _run_layout(1, dict(_model="tiny-moe"), False, init, ref_path)
+    ref = torch.load(ref_path + ".r0", weights_only=True)
+    out = str(tmp_path / "ep2")
+    _run_layout(2, dict(_model="tiny-moe", data_parallel_size=2, expert_parallel_size=2), False, init, out)
+    parts = sorted((torch.load(f"{out}.r{r}", weights_only=True) for r in range(2)), key=lambda p: p["dpr"])
+    assert parts[0]["norms"] == pytest.approx(ref["norms"], rel=5e-2), (parts[0]["norms"], ref["norms"])
+    fw = torch.cat([p["fw"] for p in parts])
+    S = min(fw.shape[1], ref["fw"].shape[1])
+    valid = torch.zeros(len(_LAYOUT_LENS), S, dtype=torch.bool)
+    for i, n in enumerate(_LAYOUT_LENS):
+        valid[i, :n - 1] = True
+    diff = (fw[:, :S] - ref["fw"][:, :S]).abs()[valid]
+    assert float(diff.mean()) < 0.03 and float(diff.max()) < 0.5, (float(diff.mean()), float(diff.max()))
+
