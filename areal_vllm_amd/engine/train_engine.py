@@ -255,12 +255,16 @@ class NativeTrainEngine(TrainEngine):
         if int(cfg.native.zero_stage) == 3 or cfg.fsdp.offload_params:
             from ..parallel.zero3 import Zero3
 
-            assert g.tp == 1 and g.pp == 1 and g.ep == 1 and self.model.flat_experts is None, \
-                "zero_stage 3 shards over data / context parallel ranks; combine tensor or pipeline parallelism " \
-                "with zero_stage 1"
+            assert g.pp == 1 and g.ep == 1 and self.model.flat_experts is None, \
+                "zero_stage 3 shards over data / context parallel ranks (of every tensor-parallel rank); combine " \
+                "pipeline or expert parallelism with zero_stage 1"
+            rep = self._spans_by_name(self._tp_replicated_ranges()) if g.tp > 1 else []
+            partial = self._spans_by_name(self._partial_grad_ranges() + (
+                self._kv_ranges() if self._kv_replication() > 1 else [])) if g.tp > 1 else []
             self.zero3 = Zero3(self.model, self.optimizer_config if with_optim else None, group=g.group("dp_cp"),
                                reshard_after_forward=cfg.native.reshard_after_forward,
-                               offload_optimizer=cfg.native.offload_optimizer or cfg.fsdp.offload_params)
+                               offload_optimizer=cfg.native.offload_optimizer or cfg.fsdp.offload_params,
+                               tp_group=g.group("tp"), tp_replicated=rep, tp_partial_grads=partial)
             if with_optim:
                 self.optimizer = self.zero3
                 self._total_steps = max(1, ft_spec.total_train_steps if ft_spec is not None else 1)
@@ -281,6 +285,22 @@ class NativeTrainEngine(TrainEngine):
         self.initialized = True
         logger.info(f"model {mc.family} ({flat.numel / 1e6:.1f}M params on this rank) ready in "
                     f"{time.perf_counter() - tik:.2f}s")
+
+    def _spans_by_name(self, ranges: List[Tuple[int, int, int]]) -> List[Tuple[str, int, int, int]]:
+        """Ranges of the flat parameter buffer as (parameter name, first element, end element, value)."""
+        out = []
+        for a, b, v in ranges:
+            for n, (o, numel) in self.model.flat.offsets.items():
+                if o <= a and b <= o + numel:
+                    out.append((n, a - o, b - o, v))
+                    break
+            else:
+                raise AssertionError(f"flat range [{a}, {b}) spans more than one parameter")
+        return out
+
+    def _zero3_tp_tag(self) -> str:
+        g = self.grid
+        return f"-tp{g.coord.tp}of{g.tp}" if g.tp > 1 else ""
 
     def _kv_replication(self) -> int:
         return max(1, self.grid.tp // self.model_config.n_kv_heads)
@@ -543,7 +563,8 @@ class NativeTrainEngine(TrainEngine):
     def optimizer_step(self) -> Dict[str, float]:
         """Reduce gradients, clip by the global norm (dense + expert parameters), AdamW, re-gather params."""
         lr = self.current_lr()
-        self._sync_replicated_kv_grads()
+        if self.zero3 is None:  # ZeRO-3 sums the partial gradients on its shards, inside its step
+            self._sync_replicated_kv_grads()
         if self.expert_optimizer is None:
             self.optimizer.step(lr=lr)
         else:
@@ -692,8 +713,8 @@ class NativeTrainEngine(TrainEngine):
         if self.zero3 is not None:  # every data-parallel rank owns a different slice of every parameter
             z = self.zero3
             save_file({"param_shard": z.param_shard.detach().cpu()},
-                      os.path.join(meta.path, f"zero3-shard-{z.rank}-of-{z.n}.safetensors"))
-            if z.rank == 0:
+                      os.path.join(meta.path, f"zero3-shard-{z.rank}-of-{z.n}{self._zero3_tp_tag()}.safetensors"))
+            if z.rank == 0 and g.coord.tp == 0:
                 with open(os.path.join(meta.path, "config.json"), "w") as f:
                     json.dump(self.model_config.to_hf_dict(), f, indent=2)
             if meta.with_optim and self.optimizer is not None:
@@ -739,7 +760,7 @@ class NativeTrainEngine(TrainEngine):
         g = self.grid
         if self.zero3 is not None:
             z = self.zero3
-            fn = os.path.join(meta.path, f"zero3-shard-{z.rank}-of-{z.n}.safetensors")
+            fn = os.path.join(meta.path, f"zero3-shard-{z.rank}-of-{z.n}{self._zero3_tp_tag()}.safetensors")
             if not os.path.exists(fn):
                 raise FileNotFoundError(f"{fn}: a ZeRO-3 sharded checkpoint is read back by the same number of "
                                         "data-parallel ranks (convert through the hf format otherwise)")

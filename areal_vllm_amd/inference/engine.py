@@ -749,14 +749,73 @@ class NativeInferenceEngine:
         }
 
 
+def _assign_gpt2_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor], strict: bool):
+    """GPT-2 checkpoint names (`models/hf_io.py::_gpt2_state` writes them): linears are stored [in, out], q|k|v
+    fused along the output axis of `c_attn`; any subset of the model's tensors may arrive in one call."""
+    import re
+
+    cfg = model.cfg
+    D, H = cfg.head_dim, cfg.hidden_size
+    tp, tr = model.tp_size, model.tp_rank
+    params = dict(model.named_parameters())
+    local = {g: li for li, g in enumerate(model.layer_ids)}
+    v_lo, v_hi = model.vocab_range
+    plain = {"ln_1.weight": "ln1", "ln_1.bias": "ln1_bias", "ln_2.weight": "ln2", "ln_2.bias": "ln2_bias",
+             "attn.c_proj.bias": "attn.o_bias", "mlp.c_proj.bias": "mlp.proj_bias"}
+    left = []
+    for name, t in tensors.items():
+        n = name[len("transformer."):] if name.startswith("transformer.") else name
+        m = re.match(r"h\.(\d+)\.(.+)$", n)
+        if m:
+            if int(m.group(1)) not in local:  # another pipeline stage's layer
+                continue
+            pre, key = f"layers.{local[int(m.group(1))]}.", m.group(2)
+            blk = model.layers[local[int(m.group(1))]]
+            q = blk.attn.hq * D
+            if key in plain:
+                params[pre + plain[key]].data.copy_(t)
+            elif key == "attn.c_attn.weight":
+                params[pre + "attn.qkv"].data.copy_(torch.cat([t[:, o + tr * q:o + (tr + 1) * q] for o in (0, H, 2 * H)], 1).t())
+            elif key == "attn.c_attn.bias":
+                params[pre + "attn.qkv_bias"].data.copy_(torch.cat([t[o + tr * q:o + (tr + 1) * q] for o in (0, H, 2 * H)], 0))
+            elif key == "attn.c_proj.weight":
+                params[pre + "attn.o"].data.copy_(t[tr * q:(tr + 1) * q].t())
+            elif key == "mlp.c_fc.weight":
+                f = params[pre + "mlp.fc"].shape[0]
+                params[pre + "mlp.fc"].data.copy_(t[:, tr * f:(tr + 1) * f].t())
+            elif key == "mlp.c_fc.bias":
+                f = params[pre + "mlp.fc_bias"].shape[0]
+                params[pre + "mlp.fc_bias"].data.copy_(t[tr * f:(tr + 1) * f])
+            elif key == "mlp.c_proj.weight":
+                f = params[pre + "mlp.proj"].shape[1]
+                params[pre + "mlp.proj"].data.copy_(t[tr * f:(tr + 1) * f].t())
+            else:
+                left.append(name)
+        elif n == "wte.weight":
+            if model.has_embed:
+                params["embed"].data.copy_(t[v_lo:v_hi])
+        elif n == "wpe.weight":
+            if model.has_embed:
+                params["pos_embed"].data.copy_(t)
+        elif n in ("ln_f.weight", "ln_f.bias"):
+            if model.has_head:
+                params["norm" if n.endswith("weight") else "norm_bias"].data.copy_(t)
+        elif n in ("lm_head.weight", "score.weight"):
+            if model.has_head and "head" in params:
+                params["head"].data.copy_(t if n == "score.weight" else t[v_lo:v_hi])
+        else:
+            left.append(name)
+    if strict and left:
+        raise KeyError(f"{len(left)} received tensor(s) map onto no parameter of this model: {sorted(left)[:8]}")
+
+
 def assign_hf_named_tensors(model: Transformer, tensors: Dict[str, torch.Tensor], strict: bool = True):
     """Copy HF-named FULL tensors into the (possibly tensor-parallel) native parameters. With `strict`, a
     tensor whose name maps onto no parameter of this model raises instead of being dropped (a silent drop
     leaves that part of the rollout model on stale weights)."""
     cfg = model.cfg
     if cfg.family == "gpt2":
-        raise NotImplementedError("named weight updates are implemented for the RMSNorm / rotary / gated-MLP "
-                                  "families; GPT-2 is a training-side family (use the hf checkpoint path)")
+        return _assign_gpt2_named_tensors(model, tensors, strict)
     D = cfg.head_dim
     tp, tr = model.tp_size, model.tp_rank
     params = dict(model.named_parameters())

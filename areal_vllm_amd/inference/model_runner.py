@@ -55,15 +55,20 @@ class ModelRunner:
         if not self.buckets or self.buckets[-1] < max_batch:
             self.buckets.append(max_batch)
         cfg = self.cfg
-        if cfg.norm_type != "rms" or cfg.pos_embed != "rope" or not cfg.mlp_gated or cfg.linear_bias:
-            raise NotImplementedError(
-                f"the rollout engine serves the RMSNorm / rotary / gated-MLP families; {cfg.family} is a "
-                "training-side family (train engine, checkpoint conversion)")
         self.hq = model.layers[0].attn.hq
         self.hkv = model.layers[0].attn.hkv
         self.kv = [ops.alloc_kv_cache(num_pages, self.hkv, cfg.head_dim, self.dtype, self.device)
                    for _ in model.layers]
-        self.rope = model.rope(self.device)
+        if cfg.pos_embed == "rope":
+            self.rope = model.rope(self.device)
+        else:
+            # learned absolute positions (GPT-2) are added to the embeddings; q and k go into attention and the
+            # cache unrotated: the rotate-and-write kernels run on a table of angle zero
+            self.rope = ops.RotaryTable(cfg.head_dim, 1, device=self.device)
+            self.rope.cos.fill_(1.0)
+            self.rope.sin.zero_()
+        # LayerNorm with bias, projections with bias, the MLP without a gate (GPT-2): the unfused layer body
+        self.plain_family = cfg.norm_type != "rms" or not cfg.mlp_gated or cfg.linear_bias or cfg.pos_embed != "rope"
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._gloo_group = None  # lazily: is the tp group a host backend (one-GPU rehearsal)
         self.ipc_ar = None  # peer-memory all-reduce of the tp group (ops/ipc_allreduce.py), set by the engine
@@ -81,7 +86,8 @@ class ModelRunner:
         self.mm: Dict[int, Dict[str, Any]] = {}
         # Decode batches of FUSED_MIN_BATCH rows and more run the layer as seven launches (ops/decode_gemm.py);
         # smaller ones, and model variants its epilogues do not cover, take the library GEMMs.
-        fusable = (cfg.n_experts == 0 and not cfg.qk_norm and cfg.hidden_act == "silu" and model.tp_size == 1
+        fusable = (not self.plain_family and cfg.n_experts == 0 and not cfg.qk_norm and cfg.hidden_act == "silu"
+                   and model.tp_size == 1
                    and cfg.hidden_size % 64 == 0 and cfg.intermediate_size % 64 == 0 and cfg.head_dim % 16 == 0)
         if fused_decode is None:
             fused_decode = self.device.type == "cuda" and os.environ.get("AREAL_FUSED_DECODE", "1") != "0"
@@ -157,6 +163,8 @@ class ModelRunner:
     # ------------------------------------------------------------------------ model pieces
     def _layer(self, blk, h, residual, positions, slots, attn_fn):
         cfg = self.cfg
+        if self.plain_family:
+            return self._layer_plain(blk, h, residual, attn_fn)
         x, residual = ops.rmsnorm(h, blk.ln1, cfg.rms_norm_eps, residual, cfg.gemma_norm)
         qkv = blk.attn.project_qkv(x)
         attn = attn_fn(blk, qkv)
@@ -170,6 +178,36 @@ class ModelRunner:
             h = F.linear(ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act), blk.mlp.down)
         if self.model.tp_size > 1:
             self._tp_all_reduce(h)
+        return h, residual
+
+    def _layer_plain(self, blk, h, residual, attn_fn):
+        """The layer of the families outside the fused kernels' reach (GPT-2: LayerNorm with bias, biases on the
+        output projections, fc -> activation -> proj): the trainer's own norm helper and library GEMMs. Biases of the
+        row-parallel projections are added once, after the reduction."""
+        from ..models.transformer import add_norm
+
+        cfg = self.cfg
+        tp = self.model.tp_size > 1
+        x, residual = add_norm(cfg, h, blk.ln1, getattr(blk, "ln1_bias", None), residual)
+        attn = attn_fn(blk, blk.attn.project_qkv(x))
+        h = F.linear(attn.reshape(attn.shape[0], -1), blk.attn.o)
+        if tp:
+            self._tp_all_reduce(h)
+        if cfg.linear_bias:
+            h = h + blk.attn.o_bias
+        x, residual = add_norm(cfg, h, blk.ln2, getattr(blk, "ln2_bias", None), residual)
+        if cfg.n_experts > 0:
+            h = blk.mlp(x, None, self.model.ep_group)
+        elif cfg.mlp_gated:
+            h = F.linear(ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act), blk.mlp.down)
+        else:
+            a = F.linear(x, blk.mlp.fc, blk.mlp.fc_bias)
+            a = F.gelu(a, approximate="tanh") if blk.mlp.act == "gelu_tanh" else F.silu(a)
+            h = F.linear(a, blk.mlp.proj)
+        if tp:
+            self._tp_all_reduce(h)
+        if not cfg.mlp_gated and cfg.n_experts == 0:
+            h = h + blk.mlp.proj_bias
         return h, residual
 
     def _tp_all_reduce(self, h: torch.Tensor):
@@ -216,7 +254,12 @@ class ModelRunner:
 
     def _final_logits(self, h, residual) -> torch.Tensor:
         cfg = self.cfg
-        x, _ = ops.rmsnorm(h, self.model.norm, cfg.rms_norm_eps, residual, cfg.gemma_norm)
+        if cfg.norm_type != "rms":
+            from ..models.transformer import add_norm
+
+            x, _ = add_norm(cfg, h, self.model.norm, getattr(self.model, "norm_bias", None), residual)
+        else:
+            x, _ = ops.rmsnorm(h, self.model.norm, cfg.rms_norm_eps, residual, cfg.gemma_norm)
         return F.linear(x, self.model.head_weight)
 
     # ----------------------------------------------------------------------------- prefill
@@ -242,7 +285,9 @@ class ModelRunner:
             rope = self.model.mrope(pos3)  # per-token table, addressed by the token's index in the plan
             pos = torch.arange(T, dtype=torch.int32, device=dev)
         else:
-            h = self.model.embed_tokens(ids)
+            h = self.model.embed_tokens(ids, pos)
+        if self.cfg.pos_embed != "rope":
+            pos = torch.zeros_like(pos)  # the only row of the angle-zero table
         residual = None
         for li, blk in enumerate(self.model.layers):
             kc, vc = self.kv[li]
@@ -314,6 +359,7 @@ class ModelRunner:
             top_k=torch.full((Bp,), self.V, dtype=torch.int32, device=dev),
             rope_delta=torch.zeros(Bp, dtype=torch.int32, device=dev),
             rope_pos=torch.zeros(Bp, dtype=torch.int32, device=dev),
+            zero_pos=torch.zeros(Bp, dtype=torch.int32, device=dev),
             out_tokens=torch.zeros(k, Bp, dtype=torch.int64, device=dev),
             out_logprobs=torch.zeros(k, Bp, dtype=torch.float32, device=dev),
             active=torch.zeros(Bp, dtype=torch.int32, device=dev),
@@ -448,9 +494,9 @@ class ModelRunner:
         ops.decode_begin_(st["kill"], st["active"], st["positions"], st["context_lens"], st["slots"],
                           st["block_tables"])
         for s in range(self.decode_steps):
-            h = self.model.embed_tokens(st["input_ids"])
+            h = self.model.embed_tokens(st["input_ids"], st["positions"])
             residual = None
-            rope_pos = st["positions"]
+            rope_pos = st["positions"] if self.cfg.pos_embed == "rope" else st["zero_pos"]
             if self.is_vl:  # generated tokens of a request with images sit `delta` away from their index
                 torch.add(st["positions"], st["rope_delta"], out=st["rope_pos"])
                 rope_pos = st["rope_pos"]

@@ -1,4 +1,5 @@
-"""ZeRO-3: parameters, gradients and optimizer state all sharded over the data-parallel group.
+"""ZeRO-3: parameters, gradients and optimizer state all sharded over the data-parallel group (of every tensor-parallel
+rank, when the model is also split over tp).
 
 The default on MI355X is ZeRO-1 (``parallel/zero.py``): 288 GB of HBM hold replicated bf16 weights and fp32
 gradient accumulators of everything up to ~30B parameters, and a step costs two large collectives. This module
@@ -52,10 +53,18 @@ class _Unit:
 
 class Zero3:
     def __init__(self, model, cfg: Optional[OptimizerConfig], group=None, reshard_after_forward: bool = True,
-                 offload_optimizer: bool = False, offload_slab: int = 1 << 26):
+                 offload_optimizer: bool = False, offload_slab: int = 1 << 26, tp_group=None,
+                 tp_replicated: Optional[List[Tuple[str, int, int, int]]] = None,
+                 tp_partial_grads: Optional[List[Tuple[str, int, int, int]]] = None):
+        """`group`: the ranks that shard this rank's parameters (data x context parallel). With tensor parallelism
+        every tp rank shards ITS slice of the model over its own `group`; `tp_group` joins the ranks whose slices
+        differ. `tp_replicated`: (parameter, first element, end element, rep) - element ranges that `rep`
+        neighbouring tp ranks hold alike (they count once in the gradient norm); `tp_partial_grads`: those of them
+        whose gradient on one rank is only a partial sum, to be summed inside every set of `rep` neighbours."""
         self.model = model
         self.cfg = cfg
         self.group = group
+        self.tp_group = tp_group if comm.group_size(tp_group) > 1 else None
         self.n = comm.group_size(group)
         self.rank = comm.group_rank(group)
         self.reshard_after_forward = reshard_after_forward
@@ -127,6 +136,11 @@ class Zero3:
             self.m = torch.zeros(self.shard_numel, dtype=torch.float32, **host)
             self.v = torch.zeros(self.shard_numel, dtype=torch.float32, **host)
 
+        # ---- tensor parallelism: where the replicated / partially summed parameters sit in this rank's shard
+        self.tp_rank = comm.group_rank(self.tp_group)
+        self._rep_ranges = self._shard_ranges(tp_replicated or []) if self.tp_group is not None else []
+        self._partial_ranges = self._shard_ranges(tp_partial_grads or []) if self.tp_group is not None else []
+
         # ---- hooks
         for i, blk in enumerate(model.layers):
             blk.register_forward_pre_hook(lambda _m, _a, i=i: self._pre_forward(i))
@@ -136,6 +150,23 @@ class Zero3:
             for _name, p, _off in u.params:
                 if p.requires_grad and cfg is not None:
                     p.register_post_accumulate_grad_hook(self._grad_ready)
+
+    def _shard_ranges(self, spans: List[Tuple[str, int, int, int]]) -> List[Tuple[int, int, int]]:
+        """(lo, hi, rep) ranges of the rank's flat shard buffers that hold the given element spans of parameters.
+        The layout is the same on every tp rank (same shapes), so equal ranges of tp peers hold the same elements."""
+        by_name: Dict[str, List[Tuple[int, int, int]]] = {}
+        for name, a, b, rep in spans:
+            by_name.setdefault(name, []).append((a, b, rep))
+        out = []
+        for u in self.units:
+            per = u.numel // self.n
+            s0 = self.rank * per
+            for name, p, off in u.params:
+                for pa, pb, rep in by_name.get(name, ()):
+                    a, b = max(off + pa, s0), min(off + pb, s0 + per)
+                    if a < b:
+                        out.append((u.shard_off + a - s0, u.shard_off + b - s0, rep))
+        return out
 
     # ---------------------------------------------------------------------------- storage
     def _shard_view(self, u: _Unit) -> torch.Tensor:
@@ -279,9 +310,27 @@ class Zero3:
         cfg = self.cfg
         lr = self.lr if lr is None else lr
         self._wait_reductions()
+        if self._partial_ranges:  # e.g. norm weights under sequence parallelism: every tp rank saw its own tokens
+            tp = comm.group_size(self.tp_group)
+            for rep in sorted({r for _, _, r in self._partial_ranges}):
+                sel = [(a, b) for a, b, r in self._partial_ranges if r == rep]
+                packed = torch.cat([self.grad_shard[a:b] for a, b in sel])
+                if rep == tp:
+                    comm.all_reduce_sum(packed, self.tp_group)
+                else:  # K/V projections shared by `rep` neighbouring ranks (more tp ranks than KV heads)
+                    s0 = self.tp_rank // rep * rep
+                    packed = comm.all_gather_cat(packed.unsqueeze(0), self.tp_group)[s0:s0 + rep].sum(0)
+                o = 0
+                for a, b in sel:
+                    self.grad_shard[a:b].copy_(packed[o:o + b - a])
+                    o += b - a
         self._norm_buf.zero_()
         ops.sumsq_(self.grad_shard, self._norm_buf)
+        for a, b, rep in self._rep_ranges:  # held by `rep` tp ranks: count once over the tp group
+            self._norm_buf.sub_(self.grad_shard[a:b].pow(2).sum() * (1.0 - 1.0 / rep))
         comm.all_reduce_sum(self._norm_buf, self.group)
+        if self.tp_group is not None:
+            comm.all_reduce_sum(self._norm_buf, self.tp_group)
         self.state[0:1].copy_(self._norm_buf)
         ops.adam_prepare_(self.state, float(cfg.gradient_clipping or 0.0), grad_prescale, cfg.beta1, cfg.beta2)
         bf16 = self.param_shard.dtype == torch.bfloat16

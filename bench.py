@@ -80,7 +80,9 @@ def parse_args():
                    help="decoupled mode: how the rollout servers get new weights (ipc falls back to disk if the "
                         "peer mapping cannot be opened)")
     p.add_argument("--share-gpu", action="store_true",
-                   help="decoupled rehearsal on a single GPU: every rank uses device 0 (not a benchmark of N GPUs)")
+                   help="rehearsal on a single GPU: every rank uses device 0 (not a benchmark of N GPUs). With more than one "
+                        "trainer rank the collectives are staged through host memory, and the processes time-slice "
+                        "the card, so expect minutes per step at the headline config - pair it with --model small")
     a = p.parse_args()
     if a.seq_len:
         a.max_new_tokens = a.seq_len - a.prompt_len_max
@@ -194,6 +196,11 @@ def main():
     if args.share_gpu:
         local_rank = 0
         os.environ["LOCAL_RANK"] = "0"
+        n_train = world // 2 if decoupled else world
+        if n_train > 1:
+            # several trainer ranks on ONE device: RCCL cannot host them, the collectives go through the host
+            # backend with staged copies (a rehearsal of the control flow and the kernels, not of the transport)
+            os.environ["AREAL_HOST_STAGED_COLLECTIVES"] = "1"
     if on_gpu:
         assert torch.cuda.is_available(), "bench.py needs an MI355X"
         if not args.share_gpu:

@@ -373,6 +373,40 @@ def test_gemma_family_rolls_out_with_head_size_256():
         actor.destroy()
 
 
+def test_gpt2_family_rolls_out_on_gpu():
+    """GPT-2 (LayerNorm with bias, learned positions, head size 64, ungated MLP with biases) through the rollout
+    engine under graph replay: unrotated q / k through the rotate-and-write kernels on an angle-zero table, paged
+    decode attention at D = 64."""
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters
+    from areal_vllm_amd.workflow.rlvr import RLVRWorkflow
+
+    actor, eng, ro, meta, dev = _rollout_pair(model="tiny-gpt2", decode_steps=4, pages=256)
+    try:
+        assert actor.model_config.family == "gpt2" and not eng.runner.fused_decode
+        torch.manual_seed(0)
+        with torch.no_grad():
+            actor.model.flat.flat.normal_(0, 0.05)
+        actor.upload_weights(meta)
+        g = GenerationHyperparameters(n_samples=2, max_new_tokens=64, temperature=1.0, stop_token_ids=[1])
+        wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: 0.0, g, reward_in_process=True)
+        gen = torch.Generator().manual_seed(5)
+        prompts = [dict(input_ids=torch.randint(2, 500, (n,), generator=gen).tolist()) for n in (7, 40, 33, 90)]
+        batch = ro.rollout_batch(prompts, workflow=wf)
+        batch = {k: v.to(dev) if torch.is_tensor(v) else v for k, v in batch.items()}
+        lm = batch["loss_mask"].bool()
+        assert int(lm.sum()) > 8 * 20
+        prox = actor.compute_logp(batch)
+        behav = torch.roll(batch["logprobs"], -1, 1)
+        m = torch.roll(lm, -1, 1)
+        m[:, -1] = False
+        diff = (prox.float() - behav.float()).abs()[m]
+        assert float(diff.mean()) < 0.03 and float(diff.max()) < 0.3, (float(diff.mean()), float(diff.max()))
+    finally:
+        ro.destroy()
+        eng.destroy()
+        actor.destroy()
+
+
 def test_weight_update_interrupts_running_generation():
     """Requests in flight when new weights arrive are aborted, re-issued by the client with their partial
     output, and finish with tokens tagged by both weight versions."""

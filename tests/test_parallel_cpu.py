@@ -301,10 +301,14 @@ def test_interleaved_pipeline_stages_match_single_process():
     ("z3dp2offload", 2, dict(data_parallel_size=2, _zero3=dict(offload=True, ckpt=True)), 2),
     ("z3cp2", 2, dict(context_parallel_size=2, _zero3={}), 2),
     ("z3dp1", 1, dict(_zero3={}), 2),
+    ("z3tp2", 2, dict(tensor_parallel_size=2, _zero3={}), 2),
+    ("z3tp2sp", 2, dict(tensor_parallel_size=2, _seq_par=True, _zero3=dict(ckpt=True)), 2),
+    ("z3dp2tp2", 4, dict(data_parallel_size=2, tensor_parallel_size=2, _zero3={}), 1),
 ])
 def test_zero3_matches_single_process(dense_reference, name, world, kw, n_mbs):
     """ZeRO-3 (weights, gradients, optimizer state sharded; blocks gathered on demand, with and without
-    re-sharding after the forward, gradient checkpointing, host-resident optimizer state) takes the same two
+    re-sharding after the forward, gradient checkpointing, host-resident optimizer state; alone and under tensor
+    parallelism, where every tp rank shards its slice over its own data-parallel group) takes the same two
     optimizer steps as the single-process ZeRO-1 run; eval / forward / hf save / sharded save + load work from
     the sharded state."""
     d, init, ref = dense_reference
