@@ -49,6 +49,10 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--target-wgs", type=int, default=0, help="override the split-KV workgroup target (experiment)")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="also time every batch split over this many runners (own KV cache, graphs and stream each, "
+                         "shared weights) replaying concurrently: do the dependent-kernel gaps of one lane hide "
+                         "behind the other lane's kernels?")
     args = ap.parse_args()
     if args.target_wgs:
         from areal_vllm_amd.ops import attention as _att
@@ -101,6 +105,51 @@ def main():
         print(f"B={B:4d} ctx={args.ctx}: {dp * 1e3:7.3f} ms/step  {B / dp:9.0f} tok/s  "
               f"({dp * 1e6 / cfg.n_layers:6.1f} us/layer incl. head+sampler)  [pipelined]  "
               f"host gap removed: {(dt - dp) * args.steps * 1e3:6.3f} ms per {args.steps}-step plan", flush=True)
+    if args.lanes > 1:
+        del runner
+        torch.cuda.empty_cache()
+        probe_lanes(args, model, cfg, batches, pages_per_seq, grow)
+
+
+def probe_lanes(args, model, cfg, batches, pages_per_seq, grow):
+    dev = next(model.parameters()).device
+    L = args.lanes
+    for B in batches:
+        Bh = B // L
+        runners = [ModelRunner(model, Bh * pages_per_seq + 8, args.ctx + grow + 64, Bh, decode_steps=args.steps,
+                               use_graph=True, buckets=[Bh]) for _ in range(L)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(L)]
+        for r in runners:
+            for kc, vc in r.kv:
+                kc.normal_(0, 0.5)
+                vc.normal_(0, 0.5)
+        plan0 = make_plan(Bh, args.ctx, args.steps, runners[0].max_pages, cfg.vocab_size, pages_per_seq=pages_per_seq)
+        cont = dict(req_ids=plan0["req_ids"], n_steps=args.steps, continuation=True, max_pages=pages_per_seq,
+                    block_tables=plan0["block_tables"], kill=np.zeros(Bh, np.int32))
+        for r, st in zip(runners, streams):
+            with torch.cuda.stream(st):
+                r.decode(plan0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cur = []
+        for r, st in zip(runners, streams):
+            with torch.cuda.stream(st):
+                cur.append(r.decode_launch(plan0))
+        for i in range(1, args.iters):
+            for k, (r, st) in enumerate(zip(runners, streams)):
+                with torch.cuda.stream(st):
+                    nxt = r.decode_launch(cont)
+                    r.decode_wait(cur[k])
+                    cur[k] = nxt
+        for k, (r, st) in enumerate(zip(runners, streams)):
+            with torch.cuda.stream(st):
+                r.decode_wait(cur[k])
+        torch.cuda.synchronize()
+        dp = (time.perf_counter() - t0) / (args.iters * args.steps)
+        print(f"B={B:4d} as {L} lanes of {Bh} ctx={args.ctx}: {dp * 1e3:7.3f} ms per step of all lanes  "
+              f"{Bh * L / dp:9.0f} tok/s  [pipelined, concurrent lanes]", flush=True)
+        del runners
+        torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":
