@@ -788,10 +788,8 @@ class NativeTrainEngine(TrainEngine):
             if self.model.flat_experts is not None:
                 raise NotImplementedError("resharding a mixture-of-experts checkpoint across tp / pp layouts: "
                                           "convert through the hf format")
-            if g.vpp > 1 or int(lay.get("vpp", 1)) > 1:
-                raise NotImplementedError("resharding a checkpoint written or read with interleaved pipeline stages: "
-                                          "convert through the hf format")
-            src, dst = Layout(1, int(lay["tp"]), int(lay["pp"])), Layout(1, g.tp, g.pp)
+            src = Layout(1, int(lay["tp"]), int(lay["pp"]), vpp=int(lay.get("vpp", 1)))
+            dst = Layout(1, g.tp, g.pp, vpp=g.vpp)
             me = dst.index_of(g.coord.pp, 0, g.coord.tp)
             host = torch.zeros(flat.numel(), dtype=flat.dtype)
             filled = 0
@@ -805,7 +803,8 @@ class NativeTrainEngine(TrainEngine):
             used = sum(k for _, k in self.model.flat.offsets.values())
             assert filled == used, f"resharding load covered {filled} of {used} parameter elements"
             flat.copy_(host)
-            logger.info(f"resharded checkpoint load: tp{src.tp} pp{src.pp} -> tp{dst.tp} pp{dst.pp}")
+            logger.info(f"resharded checkpoint load: tp{src.tp} pp{src.pp} vpp{src.vpp} -> tp{dst.tp} pp{dst.pp} "
+                        f"vpp{dst.vpp}")
         if self.model.flat_experts is not None:
             if int(lay.get("ep", 1)) != g.ep:
                 raise ValueError(f"sharded checkpoint holds ep{lay.get('ep', 1)} expert shards, this engine is ep{g.ep}; "

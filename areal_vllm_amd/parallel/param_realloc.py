@@ -40,6 +40,7 @@ class Layout:
     tp: int = 1
     pp: int = 1
     vocab_parallel: bool = True  # embedding / LM head rows split over tp (the trainer's layout under tp > 1)
+    vpp: int = 1  # interleaved pipeline: every pp rank hosts `vpp` slices of the layers (virtual stages)
 
     @property
     def world(self) -> int:
@@ -51,9 +52,13 @@ class Layout:
 
 
 def _meta_shard(cfg: ModelConfig, lay: Layout, tp_rank: int, pp_rank: int, dtype=torch.bfloat16) -> Transformer:
-    lr = stage_layer_range(cfg.n_layers, lay.pp, pp_rank)
+    lr, chunks = stage_layer_range(cfg.n_layers, lay.pp, pp_rank), None
+    if lay.vpp > 1:  # virtual stage c of rank p is slice c * pp + p of pp * vpp slices
+        lr, chunks = None, [stage_layer_range(cfg.n_layers, lay.pp * lay.vpp, c * lay.pp + pp_rank)
+                            for c in range(lay.vpp)]
     m = Transformer(cfg, dtype=dtype, device="meta", tp_size=lay.tp, tp_rank=tp_rank, layer_range=lr,
-                    has_embed=pp_rank == 0, has_head=pp_rank == lay.pp - 1, vocab_parallel=lay.vocab_parallel)
+                    layer_chunks=chunks, has_embed=pp_rank == 0, has_head=pp_rank == lay.pp - 1,
+                    vocab_parallel=lay.vocab_parallel)
     m.flatten()
     return m
 

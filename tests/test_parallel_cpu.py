@@ -277,7 +277,7 @@ def test_interleaved_pipeline_stages_match_single_process():
     """Virtual pipeline stages (two layer chunks per rank, five layers over four virtual stages): the interleaved
     1F1B schedule, its all-forward-all-backward form for a micro-batch count that is no multiple of pp, and the
     combination with tensor + sequence parallelism end at the single-process weights; eval and forward agree;
-    the sharded checkpoint round-trips in the interleaved layout."""
+    the sharded checkpoint round-trips in the interleaved layout and loads into / from other layouts."""
     d = tempfile.mkdtemp(prefix="areal_vpp_")
     init, ref = os.path.join(d, "init"), os.path.join(d, "ref")
     _run(1, {}, None, init, preset_name="tiny-deep")
@@ -293,6 +293,15 @@ def test_interleaved_pipeline_stages_match_single_process():
             fw = torch.load(os.path.join(out, f), weights_only=True)
             for i, n in enumerate([23, 9, 31, 14][: fw.shape[0]]):
                 torch.testing.assert_close(fw[i, : n - 1], ref_fw[i, : n - 1], atol=1e-4, rtol=1e-4)
+    # resharding loads across interleaved layouts: interleaved -> tensor parallel, and that one's -> interleaved
+    for name, world, kw, src in (("v2_to_tp2", 2, dict(tensor_parallel_size=2), "pp2v2"),
+                                 ("tp2pp2v2_to_v2", 2, v2, "tp2pp2v2sp")):
+        out = os.path.join(d, name)
+        _run(world, dict(kw, _reshard_from=os.path.join(d, src, "sharded")), init, out, preset_name="tiny-deep")
+        a, b = _load_ckpt(os.path.join(d, src)), _load_ckpt(out)
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("name,world,kw,n_mbs", [
