@@ -79,6 +79,9 @@ def parse_args():
     p.add_argument("--weight-update", default="ipc", choices=["ipc", "disk"],
                    help="decoupled mode: how the rollout servers get new weights (ipc falls back to disk if the "
                         "peer mapping cannot be opened)")
+    p.add_argument("--stall-timeout", type=float, default=1800.0,
+                   help="seconds without passing a milestone (set-up stage, phase of a step) after which a rank dumps "
+                        "its threads' stacks and exits with status 3 instead of hanging; 0 disables")
     p.add_argument("--share-gpu", action="store_true",
                    help="rehearsal on a single GPU: every rank uses device 0 (not a benchmark of N GPUs). With more than one "
                         "trainer rank the collectives are staged through host memory, and the processes time-slice "
@@ -173,17 +176,36 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:  # long configurations say nothing for minutes: a line a minute shows the run is alive
-        import threading
+    import threading
 
-        t_start = time.perf_counter()
+    t_start = time.perf_counter()
+    progress = [t_start, "start"]  # (time, label) of the last milestone this rank passed
 
-        def heartbeat():
-            while True:
-                time.sleep(60)
-                print(f"[bench] running, {time.perf_counter() - t_start:.0f} s since start", file=sys.stderr, flush=True)
+    def mark(label):
+        progress[0], progress[1] = time.perf_counter(), label
 
-        threading.Thread(target=heartbeat, daemon=True, name="bench-heartbeat").start()
+    def heartbeat():
+        # rank 0: a line a minute shows that a long configuration is alive. Every rank: a run that passes no
+        # milestone (set-up stage, phase of a step) for --stall-timeout seconds - a collective waiting for a rank
+        # that died, a wedged device - prints every thread's stack and exits non-zero instead of hanging
+        tick = min(60.0, max(1.0, args.stall_timeout / 4)) if args.stall_timeout > 0 else 60.0
+        said = t_start
+        while True:
+            time.sleep(tick)
+            now = time.perf_counter()
+            if rank == 0 and now - said >= 60:
+                said = now
+                print(f"[bench] running, {now - t_start:.0f} s since start (last: {progress[1]})", file=sys.stderr,
+                      flush=True)
+            if args.stall_timeout > 0 and now - progress[0] > args.stall_timeout:
+                import faulthandler
+
+                print(f"[bench] rank {rank}: no progress for {now - progress[0]:.0f} s after '{progress[1]}', giving up",
+                      file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                os._exit(3)
+
+    threading.Thread(target=heartbeat, daemon=True, name="bench-heartbeat").start()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
@@ -219,6 +241,7 @@ def main():
         n_gen = world // 2
         store = _store(args, rank)
         if rank >= world - n_gen:
+            progress[0] = float("inf")  # a server rank passes no milestones: it lives as long as the trainer side
             serve_rollouts(args, rank, local_rank, store)
             return
         # the trainer half forms its own process group: ranks 0 .. n_train-1 on the next port
@@ -263,9 +286,11 @@ def main():
     )
     actor = NativePPOActor(actor_cfg)
     actor.create_process_group(ParallelStrategy(data_parallel_size=world))
+    mark("process group")
     actor.initialize(None, FinetuneSpec(total_train_epochs=1, dataset_size=10**6,
                                         train_batch_size=args.prompts_per_gpu * world))
 
+    mark("trainer initialised")
     engine = None
     if decoupled:
         from areal_vllm_amd.engine.remote_engine import RemoteInferenceEngine
@@ -366,6 +391,7 @@ def main():
     if decoupled:
         push_weights(0)  # the servers start from their own random init: give them the trainer's weights
 
+    mark("rollout side ready")
     mc = actor.model_config
     gconfig = GenerationHyperparameters(n_samples=args.n_samples, max_new_tokens=args.max_new_tokens, temperature=1.0,
                                         stop_token_ids=[t for t in (mc.eos_token_id, mc.pad_token_id) if t is not None])
@@ -400,6 +426,7 @@ def main():
     def timed(name):
         class _T:
             def __enter__(s):
+                mark(name)
                 dev_sync()
                 s.t = time.perf_counter()
                 if engine is not None:

@@ -58,3 +58,16 @@ def test_decoupled_mode_refuses_an_odd_rank_count():
     p = subprocess.run([sys.executable, "bench.py", "--mode", "decoupled", *ARGS], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "even --gpus" in p.stderr
+
+
+def test_a_stalled_run_exits_with_its_stacks_instead_of_hanging():
+    """No milestone within --stall-timeout: every thread's stack goes to stderr and the process exits with
+    status 3 (a scaling run with a dead rank then fails in bounded time; here the limit is simply set below the
+    start-up time)."""
+    env = dict(os.environ, AREAL_PLATFORM="cpu", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--stall-timeout", "0.01", *ARGS, "--steps", "500"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert "no progress for" in p.stderr and "Thread" in p.stderr and not p.stdout.strip()
