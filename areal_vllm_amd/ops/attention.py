@@ -49,10 +49,11 @@ def attention_varlen_ref(q, k, v, cu_q, cu_k, scale, causal=True):
 
 
 def attention_varlen_sdpa(q, k, v, cu_q, cu_k, scale, causal=True):
-    """Head sizes above 128 on the GPU (the MFMA kernels are specialised for D = 128, the head size of the
-    Qwen2 / Llama-3 8B+ families; smaller heads run on them zero-padded, see `_pad_heads`; 256 of Gemma comes
-    here): PyTorch's fused attention, one call per packed sequence, the
-    causal mask aligned to the bottom-right corner. Differentiable through autograd; returns out only."""
+    """Head sizes the MFMA kernels do not take on the GPU (they are built for D = 128, the head size of the
+    Qwen2 / Llama-3 8B+ families, and D = 256 of Gemma; other sizes that are multiples of 8 run on them
+    zero-padded, see `_pad_heads`; what is left - above 256, or no multiple of 8 - comes here): PyTorch's fused
+    attention, one call per packed sequence, the causal mask aligned to the bottom-right corner. Differentiable
+    through autograd; returns out only."""
     import torch.nn.functional as F
 
     Hq, Hkv = q.shape[1], k.shape[1]
@@ -76,19 +77,22 @@ def attention_varlen_sdpa(q, k, v, cu_q, cu_k, scale, causal=True):
     return torch.cat(outs, 0)
 
 
-HIP_HEAD_DIM = 128  # the head size flash_attn.hip / paged_attn.hip are built for
+HIP_HEAD_DIM = 128  # the head size flash_attn.hip is built for
+HIP_HEAD_DIMS = (128, 256)  # ... and flash_attn_d256.hip
 
 
 def _pad_heads(t: torch.Tensor) -> torch.Tensor:
-    """[.., D] -> [.., 128] with zeros. Zero columns change neither q.k nor the first D columns of p.v, so a
-    smaller head (64 of Qwen2-0.5B, 80 / 96 of the Phi and small Llama families) runs on the same MFMA kernels,
-    packed sequences and all, at the price of the idle half of every K-slab; the caller passes the softmax scale
-    of the true head size and drops the padded output columns. Autograd slices the gradients back."""
-    return torch.nn.functional.pad(t, (0, HIP_HEAD_DIM - t.shape[-1]))
+    """[.., D] -> [.., 128] (or [.., 256] for 128 < D < 256) with zeros. Zero columns change neither q.k nor the
+    first D columns of p.v, so a smaller head (64 of Qwen2-0.5B, 80 / 96 of the Phi and small Llama families)
+    runs on the same MFMA kernels, packed sequences and all, at the price of the idle part of every K-slab; the
+    caller passes the softmax scale of the true head size and drops the padded output columns. Autograd slices
+    the gradients back."""
+    d = t.shape[-1]
+    return torch.nn.functional.pad(t, (0, next(x for x in HIP_HEAD_DIMS if x >= d) - d))
 
 
 def _paddable(d: int) -> bool:
-    return d < HIP_HEAD_DIM and d % 8 == 0
+    return d < HIP_HEAD_DIMS[-1] and d % 8 == 0 and d not in HIP_HEAD_DIMS
 
 
 # ------------------------------------------------------------------------------- autograd op
@@ -142,7 +146,7 @@ def flash_attn_varlen_qkv(qkv: torch.Tensor, cu_seqlens: torch.Tensor, max_seqle
     """Differentiable packed self-attention on a fused qkv tensor; returns [T, Hq, D]."""
     if scale is None:
         scale = 1.0 / math.sqrt(qkv.shape[-1])
-    if L.use_hip(qkv) and qkv.shape[-1] != HIP_HEAD_DIM:
+    if L.use_hip(qkv) and qkv.shape[-1] not in HIP_HEAD_DIMS:
         d = qkv.shape[-1]
         if _paddable(d):
             return _FlashVarlenFn.apply(_pad_heads(qkv), cu_seqlens, int(max_seqlen), n_q_heads, n_kv_heads,
@@ -182,7 +186,7 @@ def _flash_bwd_hip(q, k, v, out, dout, lse, dq, dk, dv, cu_q, cu_k, max_k, scale
     B = cu_q.numel() - 1
     delta = torch.empty(Hq, Tq, dtype=torch.float32, device=q.device)
     # the fp32 accumulator of the atomic dQ path; long sequences compute dQ in a kernel of its own and need none
-    split = bool(L.lib().areal_flash_bwd_split(L.c_int(int(max_k))))
+    split = D == 256 or bool(L.lib().areal_flash_bwd_split(L.c_int(int(max_k))))  # head size 256: always two kernels
     dq_acc = None if split else torch.zeros(Tq, Hq, D, dtype=torch.float32, device=q.device)
     L.check(
         L.lib().areal_flash_bwd(
@@ -240,7 +244,7 @@ def flash_attn_varlen_sep(q, k, v, cu_q, cu_k, max_q: int, max_k: int, scale: Op
     of queries against the keys of its sequences up to the chunk's end)."""
     if scale is None:
         scale = 1.0 / math.sqrt(q.shape[-1])
-    if L.use_hip(q) and q.shape[-1] != HIP_HEAD_DIM:
+    if L.use_hip(q) and q.shape[-1] not in HIP_HEAD_DIMS:
         d = q.shape[-1]
         if _paddable(d):
             return _FlashVarlenSepFn.apply(_pad_heads(q), _pad_heads(k), _pad_heads(v), cu_q, cu_k, int(max_q),
@@ -259,7 +263,7 @@ def flash_attn_varlen(q, k, v, cu_q, cu_k, max_q, scale=None, causal=True):
         if _paddable(d):
             out, lse = _flash_fwd_hip(_pad_heads(q), _pad_heads(k), _pad_heads(v), cu_q, cu_k, max_q, scale, causal)
             return out[..., :d], lse
-        if d != HIP_HEAD_DIM:  # no log-sum-exp on this path (the prefill does not need it)
+        if d not in HIP_HEAD_DIMS:  # no log-sum-exp on this path (the prefill does not need it)
             return attention_varlen_sdpa(q, k, v, cu_q, cu_k, float(scale), causal), None
         return _flash_fwd_hip(q, k, v, cu_q, cu_k, max_q, scale, causal)
     return attention_varlen_ref(q, k, v, cu_q, cu_k, scale, causal)

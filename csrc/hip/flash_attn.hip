@@ -17,39 +17,7 @@
 // LDS tiles use 256-byte rows with the 16-byte-chunk XOR swizzle
 //   off(row, ch) = 256*row + 16*(ch ^ (((row&3)<<2) | ((row>>2)&3)))
 // which is conflict-free for both ds_read_b128 row reads and transposed reads.
-#include "common.hpp"
-
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
-DEVINL f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-// (exponentials go through fast_exp2 of common.hpp: v_exp_f32 directly; exp2f() expands to a denormal-safe
-// sequence (scale, v_exp, ldexp, compare) that the compiler then guards with per-element branches)
-DEVINL int swz_off(int row, int ch) {  // byte offset of 16-byte chunk `ch` of `row`
-  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
-}
-// Transposed read of a 4-row x 16-col block: every lane supplies the address of
-// (row0 + q, col0 + 4p) with its group-lane index 4q+p and receives column `i` of the four
-// rows. `base` is the LDS tile, rows are 256 bytes, col0 must be a multiple of 16.
-DEVINL bf16x4 tr_read(const char* tile, int row0, int col0, int gl) {
-  const int q = gl >> 2, p = gl & 3;
-  const int ch = (col0 >> 3) + (p >> 1);
-  const char* a = tile + swz_off(row0 + q, ch) + 8 * (p & 1);
-  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
-}
-DEVINL bf16x8 cat4(bf16x4 a, bf16x4 b) {
-  bf16x8 r;
-  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-  return r;
-}
-DEVINL bf16x8 lds_row_read(const char* tile, int row, int ch) {
-  return *reinterpret_cast<const bf16x8*>(tile + swz_off(row, ch));
-}
-DEVINL void lds_row_write(char* tile, int row, int ch, bf16x8 v) {
-  *reinterpret_cast<bf16x8*>(tile + swz_off(row, ch)) = v;
-}
+#include "flash_tiles.hpp"
 
 // =====================================================================================
 // Forward. 1-D grid over (q-tile rank, sequence, head). block: 256 threads = 4 waves x 32 q rows.
@@ -244,16 +212,31 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_kernel(
   }
 }
 
+// head size 256: flash_attn_d256.hip
+extern "C" int areal_flash_fwd_d256(const void* q, const void* k, const void* v, void* o, float* lse,
+                                    const int* cu_q, const int* cu_k, int B, int max_q, int total_q, int Hq, int Hkv,
+                                    int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t o_stride,
+                                    float softmax_scale, int causal, hipStream_t st);
+extern "C" int areal_flash_bwd_d256(const void* q, const void* k, const void* v, const void* o, const void* d_o,
+                                    const float* lse, float* delta, void* dq, void* dk, void* dv, const int* cu_q,
+                                    const int* cu_k, int B, int max_k, int total_q, int Hq, int Hkv, int64_t q_stride,
+                                    int64_t k_stride, int64_t v_stride, int64_t o_stride, int64_t do_stride,
+                                    int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, float softmax_scale,
+                                    int causal, hipStream_t st);
+
 extern "C" int areal_flash_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                                const int* cu_q, const int* cu_k, int B, int max_q, int total_q,
                                int Hq, int Hkv, int D, int64_t q_stride, int64_t k_stride,
                                int64_t v_stride, int64_t o_stride, float softmax_scale, int causal,
                                hipStream_t st) {
   if (B == 0 || max_q == 0) return 0;
-  if (D != 128) return -1;
+  if (D != 128 && D != 256) return -1;
   if (Hq % Hkv != 0) return -2;
   if ((q_stride | k_stride | v_stride | o_stride) % 8 != 0) return -3;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 != 0) return -4;
+  if (D == 256)
+    return areal_flash_fwd_d256(q, k, v, o, lse, cu_q, cu_k, B, max_q, total_q, Hq, Hkv, q_stride, k_stride, v_stride,
+                                o_stride, softmax_scale, causal, st);
   const int n_g_pad = (Hkv * B + 7) & ~7;  // see the XCD placement note in the kernel
   dim3 grid((unsigned)(((max_q + 127) / 128) * (Hq / Hkv) * n_g_pad)), block(256);
   hipLaunchKernelGGL(flash_fwd_kernel, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
@@ -740,10 +723,14 @@ extern "C" int areal_flash_bwd(const void* q, const void* k, const void* v, cons
                                int64_t dk_stride, int64_t dv_stride, float softmax_scale, int causal,
                                hipStream_t st) {
   if (B == 0 || total_q == 0) return 0;
-  if (D != 128) return -1;
+  if (D != 128 && D != 256) return -1;
   if (Hq % Hkv != 0) return -2;
   if ((q_stride | k_stride | v_stride | o_stride | do_stride | dq_stride | dk_stride | dv_stride) % 8)
     return -3;
+  if (D == 256)  // always the two-kernel form (dq_acc is not used)
+    return areal_flash_bwd_d256(q, k, v, o, d_o, lse, delta, dq, dk, dv, cu_q, cu_k, B, max_k, total_q, Hq, Hkv,
+                                q_stride, k_stride, v_stride, o_stride, do_stride, dq_stride, dk_stride, dv_stride,
+                                softmax_scale, causal, st);
   {
     const int64_t n = (int64_t)total_q * Hq * 16;
     hipLaunchKernelGGL(flash_bwd_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,

@@ -114,9 +114,9 @@ def _rand_seqlens(B, lo, hi, seed):
     (28, 4, [700, 1, 129]),
     (8, 1, [1024]),
 ])
-def test_flash_attn_fwd_bwd(Hq, Hkv, lens):
+@pytest.mark.parametrize("D", [128, 256])
+def test_flash_attn_fwd_bwd(Hq, Hkv, lens, D):
     torch.manual_seed(3)
-    D = 128
     T = sum(lens)
     cu = torch.tensor([0] + np.cumsum(lens).tolist(), dtype=torch.int32, device=DEV)
     qkv = (0.5 * torch.randn(T, Hq + 2 * Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
@@ -133,11 +133,11 @@ def test_flash_attn_fwd_bwd(Hq, Hkv, lens):
     _close(qkv.grad[:, Hq + Hkv:].cpu(), qf.grad[:, Hq + Hkv:], 3e-2, 5e-2, "dv")
 
 
-@pytest.mark.parametrize("D,Hq,Hkv", [(64, 8, 2), (256, 4, 1), (80, 4, 4), (96, 6, 2)])
+@pytest.mark.parametrize("D,Hq,Hkv", [(64, 8, 2), (256, 4, 1), (80, 4, 4), (96, 6, 2), (192, 4, 2), (320, 2, 1)])
 def test_attention_head_sizes_other_than_128(D, Hq, Hkv):
-    """Smaller heads run zero-padded on the MFMA kernels, larger ones take PyTorch's fused attention per
-    sequence; forward, backward and the bottom-right aligned mask of the separate-stream entries against the
-    fp32 reference."""
+    """Head size 256 has MFMA kernels of its own, other multiples of 8 up to 256 run zero-padded on the 128 / 256
+    kernels, larger ones take PyTorch's fused attention per sequence; forward, backward and the bottom-right
+    aligned mask of the separate-stream entries against the fp32 reference."""
     torch.manual_seed(5)
     lens = [33, 1, 130, 64]
     T = sum(lens)
@@ -263,6 +263,25 @@ def test_flash_attn_long_context_fwd_bwd(lens):
     T = sum(lens)
     cu = torch.tensor([0] + np.cumsum(lens).tolist(), dtype=torch.int32, device=DEV)
     qkv = (0.5 * torch.randn(T, Hq + 2 * Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
+    out = ops.flash_attn_varlen_qkv(qkv, cu, max(lens), Hq, Hkv)
+    g = torch.randn_like(out)
+    out.backward(g)
+    ref, dq, dk, dv = _blockwise_attention_ref(qkv[:, :Hq], qkv[:, Hq:Hq + Hkv], qkv[:, Hq + Hkv:], lens, lens, g)
+    _close_long(out, ref, f"out {lens}")
+    _close_long(qkv.grad[:, :Hq], dq, f"dq {lens}")
+    _close_long(qkv.grad[:, Hq:Hq + Hkv], dk, f"dk {lens}")
+    _close_long(qkv.grad[:, Hq + Hkv:], dv, f"dv {lens}")
+
+
+@pytest.mark.parametrize("lens", [[4096], [2500, 700, 129], [8192, 300]])
+def test_flash_attn_head_size_256_long_context_fwd_bwd(lens):
+    """The head-size-256 kernels (Gemma) on multi-thousand-token packed sequences, GQA, against the blockwise fp32
+    reference with the hard per-element bound."""
+    torch.manual_seed(23)
+    D, Hq, Hkv = 256, 4, 2
+    T = sum(lens)
+    cu = torch.tensor([0] + np.cumsum(lens).tolist(), dtype=torch.int32, device=DEV)
+    qkv = (0.35 * torch.randn(T, Hq + 2 * Hkv, D, device=DEV)).bfloat16().requires_grad_(True)
     out = ops.flash_attn_varlen_qkv(qkv, cu, max(lens), Hq, Hkv)
     g = torch.randn_like(out)
     out.backward(g)
