@@ -1,10 +1,12 @@
 """Grouped GEMM for expert-sorted tokens (MoE): ``out[t] = x[t] @ W[expert(t)]^T``.
 
 Forward runs the MFMA kernel of ``csrc/hip/grouped_gemm.hip`` (one launch for all experts, tiles never
-straddle experts). The backward pass computes ``dx`` with the same kernel on the transposed weights and
-``dW`` per expert with library GEMMs. Counterpart of ``grouped_gemm.ops.gmm`` in the reference
+straddle experts). The backward pass computes ``dx`` with a sibling kernel that reads the weights untransposed and
+``dW`` of all experts with one launch of the grouped weight-gradient kernel (expert shapes that are no multiples of
+128: per expert with library GEMMs). Counterpart of ``grouped_gemm.ops.gmm`` in the reference
 (``realhf/impl/model/modules/moe/experts.py:195-210``).
 """
+import os
 from typing import List
 
 import torch
@@ -32,9 +34,11 @@ def _launch(x: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor) -> torch.Te
     assert K == K2 and offsets.numel() == E + 1 and offsets.dtype == torch.int32 and offsets.is_cuda
     assert x.is_contiguous() and w.stride(2) == 1 and w.stride(1) == K, "operands must be K-contiguous"
     out = torch.empty(T, N, dtype=x.dtype, device=x.device)
+    tile_m = int(os.environ.get("AREAL_GROUPED_GEMM_TILE_M", "0"))  # 0: chosen from the rows per expert
+    tm = L.lib().areal_grouped_gemm_tile_m(L.c_int(T), L.c_int(E), L.c_int(N), L.c_int(tile_m))
     L.check(L.lib().areal_grouped_gemm_nt(L.ptr(x), L.ptr(w), L.ptr(out), L.ptr(offsets), L.c_int(T), L.c_int(E),
-                                          L.c_int(N), L.c_int(K), L.c_int64(w.stride(0)), L.c_int(T // 64 + E),
-                                          L.stream_ptr()), "grouped_gemm_nt")
+                                          L.c_int(N), L.c_int(K), L.c_int64(w.stride(0)), L.c_int(T // tm + E),
+                                          L.c_int(tile_m), L.stream_ptr()), "grouped_gemm_nt")
     return out
 
 
@@ -51,21 +55,55 @@ class _GroupedGemmFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            # dx[t] = dy[t] @ W[e]  =  dy[t] @ (W[e]^T)^T : the same kernel on K-contiguous transposed weights
-            dx = _launch(dy, w.transpose(1, 2).contiguous(), offsets)
+            E, N, K = w.shape
+            if K % 128 == 0:
+                # dx[t] = dy[t] @ W[e]: the weights are read as they are (transposed LDS reads in the kernel)
+                T = dy.shape[0]
+                dx = torch.empty(T, K, dtype=dy.dtype, device=dy.device)
+                tile_m = int(os.environ.get("AREAL_GROUPED_GEMM_TILE_M", "0"))
+                tm = L.lib().areal_grouped_gemm_tile_m(L.c_int(T), L.c_int(E), L.c_int(K), L.c_int(tile_m))
+                L.check(L.lib().areal_grouped_gemm_nn(L.ptr(dy), L.ptr(w), L.ptr(dx), L.ptr(offsets), L.c_int(T),
+                                                      L.c_int(E), L.c_int(N), L.c_int(K), L.c_int64(w.stride(0)),
+                                                      L.c_int(T // tm + E), L.c_int(tile_m), L.stream_ptr()),
+                        "grouped_gemm_nn")
+            else:  # the forward kernel on a K-contiguous transposed copy of the weights
+                dx = _launch(dy, w.transpose(1, 2).contiguous(), offsets)
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
-            s = 0
-            for e, n in enumerate(ctx.counts):
-                if n:
-                    torch.mm(dy[s:s + n].t(), x[s:s + n], out=dw[e])
-                s += n
+            E, N, K = w.shape
+            if N % 128 == 0 and K % 128 == 0 and x.shape[0] > 0:
+                # dW[e] = dy_e^T . x_e for all experts in one launch (csrc/hip/grouped_gemm.hip)
+                dw = torch.empty_like(w)
+                L.check(L.lib().areal_grouped_gemm_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(offsets),
+                                                         L.c_int(x.shape[0]), L.c_int(E), L.c_int(N), L.c_int(K),
+                                                         L.c_int64(dw.stride(0)), L.stream_ptr()), "grouped_gemm_wgrad")
+            else:
+                dw = torch.zeros_like(w)
+                s = 0
+                for e, n in enumerate(ctx.counts):
+                    if n:
+                        torch.mm(dy[s:s + n].t(), x[s:s + n], out=dw[e])
+                    s += n
         return dx, dw, None, None
+
+
+# Few, large experts (Mixtral: 8 experts, thousands of rows each): one library GEMM per expert runs at 0.9-1.1 PFLOP/s,
+# the grouped kernel at about half of that; many small experts (Qwen3-MoE: 128 experts, ~1000 rows each): the loop is
+# launch-bound and the grouped kernel is 2-3x faster (tools/grouped_gemm_probe.py). AREAL_GROUPED_GEMM=hip|library
+# overrides the choice.
+LIBRARY_MAX_EXPERTS = 16
+LIBRARY_MIN_ROWS_PER_EXPERT = 1024
+
+
+def _prefer_library(n_rows: int, n_experts: int) -> bool:
+    forced = os.environ.get("AREAL_GROUPED_GEMM", "auto")
+    if forced in ("hip", "library"):
+        return forced == "library"
+    return n_experts <= LIBRARY_MAX_EXPERTS and n_rows >= LIBRARY_MIN_ROWS_PER_EXPERT * n_experts
 
 
 def grouped_gemm(x: torch.Tensor, w: torch.Tensor, counts: List[int]) -> torch.Tensor:
     """x [T, K] rows sorted by expert, w [E, N, K], counts[e] rows per expert (host ints, sum = T)."""
-    if not _hip_ok(x, w) or x.shape[0] == 0:
+    if not _hip_ok(x, w) or x.shape[0] == 0 or _prefer_library(x.shape[0], w.shape[0]):
         if x.is_cuda and x.dtype == torch.bfloat16:
             L.lib()  # on a GPU box the library must exist even when a shape falls back
         return grouped_gemm_ref(x, w, counts)

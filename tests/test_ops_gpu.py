@@ -747,13 +747,22 @@ def test_linear_accumulates_wgrad_into_fp32_main_grad():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("counts", [[64, 0, 130, 1, 61], [5, 300, 7, 0, 0, 200, 33, 64]])
-def test_grouped_gemm_matches_reference_fwd_bwd(counts):
+@pytest.mark.parametrize("tile_m", [64, 128])
+@pytest.mark.parametrize("K", [256, 192])
+@pytest.mark.parametrize("N", [192, 256, 384, 512])
+@pytest.mark.parametrize("counts", [[64, 0, 130, 1, 61], [5, 300, 7, 0, 0, 200, 33, 64], [129, 128, 127, 0, 513]])
+def test_grouped_gemm_matches_reference_fwd_bwd(counts, N, K, tile_m, monkeypatch):
+    """Every tile shape of the kernel (64 / 128 rows x 64 / 128 columns), experts with no rows, with fewer rows
+    than a tile and with rows just past a tile boundary; forward, dx (the untransposed-weight kernel when K is a
+    multiple of 128, else the forward kernel on a transposed copy) and dW (the grouped weight-gradient kernel when
+    N and K are multiples of 128, library GEMMs per expert otherwise)."""
     from areal_vllm_amd import ops
 
+    monkeypatch.setenv("AREAL_GROUPED_GEMM_TILE_M", str(tile_m))
+    monkeypatch.setenv("AREAL_GROUPED_GEMM", "hip")
     torch.manual_seed(0)
     dev = torch.device("cuda")
-    E, N, K = len(counts), 192, 256
+    E = len(counts)
     T = sum(counts)
     x = (torch.randn(T, K, device=dev)).bfloat16().requires_grad_(True)
     w = (torch.randn(E, N, K, device=dev) * 0.05).bfloat16().requires_grad_(True)
