@@ -92,6 +92,14 @@ class ModelConfig:
             n += H
         return n
 
+    def n_active_params(self, with_embedding: bool = True) -> int:
+        """Parameters one token passes through: for mixture-of-experts models the routed experts count
+        `n_experts_per_tok` of `n_experts` times (FLOP accounting); equal to `n_params` for dense models."""
+        n = self.n_params(with_embedding)
+        if self.n_experts > 0:
+            n -= self.n_layers * (self.n_experts - self.n_experts_per_tok) * 3 * self.hidden_size * self.moe_intermediate_size
+        return n
+
     # ------------------------------------------------------------------ HF interop
     @classmethod
     def from_hf_dict(cls, d: Dict[str, Any], is_critic: bool = False) -> "ModelConfig":
@@ -267,6 +275,18 @@ PRESETS: Dict[str, Dict[str, Any]] = {
                     image_token_id=500, video_token_id=501, vision_start_token_id=502, vision_end_token_id=503,
                     vision=dict(depth=2, embed_dim=64, hidden_size=256, num_heads=4, mlp_ratio=2, patch_size=14,
                                 spatial_merge_size=2, temporal_patch_size=2, in_channels=3)),
+    # Qwen3-30B-A3B (128 experts of width 768, 8 per token) and a 12-layer cut of it that trains on one GPU with
+    # fp32 master weights and Adam state resident (expert GEMM benchmarking)
+    "qwen3-30b-a3b": dict(family="qwen3_moe", vocab_size=151936, hidden_size=2048, n_layers=48, n_q_heads=32,
+                          n_kv_heads=4, head_dim=128, intermediate_size=6144, tie_word_embeddings=False,
+                          qkv_bias=False, qk_norm=True, rope_theta=1e6, max_position_embeddings=40960,
+                          rms_norm_eps=1e-6, n_experts=128, n_experts_per_tok=8, moe_intermediate_size=768,
+                          norm_topk_prob=True, eos_token_id=151645, pad_token_id=151643),
+    "qwen3-moe-a3b-12l": dict(family="qwen3_moe", vocab_size=151936, hidden_size=2048, n_layers=12, n_q_heads=32,
+                              n_kv_heads=4, head_dim=128, intermediate_size=6144, tie_word_embeddings=False,
+                              qkv_bias=False, qk_norm=True, rope_theta=1e6, max_position_embeddings=40960,
+                              rms_norm_eps=1e-6, n_experts=128, n_experts_per_tok=8, moe_intermediate_size=768,
+                              norm_topk_prob=True, eos_token_id=151645, pad_token_id=151643),
     "tiny-moe": dict(family="qwen3_moe", vocab_size=512, hidden_size=256, n_layers=2, n_q_heads=2, n_kv_heads=1,
                      head_dim=128, intermediate_size=512, tie_word_embeddings=False, qkv_bias=False, qk_norm=True,
                      rope_theta=1e4, max_position_embeddings=4096, n_experts=4, n_experts_per_tok=2,

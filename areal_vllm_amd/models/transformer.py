@@ -275,10 +275,12 @@ class MoE(nn.Module):
                 0, ti.reshape(-1), torch.ones(ti.numel(), device=x.device)) / max(1, ti.numel())
             mean_p = pr.mean(0) if n_valid > 0 else probs.sum(0) * 0.0
             self.aux_loss = aux_scale * cfg.router_aux_loss_coef * cfg.n_experts * (frac * mean_p).sum()
+        k = cfg.n_experts_per_tok
         flat_e = topi.reshape(-1)
-        order = torch.argsort(flat_e, stable=True)
-        tok = order // cfg.n_experts_per_tok
-        xs = x[tok]
+        order = torch.argsort(flat_e, stable=True)  # expert-sorted position -> (token, choice) pair t*k + j
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(order.numel(), device=order.device)
+        xs = ops.moe_permute(x, order, inv, k)
         counts = torch.bincount(flat_e, minlength=cfg.n_experts)
         if ep_group is not None and self.ep_size > 1:
             from ..parallel.expert_parallel import ep_dispatch_combine
@@ -286,8 +288,8 @@ class MoE(nn.Module):
             ys = ep_dispatch_combine(self, xs, counts, ep_group)
         else:
             ys = self._experts(xs, counts.tolist())
-        w = topv.reshape(-1)[order].to(ys.dtype).unsqueeze(-1)
-        return torch.zeros_like(x).index_add_(0, tok, ys * w)
+        # every token gathers its k expert outputs (no scatter-add: each output row is written once)
+        return ops.moe_combine(ys, topv, order, inv)
 
 
 def add_norm(cfg: ModelConfig, h, weight, bias, residual):

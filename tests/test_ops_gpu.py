@@ -993,3 +993,35 @@ def test_peer_memory_all_reduce_between_processes(tmp_path, world):
     first, *others = (torch.load(tmp_path / f"r{r}.pt", weights_only=True) for r in range(world))
     for other in others:
         assert all(torch.equal(x, y) for x, y in zip(first, other))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,k,E,H", [(37, 2, 4, 256), (300, 8, 16, 2048), (5, 1, 3, 64)])
+def test_moe_permute_and_combine_match_scatter_formulation(T, k, E, H):
+    """Rows into expert order and the weighted recombination as gathers (forward and every gradient) against the
+    index / index_add formulation in fp32."""
+    from areal_vllm_amd import ops
+
+    torch.manual_seed(T)
+    dev = torch.device("cuda")
+    x = torch.randn(T, H, device=dev).bfloat16().requires_grad_(True)
+    wts = torch.rand(T, k, device=dev).requires_grad_(True)
+    experts = torch.stack([torch.randperm(E, device=dev)[:k] if k <= E else torch.arange(k, device=dev) % E
+                           for _ in range(T)])
+    order = torch.argsort(experts.reshape(-1), stable=True)
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(order.numel(), device=dev)
+    xs = ops.moe_permute(x, order, inv, k)
+    assert torch.equal(xs, x.detach()[order // k])
+    scale = torch.randn(T * k, 1, device=dev).bfloat16()  # stand-in for the experts: row-wise scaling
+    out = ops.moe_combine(xs * scale, wts, order, inv)
+    g = torch.randn_like(out)
+    out.backward(g)
+    xf, wf = x.detach().float().requires_grad_(True), wts.detach().clone().requires_grad_(True)
+    tok = order // k
+    ys = xf[tok] * scale.float()
+    ref = torch.zeros(T, H, device=dev).index_add_(0, tok, ys * wf.reshape(-1)[order].unsqueeze(-1))
+    ref.backward(g.float())
+    _close(out, ref, 3e-2, 3e-2, "combine out")
+    _close(x.grad, xf.grad, 5e-2, 5e-2, "dx")
+    _close(wts.grad, wf.grad, 0.02 * math.sqrt(H), 5e-2, "dw")

@@ -58,7 +58,7 @@ def timed(fn):
 
 
 T = a.seqs * a.len
-n_params = mc.n_params()  # the embedding table is also the LM head GEMM for tied models
+n_params = mc.n_active_params()  # the embedding table is also the LM head GEMM for tied models; MoE: active experts
 attn = 2 * 2 * a.len * mc.n_q_heads * mc.head_dim * mc.n_layers / 2  # causal QK^T + PV flops per token (forward)
 fwd_flops = T * (2 * n_params + attn)
 t_fwd = timed(lambda: eng.forward(batch, post_hook=score))
