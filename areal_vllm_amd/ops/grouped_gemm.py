@@ -71,11 +71,21 @@ class _GroupedGemmFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             E, N, K = w.shape
             if N % 128 == 0 and K % 128 == 0 and x.shape[0] > 0:
-                # dW[e] = dy_e^T . x_e for all experts in one launch (csrc/hip/grouped_gemm.hip)
-                dw = torch.empty_like(w)
-                L.check(L.lib().areal_grouped_gemm_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(offsets),
+                # dW[e] = dy_e^T . x_e for all experts in one launch (csrc/hip/grouped_gemm.hip); when the weight
+                # carries an fp32 `main_grad` view the kernel adds into it (no bf16 dW, no separate add kernel)
+                mg = getattr(w, "main_grad", None)
+                fold = mg is not None and mg.dtype == torch.float32 and mg.is_contiguous()
+                dst = mg if fold else torch.empty_like(w)
+                L.check(L.lib().areal_grouped_gemm_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dst), L.ptr(offsets),
                                                          L.c_int(x.shape[0]), L.c_int(E), L.c_int(N), L.c_int(K),
-                                                         L.c_int64(dw.stride(0)), L.stream_ptr()), "grouped_gemm_wgrad")
+                                                         L.c_int64(dst.stride(0)), L.c_int(int(fold)), L.stream_ptr()),
+                        "grouped_gemm_wgrad")
+                if fold:
+                    done = getattr(w, "_after_fold", None)
+                    if done is not None:  # the gradient went into the fp32 buffer without passing the accumulation hook
+                        done(w)
+                else:
+                    dw = dst
             else:
                 dw = torch.zeros_like(w)
                 s = 0

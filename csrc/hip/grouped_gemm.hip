@@ -280,9 +280,11 @@ extern "C" int areal_grouped_gemm_nn(const void* dy, const void* w, void* out, c
 // reads (ds_read_b64_tr_b16) of token-major tiles [64 tokens][128 columns] in the swizzled layout of
 // flash_tiles.hpp; rows past the expert's last token are staged as zeros. fp32 accumulation, one bf16 store.
 // =====================================================================================
-template <int NS>  // the tile holds NS x 128 rows of dW (columns of dy): 128 x 128 or 256 x 128 per workgroup
+// OUT = bf16_t: dW is stored; OUT = float: dW is ADDED to an fp32 accumulator of the same shape (gradient
+// accumulation over micro-batches straight into the optimizer's buffer, every element touched by one workgroup).
+template <int NS, typename OUT>  // the tile holds NS x 128 rows of dW (columns of dy): 128 x 128 or 256 x 128
 __global__ __launch_bounds__(256) void grouped_gemm_wgrad_kernel(
-    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, bf16_t* __restrict__ dw,
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, OUT* __restrict__ dw,
     const int* __restrict__ offsets, int N, int K, int64_t dw_expert_stride) {
   constexpr int YT = 64 * 256;  // bytes of one [64 tokens][128 columns] sub-tile
   __shared__ __attribute__((aligned(16))) char smem[(NS + 1) * YT];
@@ -363,33 +365,47 @@ __global__ __launch_bounds__(256) void grouped_gemm_wgrad_kernel(
     }
   }
   // ---- epilogue: lane (k column = r, hf), reg -> n row (reg&3) + 8(reg>>2) + 4hf of each 32 x 32 tile
-  bf16_t* de = dw + (size_t)e * dw_expert_stride;
+  OUT* de = dw + (size_t)e * dw_expert_stride;
+  if (sizeof(OUT) == 4 && row_lo >= row_hi) return;  // accumulating: an expert without rows adds nothing
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int ki = 0; ki < 2; ++ki) {
-      bf16_t* op = de + (size_t)(n0 + 64 * NS * wn + 32 * ni + 4 * hf) * K + k0 + 64 * wk + 32 * ki + r;
+      OUT* op = de + (size_t)(n0 + 64 * NS * wn + 32 * ni + 4 * hf) * K + k0 + 64 * wk + 32 * ki + r;
+      if constexpr (sizeof(OUT) == 4) {
+        float old[16];  // all sixteen loads in flight before the first store (the compiler cannot reorder them itself)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg)
-        op[(size_t)((reg & 3) + 8 * (reg >> 2)) * K] = f2bf(acc[2 * ni + ki][reg]);
+        for (int reg = 0; reg < 16; ++reg) old[reg] = op[(size_t)((reg & 3) + 8 * (reg >> 2)) * K];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          op[(size_t)((reg & 3) + 8 * (reg >> 2)) * K] = old[reg] + acc[2 * ni + ki][reg];
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          op[(size_t)((reg & 3) + 8 * (reg >> 2)) * K] = f2bf(acc[2 * ni + ki][reg]);
+      }
     }
 }
 
-// dy [T, N], x [T, K] bf16 row-major (rows sorted by expert), dw [E, N, K] bf16 (every element is written, experts
-// without rows get zeros); N and K multiples of 128.
+// dy [T, N], x [T, K] bf16 row-major (rows sorted by expert); N and K multiples of 128. accumulate = 0: dw [E, N, K]
+// bf16, every element is written (experts without rows get zeros); accumulate = 1: dw [E, N, K] fp32, dW is added.
 extern "C" int areal_grouped_gemm_wgrad(const void* dy, const void* x, void* dw, const int* offsets, int T, int E,
-                                        int N, int K, int64_t dw_expert_stride, hipStream_t st) {
+                                        int N, int K, int64_t dw_expert_stride, int accumulate, hipStream_t st) {
   if (E == 0) return 0;
   if (N % 128 != 0 || K % 128 != 0) return -1;
   if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw) % 16 != 0) return -2;
   if (E > 65535 || N / 128 > 65535) return -3;
   dim3 block(256);
-  if (N % 256 == 0) {  // taller tiles: every transposed x fragment feeds four MFMAs instead of two
-    hipLaunchKernelGGL(grouped_gemm_wgrad_kernel<2>, dim3(K / 128, N / 256, E), block, 0, st, (const bf16_t*)dy,
-                       (const bf16_t*)x, (bf16_t*)dw, offsets, N, K, dw_expert_stride);
+  const bool tall = N % 256 == 0;  // taller tiles: every transposed x fragment feeds four MFMAs instead of two
+  dim3 grid(K / 128, tall ? N / 256 : N / 128, E);
+#define AREAL_GG_WGRAD(NS_, OUT_)                                                                            \
+  hipLaunchKernelGGL((grouped_gemm_wgrad_kernel<NS_, OUT_>), grid, block, 0, st, (const bf16_t*)dy,         \
+                     (const bf16_t*)x, (OUT_*)dw, offsets, N, K, dw_expert_stride)
+  if (accumulate) {
+    if (tall) AREAL_GG_WGRAD(2, float); else AREAL_GG_WGRAD(1, float);
   } else {
-    hipLaunchKernelGGL(grouped_gemm_wgrad_kernel<1>, dim3(K / 128, N / 128, E), block, 0, st, (const bf16_t*)dy,
-                       (const bf16_t*)x, (bf16_t*)dw, offsets, N, K, dw_expert_stride);
+    if (tall) AREAL_GG_WGRAD(2, bf16_t); else AREAL_GG_WGRAD(1, bf16_t);
   }
+#undef AREAL_GG_WGRAD
   return (int)hipGetLastError();
 }

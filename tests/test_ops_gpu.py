@@ -1025,3 +1025,30 @@ def test_moe_permute_and_combine_match_scatter_formulation(T, k, E, H):
     _close(out, ref, 3e-2, 3e-2, "combine out")
     _close(x.grad, xf.grad, 5e-2, 5e-2, "dx")
     _close(wts.grad, wf.grad, 0.02 * math.sqrt(H), 5e-2, "dw")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [256, 384])
+def test_grouped_gemm_weight_gradient_accumulates_into_main_grad(N, monkeypatch):
+    """A weight that carries an fp32 `main_grad` view gets its gradient ADDED there by the kernel (two backward
+    passes = twice the gradient, experts without rows untouched) and no bf16 gradient tensor."""
+    from areal_vllm_amd import ops
+
+    monkeypatch.setenv("AREAL_GROUPED_GEMM", "hip")
+    torch.manual_seed(1)
+    dev = torch.device("cuda")
+    counts, K = [70, 0, 200, 3], 256
+    E, T = len(counts), sum(counts)
+    x = torch.randn(T, K, device=dev).bfloat16().requires_grad_(True)
+    w = (torch.randn(E, N, K, device=dev) * 0.05).bfloat16().requires_grad_(True)
+    w.main_grad = torch.full((E, N, K), 0.5, dtype=torch.float32, device=dev)
+    folded = []
+    w._after_fold = lambda p: folded.append(p)
+    dy = torch.randn(T, N, device=dev).bfloat16()
+    for _ in range(2):
+        ops.grouped_gemm(x, w, counts).backward(dy)
+    assert w.grad is None and len(folded) == 2
+    xf, wf = x.detach().float(), w.detach().float().requires_grad_(True)
+    ops.grouped_gemm_ref(xf, wf, counts).backward(dy.float())
+    _close(w.main_grad, 0.5 + 2 * wf.grad, 0.1, 2e-2, "main_grad")
+    assert torch.equal(w.main_grad[1], torch.full((N, K), 0.5, device=dev))

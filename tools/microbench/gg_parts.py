@@ -22,7 +22,7 @@ for (rows, E, N, K) in ((131072, 128, 1536, 2048), (131072, 128, 2048, 768)):
     t_dx = bench(lambda: G._launch(dy, wT, offsets))
     def wg():
         L.check(L.lib().areal_grouped_gemm_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dw), L.ptr(offsets), L.c_int(rows), L.c_int(E),
-                                                 L.c_int(N), L.c_int(K), L.c_int64(dw.stride(0)), L.stream_ptr()), "wgrad")
+                                                 L.c_int(N), L.c_int(K), L.c_int64(dw.stride(0)), L.c_int(0), L.stream_ptr()), "wgrad")
     t_wg = bench(wg)
     fl = 2.0 * rows * N * K
     print(f"rows={rows} E={E} N={N} K={K}: transpose copy {t_tr:.0f} us, dx kernel {t_dx:.0f} us ({fl/t_dx/1e6:.0f} TF/s), "
