@@ -151,9 +151,9 @@ extern "C" int areal_grouped_gemm_nt(const void* x, const void* w, void* out, co
 //     dx[t, :] = dy[t, :] . W[e]          (W[e] is [R, C]: R = rows of W = columns of dy, C = columns of dx)
 // Same tiling as the forward kernel (TM tokens x 128 output columns per workgroup, reduction in 64-deep steps),
 // but the reduction dimension is the SLOW dimension of W: the W tile is staged as [64 r][128 c] in the swizzled
-// 256-byte-row layout of flash_tiles.hpp and becomes the A operand through transposed LDS reads, which hand a lane
-// the r values {4hf .. 4hf+3, 8+4hf .. 8+4hf+3} of a 16-deep slab; the dy fragment (B operand) is read in the same
-// order with two 8-byte reads.
+// 256-byte-row layout of flash_tiles.hpp and becomes the A operand through transposed LDS reads of the rows
+// 8hf .. 8hf+7 of a 16-deep slab - the order in which the plain 16-byte row read hands the dy fragment (B operand)
+// its values.
 // =====================================================================================
 template <int TM>
 __global__ __launch_bounds__(256) void grouped_gemm_nn_kernel(
@@ -218,15 +218,11 @@ __global__ __launch_bounds__(256) void grouped_gemm_nn_kernel(
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int col = 64 * wn + 32 * ni + 16 * (grp & 1);
-        wf[ni] = cat4(tr_read(ws, 16 * s + 4 * hf, col, gl), tr_read(ws, 16 * s + 8 + 4 * hf, col, gl));
+        wf[ni] = cat4(tr_read(ws, 16 * s + 8 * hf, col, gl), tr_read(ws, 16 * s + 8 * hf + 4, col, gl));
       }
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int row = (TM / 2) * wm + 32 * mi + r;
-        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(as + gg_off(row, 2 * s) + 8 * hf);
-        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(as + gg_off(row, 2 * s + 1) + 8 * hf);
-        xf[mi] = cat4(lo, hi);
-      }
+      for (int mi = 0; mi < MI; ++mi)
+        xf[mi] = *reinterpret_cast<const bf16x8*>(as + gg_off((TM / 2) * wm + 32 * mi + r, 2 * s + hf));
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

@@ -16,8 +16,9 @@ from collections import defaultdict
 
 
 def short(name: str) -> str:
-    name = re.sub(r"\(.*", "", name)
     name = re.sub(r"^void ", "", name)
+    name = name.replace("(anonymous namespace)::", "")  # before cutting at the parameter list's parenthesis
+    name = re.sub(r"\(.*", "", name)
     m = re.search(r"(Cijk_\w{4}_\w{4}).*?(MT\d+x\d+x\d+)", name)
     if m:
         return f"hipBLASLt {m.group(1)} {m.group(2)}"
