@@ -13,6 +13,8 @@
 // of a ds_read_b128 lane group hit 16 different 16-byte bank slots. The product is computed transposed
 // (W rows as the A operand) so that each lane ends up with 4 consecutive output columns of one token and
 // stores 8 bytes at a time.
+#include <stdlib.h>
+
 #include "flash_tiles.hpp"  // swizzled 256-byte-row LDS tiles + transposed reads (weight-gradient kernel)
 
 DEVINL int gg_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7)) << 4); }
@@ -20,14 +22,16 @@ DEVINL int gg_off(int row, int ch) { return row * 128 + ((ch ^ ((row >> 1) & 7))
 // TM x TN output tile per workgroup (64 or 128 each): the four waves form a 2 x 2 grid, a wave owns a
 // (TM/2) x (TN/2) block = MI x NI MFMA tiles of 32 x 32. With 128 x 128 every 16-byte LDS fragment read feeds two
 // MFMAs instead of one (64 x 64: the K loop is bound by LDS reads and barriers, not by the matrix cores).
-template <int TM, int TN>
+// KH = number of 64-deep sub-tiles staged per step: with 2 a step holds twice the MFMA work between the barrier
+// pairs and behind every register prefetch of the next step's global loads.
+template <int TM, int TN, int KH>
 __global__ __launch_bounds__(256) void grouped_gemm_nt_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, bf16_t* __restrict__ out,
     const int* __restrict__ offsets, int E, int N, int K, int64_t w_expert_stride) {
   constexpr int MI = TM / 64, NI = TN / 64;
-  __shared__ __attribute__((aligned(16))) char smem[(TM + TN) * 128];
-  char* as = smem;             // x tile  [TM rows][64 k]
-  char* bs = smem + TM * 128;  // W tile  [TN n][64 k]
+  __shared__ __attribute__((aligned(16))) char smem[KH * (TM + TN) * 128];
+  char* as = smem;                  // x tile  [KH][TM rows][64 k]
+  char* bs = smem + KH * TM * 128;  // W tile  [KH][TN n][64 k]
 
   // ---- which expert / m-tile is this block? (tiles are numbered expert by expert)
   int tile = blockIdx.y, e = 0, row_lo = 0, row_hi = 0;
@@ -49,22 +53,31 @@ __global__ __launch_bounds__(256) void grouped_gemm_nt_kernel(
 
   // cooperative loads: thread -> (row = tid >> 3 (+32 i), chunk = tid & 7)
   const int lrow = tid >> 3, lch = tid & 7;
-  bf16x8 areg[TM / 32], breg[TN / 32];
+  bf16x8 areg[KH * TM / 32], breg[KH * TN / 32];
   auto load = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < TM / 32; ++i) {
-      int m = m0 + lrow + 32 * i;
-      m = m < row_hi ? m : row_hi - 1;
-      areg[i] = ld8(x + (size_t)m * K + k0 + lch * 8);
-    }
+    for (int h = 0; h < KH; ++h) {
 #pragma unroll
-    for (int i = 0; i < TN / 32; ++i) breg[i] = ld8(we + (size_t)(n0 + lrow + 32 * i) * K + k0 + lch * 8);
+      for (int i = 0; i < TM / 32; ++i) {
+        int m = m0 + lrow + 32 * i;
+        m = m < row_hi ? m : row_hi - 1;
+        areg[h * (TM / 32) + i] = ld8(x + (size_t)m * K + k0 + 64 * h + lch * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < TN / 32; ++i)
+        breg[h * (TN / 32) + i] = ld8(we + (size_t)(n0 + lrow + 32 * i) * K + k0 + 64 * h + lch * 8);
+    }
   };
   auto stage = [&]() {
 #pragma unroll
-    for (int i = 0; i < TM / 32; ++i) *reinterpret_cast<bf16x8*>(as + gg_off(lrow + 32 * i, lch)) = areg[i];
+    for (int h = 0; h < KH; ++h) {
 #pragma unroll
-    for (int i = 0; i < TN / 32; ++i) *reinterpret_cast<bf16x8*>(bs + gg_off(lrow + 32 * i, lch)) = breg[i];
+      for (int i = 0; i < TM / 32; ++i)
+        *reinterpret_cast<bf16x8*>(as + h * TM * 128 + gg_off(lrow + 32 * i, lch)) = areg[h * (TM / 32) + i];
+#pragma unroll
+      for (int i = 0; i < TN / 32; ++i)
+        *reinterpret_cast<bf16x8*>(bs + h * TN * 128 + gg_off(lrow + 32 * i, lch)) = breg[h * (TN / 32) + i];
+    }
   };
 
   f32x16 acc[MI * NI];
@@ -74,21 +87,23 @@ __global__ __launch_bounds__(256) void grouped_gemm_nt_kernel(
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
   load(0);
-  for (int k0 = 0; k0 < K; k0 += 64) {
+  for (int k0 = 0; k0 < K; k0 += 64 * KH) {
     __syncthreads();  // previous tile fully consumed
     stage();
-    if (k0 + 64 < K) load(k0 + 64);
+    if (k0 + 64 * KH < K) load(k0 + 64 * KH);
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 4 * KH; ++s) {
       // A operand = W rows (output columns), B operand = token rows: acc[n][m]
       bf16x8 wf[NI], xf[MI];
+      const char* bt = bs + (s >> 2) * TN * 128;
+      const char* at = as + (s >> 2) * TM * 128;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        wf[ni] = *reinterpret_cast<const bf16x8*>(bs + gg_off((TN / 2) * wn + 32 * ni + r, 2 * s + hf));
+        wf[ni] = *reinterpret_cast<const bf16x8*>(bt + gg_off((TN / 2) * wn + 32 * ni + r, 2 * (s & 3) + hf));
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
-        xf[mi] = *reinterpret_cast<const bf16x8*>(as + gg_off((TM / 2) * wm + 32 * mi + r, 2 * s + hf));
+        xf[mi] = *reinterpret_cast<const bf16x8*>(at + gg_off((TM / 2) * wm + 32 * mi + r, 2 * (s & 3) + hf));
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -135,13 +150,20 @@ extern "C" int areal_grouped_gemm_nt(const void* x, const void* w, void* out, co
   if (max_tiles < T / tm + E) return -4;  // the caller sized its bound for another tile height
   const int tn = (N % 128 == 0) ? 128 : 64;
   dim3 grid(N / tn, max_tiles), block(256);
-#define AREAL_GG_LAUNCH(TM_, TN_)                                                                                  \
-  hipLaunchKernelGGL((grouped_gemm_nt_kernel<TM_, TN_>), grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)w,  \
-                     (bf16_t*)out, offsets, E, N, K, w_expert_stride)
-  if (tm == 128 && tn == 128) AREAL_GG_LAUNCH(128, 128);
-  else if (tm == 128) AREAL_GG_LAUNCH(128, 64);
-  else if (tn == 128) AREAL_GG_LAUNCH(64, 128);
-  else AREAL_GG_LAUNCH(64, 64);
+  // 128-deep steps (AREAL_GROUPED_GEMM_KSTEP=128) halve the barrier pairs of the large tile but cost a wave of
+  // occupancy per SIMD (3 -> 2): measured 3-15 % slower on the Qwen3-MoE expert shapes, so 64 is the default
+  static const int deep = [] {
+    const char* e = getenv("AREAL_GROUPED_GEMM_KSTEP");
+    return e && atoi(e) == 128;
+  }();
+#define AREAL_GG_LAUNCH(TM_, TN_, KH_)                                                                    \
+  hipLaunchKernelGGL((grouped_gemm_nt_kernel<TM_, TN_, KH_>), grid, block, 0, st, (const bf16_t*)x,      \
+                     (const bf16_t*)w, (bf16_t*)out, offsets, E, N, K, w_expert_stride)
+  if (tm == 128 && tn == 128) {
+    if (deep && K % 128 == 0) AREAL_GG_LAUNCH(128, 128, 2); else AREAL_GG_LAUNCH(128, 128, 1);
+  } else if (tm == 128) AREAL_GG_LAUNCH(128, 64, 1);
+  else if (tn == 128) AREAL_GG_LAUNCH(64, 128, 1);
+  else AREAL_GG_LAUNCH(64, 64, 1);
 #undef AREAL_GG_LAUNCH
   return (int)hipGetLastError();
 }
@@ -392,7 +414,10 @@ extern "C" int areal_grouped_gemm_wgrad(const void* dy, const void* x, void* dw,
   if (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dw) % 16 != 0) return -2;
   if (E > 65535 || N / 128 > 65535) return -3;
   dim3 block(256);
-  const bool tall = N % 256 == 0;  // taller tiles: every transposed x fragment feeds four MFMAs instead of two
+  // 256 x 128 tiles feed four MFMAs per transposed x fragment but hold one wave per SIMD (282 registers); the
+  // 128 x 128 tile runs two and measured 3 % faster on the Qwen3-MoE shapes. AREAL_GROUPED_WGRAD_TALL=1 selects it.
+  static const bool want_tall = [] { const char* e = getenv("AREAL_GROUPED_WGRAD_TALL"); return e && e[0] == '1'; }();
+  const bool tall = want_tall && N % 256 == 0;
   dim3 grid(K / 128, tall ? N / 256 : N / 128, E);
 #define AREAL_GG_WGRAD(NS_, OUT_)                                                                            \
   hipLaunchKernelGGL((grouped_gemm_wgrad_kernel<NS_, OUT_>), grid, block, 0, st, (const bf16_t*)dy,         \
