@@ -42,7 +42,21 @@ def _launch(x: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor) -> torch.Te
     return out
 
 
+def _fold_target(w: torch.Tensor):
+    """The fp32 `main_grad` view of a weight, when its gradient can be accumulated there directly."""
+    mg = getattr(w, "main_grad", None)
+    return mg if mg is not None and mg.dtype == torch.float32 and mg.is_contiguous() else None
+
+
+def _after_fold(w: torch.Tensor):
+    done = getattr(w, "_after_fold", None)
+    if done is not None:  # the gradient went into the fp32 buffer without passing the accumulation hook
+        done(w)
+
+
 class _GroupedGemmFn(torch.autograd.Function):
+    """Grouped MFMA kernels: forward, dx on the untransposed weights, dW of all experts in one launch."""
+
     @staticmethod
     def forward(ctx, x, w, offsets, counts):
         ctx.save_for_backward(x, w, offsets)
@@ -54,8 +68,8 @@ class _GroupedGemmFn(torch.autograd.Function):
         x, w, offsets = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dw = None
+        E, N, K = w.shape
         if ctx.needs_input_grad[0]:
-            E, N, K = w.shape
             if K % 128 == 0:
                 # dx[t] = dy[t] @ W[e]: the weights are read as they are (transposed LDS reads in the kernel)
                 T = dy.shape[0]
@@ -69,21 +83,17 @@ class _GroupedGemmFn(torch.autograd.Function):
             else:  # the forward kernel on a K-contiguous transposed copy of the weights
                 dx = _launch(dy, w.transpose(1, 2).contiguous(), offsets)
         if ctx.needs_input_grad[1]:
-            E, N, K = w.shape
             if N % 128 == 0 and K % 128 == 0 and x.shape[0] > 0:
                 # dW[e] = dy_e^T . x_e for all experts in one launch (csrc/hip/grouped_gemm.hip); when the weight
                 # carries an fp32 `main_grad` view the kernel adds into it (no bf16 dW, no separate add kernel)
-                mg = getattr(w, "main_grad", None)
-                fold = mg is not None and mg.dtype == torch.float32 and mg.is_contiguous()
-                dst = mg if fold else torch.empty_like(w)
+                mg = _fold_target(w)
+                dst = mg if mg is not None else torch.empty_like(w)
                 L.check(L.lib().areal_grouped_gemm_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dst), L.ptr(offsets),
                                                          L.c_int(x.shape[0]), L.c_int(E), L.c_int(N), L.c_int(K),
-                                                         L.c_int64(dst.stride(0)), L.c_int(int(fold)), L.stream_ptr()),
-                        "grouped_gemm_wgrad")
-                if fold:
-                    done = getattr(w, "_after_fold", None)
-                    if done is not None:  # the gradient went into the fp32 buffer without passing the accumulation hook
-                        done(w)
+                                                         L.c_int64(dst.stride(0)), L.c_int(int(mg is not None)),
+                                                         L.stream_ptr()), "grouped_gemm_wgrad")
+                if mg is not None:
+                    _after_fold(w)
                 else:
                     dw = dst
             else:
@@ -94,6 +104,53 @@ class _GroupedGemmFn(torch.autograd.Function):
                         torch.mm(dy[s:s + n].t(), x[s:s + n], out=dw[e])
                     s += n
         return dx, dw, None, None
+
+
+class _LibraryLoopFn(torch.autograd.Function):
+    """One library GEMM per expert, forward and backward, written straight into slices of the outputs (no
+    concatenation, no per-expert autograd nodes); dW is accumulated by the GEMM into the fp32 `main_grad` view of the
+    weight when it has one (``ops/linear.py`` does the same for the dense layers)."""
+
+    @staticmethod
+    def forward(ctx, x, w, counts):
+        ctx.save_for_backward(x, w)
+        ctx.counts = counts
+        out = torch.empty(x.shape[0], w.shape[1], dtype=x.dtype, device=x.device)
+        s = 0
+        for e, n in enumerate(counts):
+            if n:
+                torch.mm(x[s:s + n], w[e].t(), out=out[s:s + n])
+            s += n
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            s = 0
+            for e, n in enumerate(ctx.counts):
+                if n:
+                    torch.mm(dy[s:s + n], w[e], out=dx[s:s + n])
+                s += n
+        if ctx.needs_input_grad[1]:
+            mg = _fold_target(w)
+            fold = mg is not None and dy.is_cuda and dy.dtype in (torch.bfloat16, torch.float16)
+            if not fold:
+                dw = torch.zeros_like(w)
+            s = 0
+            for e, n in enumerate(ctx.counts):
+                if n:
+                    if fold:
+                        torch.addmm(mg[e], dy[s:s + n].t(), x[s:s + n], out_dtype=torch.float32, out=mg[e])
+                    else:
+                        torch.mm(dy[s:s + n].t(), x[s:s + n], out=dw[e])
+                s += n
+            if fold:
+                _after_fold(w)
+        return dx, dw, None
 
 
 # Few, large experts (Mixtral: 8 experts, thousands of rows each): one library GEMM per expert runs at 0.9-1.1 PFLOP/s,
@@ -113,7 +170,10 @@ def _prefer_library(n_rows: int, n_experts: int) -> bool:
 
 def grouped_gemm(x: torch.Tensor, w: torch.Tensor, counts: List[int]) -> torch.Tensor:
     """x [T, K] rows sorted by expert, w [E, N, K], counts[e] rows per expert (host ints, sum = T)."""
-    if not _hip_ok(x, w) or x.shape[0] == 0 or _prefer_library(x.shape[0], w.shape[0]):
+    if _hip_ok(x, w) and x.shape[0] > 0 and _prefer_library(x.shape[0], w.shape[0]):
+        L.lib()  # on a GPU box the kernel library must exist even when a shape goes to the GEMM library
+        return _LibraryLoopFn.apply(x.contiguous(), w, list(counts))
+    if not _hip_ok(x, w) or x.shape[0] == 0:
         if x.is_cuda and x.dtype == torch.bfloat16:
             L.lib()  # on a GPU box the library must exist even when a shape falls back
         return grouped_gemm_ref(x, w, counts)

@@ -24,6 +24,13 @@ DEVINL bf16x4 tr_read(const char* tile, int row0, int col0, int gl) {
   const char* a = tile + swz_off(row0 + q, ch) + 8 * (p & 1);
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a));
 }
+// The same read split in two: the address (loop-invariant when a tile is restaged in place) and the load.
+DEVINL const char* tr_addr(const char* tile, int row0, int col0, int gl) {
+  const int q = gl >> 2, p = gl & 3;
+  const int ch = (col0 >> 3) + (p >> 1);
+  return tile + swz_off(row0 + q, ch) + 8 * (p & 1);
+}
+DEVINL bf16x4 tr_load(const char* a) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a)); }
 DEVINL bf16x8 cat4(bf16x4 a, bf16x4 b) {
   bf16x8 r;
   r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];

@@ -228,6 +228,21 @@ __global__ __launch_bounds__(256) void grouped_gemm_nn_kernel(
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
+  // LDS addresses of the fragment reads are the same every step: computed once, outside the loop
+  const char* wa[4][2][2];
+  const char* xa[4][MI];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int col = 64 * wn + 32 * ni + 16 * (grp & 1);
+      wa[s][ni][0] = tr_addr(ws, 16 * s + 8 * hf, col, gl);
+      wa[s][ni][1] = tr_addr(ws, 16 * s + 8 * hf + 4, col, gl);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) xa[s][mi] = as + gg_off((TM / 2) * wm + 32 * mi + r, 2 * s + hf);
+  }
+
   load(0);
   for (int r0 = 0; r0 < R; r0 += 64) {
     __syncthreads();
@@ -238,13 +253,9 @@ __global__ __launch_bounds__(256) void grouped_gemm_nn_kernel(
     for (int s = 0; s < 4; ++s) {
       bf16x8 wf[2], xf[MI];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int col = 64 * wn + 32 * ni + 16 * (grp & 1);
-        wf[ni] = cat4(tr_read(ws, 16 * s + 8 * hf, col, gl), tr_read(ws, 16 * s + 8 * hf + 4, col, gl));
-      }
+      for (int ni = 0; ni < 2; ++ni) wf[ni] = cat4(tr_load(wa[s][ni][0]), tr_load(wa[s][ni][1]));
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-        xf[mi] = *reinterpret_cast<const bf16x8*>(as + gg_off((TM / 2) * wm + 32 * mi + r, 2 * s + hf));
+      for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(xa[s][mi]);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -355,6 +366,27 @@ __global__ __launch_bounds__(256) void grouped_gemm_wgrad_kernel(
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
 
+  // LDS addresses of the transposed fragment reads: the same every step, computed once (the swizzle costs ~10
+  // vector ALU operations per address, more than the MFMAs they feed if redone inside the loop)
+  const char* ya[4][NI][2];
+  const char* xa[4][2][2];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int col = 64 * NS * wn + 32 * i;  // row of the tile = column of dy, 0 .. 128 NS
+      const int c0 = (col & 127) + 16 * (grp & 1);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) ya[s][i][h2] = tr_addr(ys + (col >> 7) * YT, 16 * s + 8 * h2 + 4 * hf, c0, gl);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c0 = 64 * wk + 32 * i + 16 * (grp & 1);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) xa[s][i][h2] = tr_addr(xs, 16 * s + 8 * h2 + 4 * hf, c0, gl);
+    }
+  }
+
   if (row_lo < row_hi) load(row_lo);
   for (int t0 = row_lo; t0 < row_hi; t0 += 64) {
     __syncthreads();  // previous tile fully consumed
@@ -365,17 +397,9 @@ __global__ __launch_bounds__(256) void grouped_gemm_wgrad_kernel(
     for (int s = 0; s < 4; ++s) {  // 16-token slabs
       bf16x8 af[NI], bf[2];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int col = 64 * NS * wn + 32 * i;  // row of the tile = column of dy, 0 .. 128 NS
-        const char* yt = ys + (col >> 7) * YT;
-        const int c0 = (col & 127) + 16 * (grp & 1);
-        af[i] = cat4(tr_read(yt, 16 * s + 4 * hf, c0, gl), tr_read(yt, 16 * s + 8 + 4 * hf, c0, gl));
-      }
+      for (int i = 0; i < NI; ++i) af[i] = cat4(tr_load(ya[s][i][0]), tr_load(ya[s][i][1]));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int c0 = 64 * wk + 32 * i + 16 * (grp & 1);
-        bf[i] = cat4(tr_read(xs, 16 * s + 4 * hf, c0, gl), tr_read(xs, 16 * s + 8 + 4 * hf, c0, gl));
-      }
+      for (int i = 0; i < 2; ++i) bf[i] = cat4(tr_load(xa[s][i][0]), tr_load(xa[s][i][1]));
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll

@@ -1052,3 +1052,34 @@ def test_grouped_gemm_weight_gradient_accumulates_into_main_grad(N, monkeypatch)
     ops.grouped_gemm_ref(xf, wf, counts).backward(dy.float())
     _close(w.main_grad, 0.5 + 2 * wf.grad, 0.1, 2e-2, "main_grad")
     assert torch.equal(w.main_grad[1], torch.full((N, K), 0.5, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_main_grad", [False, True])
+def test_grouped_gemm_library_loop_for_few_large_experts(with_main_grad, monkeypatch):
+    """The dispatch for few, large experts: one library GEMM per expert in forward and backward, dW accumulated
+    into the fp32 `main_grad` view when the weight has one."""
+    from areal_vllm_amd import ops
+
+    monkeypatch.setenv("AREAL_GROUPED_GEMM", "library")
+    torch.manual_seed(2)
+    dev = torch.device("cuda")
+    counts, N, K = [300, 0, 129, 70], 256, 192
+    E, T = len(counts), sum(counts)
+    x = torch.randn(T, K, device=dev).bfloat16().requires_grad_(True)
+    w = (torch.randn(E, N, K, device=dev) * 0.05).bfloat16().requires_grad_(True)
+    if with_main_grad:
+        w.main_grad = torch.zeros(E, N, K, dtype=torch.float32, device=dev)
+    dy = torch.randn(T, N, device=dev).bfloat16()
+    out = ops.grouped_gemm(x, w, counts)
+    out.backward(dy)
+    xf, wf = x.detach().float().requires_grad_(True), w.detach().float().requires_grad_(True)
+    ref = ops.grouped_gemm_ref(xf, wf, counts)
+    ref.backward(dy.float())
+    _close(out, ref, 3e-2, 2e-2, "out")
+    _close(x.grad, xf.grad, 3e-2, 2e-2, "dx")
+    if with_main_grad:
+        assert w.grad is None
+        _close(w.main_grad, wf.grad, 0.1, 2e-2, "main_grad")
+    else:
+        _close(w.grad, wf.grad, 0.25, 3e-2, "dw")
