@@ -119,3 +119,52 @@ def test_benchmark_formats_normalise_to_evaluator_rows(tmp_path):
     assert [r["query_id"] for r in B.load_benchmark(str(tmp_path), "gsm8k", start=1, limit=1)] == ["1"]
     p = B.few_shot_prompt("2+2?", [("1+1?", "1+1=2. The answer is 2")], instruction="Solve.")
     assert p == "Solve.\n\nQuestion: 1+1?\nAnswer: 1+1=2. The answer is 2\n\nQuestion: 2+2?\nAnswer:"
+
+
+def test_majority_and_reward_model_voting(tmp_path):
+    from areal_vllm_amd.evaluation import voting
+
+    # string grouping keeps 2/4 apart from 1/2; symbolic grouping merges them
+    groups, top = voting.group_predictions(["\\frac{1}{2}", "3", "\\frac{1}{2}", "\\frac{2}{4}"], normalise=True)
+    assert top == "\\frac{1}{2}" and sorted(map(len, groups.values())) == [1, 1, 2]
+    groups, top = voting.group_predictions(["0.5", "3", "\\frac{1}{2}", "3", "\\frac{2}{4}"], symbolic=True)
+    assert top == "0.5" and sorted(map(len, groups.values())) == [2, 3]
+    rows = [dict(pred=["4", "5", "4", "7"], score=[1, 0, 1, 0], pred_score=[[0.1], [0.9], [0.2], [0.3]]),
+            dict(pred=["1", "2", "2", "3"], score=[1, 0, 0, 0], pred_score=[0.8, 0.1, 0.2, 0.3])]
+    assert voting.maj_at_k(rows, 4) == 50.0  # first problem's vote is right, second's is not
+    assert voting.rm_at_k(rows, 4) == 50.0  # the reward model picks a wrong sample first, the right one second
+    assert voting.maj_at_k(rows, 1) == 100.0
+    p = tmp_path / "s.jsonl"
+    p.write_text("\n".join(json.dumps(r) for r in rows))
+    assert voting.main(["--samples", str(p), "-k", "4"]) == {"maj@4": 50.0, "rm@4": 50.0}
+
+
+def test_accuracy_from_rollout_dumps(tmp_path):
+    from areal_vllm_amd.evaluation import voting
+
+    (tmp_path / "a.jsonl").write_text("\n".join(json.dumps(x) for x in [
+        dict(query_id="q1@idx:0", reward=5.0), dict(query_id="q1@idx:1", reward=-5.0), dict(prompt="p", reward=1.0)]))
+    (tmp_path / "b.jsonl").write_text(json.dumps(dict(prompt="p", reward=2.0)) + "\n")
+    agg = voting.accuracy_from_rollout_dumps(str(tmp_path))
+    assert agg["per_query"]["q1"] == (2, 0.5) and len(agg["per_query"]) == 2
+    assert abs(agg["mean_accuracy"] - 0.75) < 1e-9
+
+
+def test_tool_integrated_transcripts():
+    from areal_vllm_amd.evaluation import voting
+
+    t = ("Let me compute.\n```python\nx = 2\nprint(x)\n```\n```output\n2\n```\nNow a slip.\n```python\ny = 1/0\n```\n"
+         "```output\nTraceback (most recent call last):\nZeroDivisionError: division by zero\n```\n"
+         "Again.\n```python\nprint(x + 1)\n```\n")
+    pieces = voting.split_trajectory(t)
+    assert [p["role"] for p in pieces] == ["text", "program", "output", "text", "program", "output", "text", "program"]
+    assert voting.split_trajectory(voting.join_trajectory(pieces)) == pieces
+    assert voting.program_of(t, last_only=True) == "print(x + 1)"
+    prog = voting.program_of(t)
+    assert "1/0" not in prog and "x = 2" in prog
+    from areal_vllm_amd.evaluation.python_executor import PythonExecutor
+
+    out = PythonExecutor().run(prog)
+    text = out[0] if isinstance(out, tuple) else out
+    assert str(text).strip() == "3"  # earlier successful cell re-run silently, failed cell skipped
+    assert voting.last_output_of(t).startswith("Traceback") and not voting.execution_succeeded(voting.last_output_of(t))
