@@ -86,6 +86,12 @@ def parse_args():
                    help="rehearsal on a single GPU: every rank uses device 0 (not a benchmark of N GPUs). With more than one "
                         "trainer rank the collectives are staged through host memory, and the processes time-slice "
                         "the card, so expect minutes per step at the headline config - pair it with --model small")
+    p.add_argument("--no-decoupled-pass", action="store_true",
+                   help="colocated runs on an even number of ranks >= 2 end with a short second pass in --mode decoupled "
+                        "(fresh child processes, reported under 'decoupled'); this flag leaves it out")
+    p.add_argument("--decoupled-steps", type=int, default=8, help="timed steps of that second pass (at most --steps)")
+    p.add_argument("--decoupled-budget", type=float, default=300.0,
+                   help="seconds the second pass may take before it is ended and reported as an error")
     a = p.parse_args()
     if a.seq_len:
         a.max_new_tokens = a.seq_len - a.prompt_len_max
@@ -157,8 +163,106 @@ def serve_rollouts(args, rank, local_rank, store):
     engine.destroy()
 
 
+def _port_block_free(base, offsets=(0, 1, 2, 16, 17, 18)):
+    import socket
+
+    for off in offsets:
+        with socket.socket() as sk:
+            try:
+                sk.bind(("127.0.0.1", base + off))
+            except OSError:
+                return False
+    return True
+
+
+def _pick_master_port():
+    import random
+    import socket
+
+    for _ in range(64):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            base = sk.getsockname()[1]
+        if base + 18 < 65536 and _port_block_free(base):
+            return base
+    return random.randint(20000, 40000)
+
+
+def launch_ranks(args):
+    """``python bench.py --gpus N`` with no torchrun environment: start N fresh rank processes (one per GPU,
+    torchrun-style environment), relay rank 0's single result line, fail if any rank fails. This parent never
+    imports torch and never touches a GPU (role of the reference's local launcher, areal/launcher/local.py:318-330)."""
+    import signal
+    import subprocess
+    import threading
+
+    port = _pick_master_port()
+    procs = []
+    lines = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), AREAL_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8" if args.device == "cuda" else "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=r == 0 or None,
+                                      start_new_session=True))
+
+    def pump():
+        for line in procs[0].stdout:
+            if line.strip():
+                lines.append(line.strip())
+
+    reader = threading.Thread(target=pump, daemon=True)
+    reader.start()
+
+    def stop_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)  # the rank and whatever it started (its own session: nothing else)
+                except ProcessLookupError:
+                    pass
+
+    def on_signal(signum, frame):
+        stop_all()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, rc = bad[0]
+            print(f"[bench] rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+            stop_all()
+            time.sleep(5.0)
+            stop_all(signal.SIGKILL)
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10.0)
+    if rc != 0:
+        return rc if 0 < rc < 256 else 1
+    results = [l for l in lines if l.startswith("{")]
+    if len(results) != 1:
+        print(f"[bench] expected one result line from rank 0, got {len(results)}", file=sys.stderr)
+        return 1
+    print(results[0], flush=True)
+    return 0
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
+
+
+def run_rank(args):
     if os.environ.get("AREAL_BENCH_HANG_DUMP"):  # debugging aid: stack of every thread after that many seconds
         import faulthandler
 
@@ -491,6 +595,31 @@ def main():
         dist.all_reduce(cnt)
     elapsed = float(el.item())
     samples, gen_tok, all_tok = (float(x) for x in cnt.tolist())
+    # proof of what the run saw: every rank adds a one over the trainer's collective backend (RCCL on GPUs) and
+    # names the device it computed on
+    ones = torch.ones(1, dtype=torch.float32, device=dev)
+    if world > 1:
+        dist.all_reduce(ones)
+    ranks_seen = int(ones.item())
+    if on_gpu:
+        pr = torch.cuda.get_device_properties(local_rank)
+        if all(hasattr(pr, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            my_dev = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        else:
+            my_dev = str(getattr(pr, "uuid", f"cuda:{local_rank}"))
+    else:
+        my_dev = "cpu"
+    devices = [my_dev]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, my_dev)
+    if on_gpu and not args.share_gpu:
+        assert len(set(devices)) == world, f"ranks share a GPU: {devices}"
+    backend = "none (single rank)"
+    if world > 1:
+        backend = "host-staged gloo" if os.environ.get("AREAL_HOST_STAGED_COLLECTIVES") == "1" else (
+            "rccl" if on_gpu else "gloo")
+    out = None
     if rank == 0:
         value = samples / elapsed
         mean_len = all_tok / max(1.0, samples)
@@ -519,6 +648,8 @@ def main():
             "mean_token_staleness_rank0": round(tot.get("stale_sum", 0.0) / args.steps, 3),
             "pipeline_prime_steps": prime,
             "mode": args.mode, "weight_update": wu,
+            "rccl_ranks_seen": ranks_seen + n_gen, "trainer_ranks_in_collective": ranks_seen,
+            "collective_backend": backend, "devices": devices,
             "rollout_servers": server_stats,
             "other_hardware_context": {
                 "note": "NOT the same configuration: the reference's closest published figure is end-to-end tokens/s "
@@ -535,14 +666,11 @@ def main():
                        "max_tokens_per_mb": args.max_tokens_per_mb, "decode_steps_per_plan": args.decode_steps,
                        "gradient_checkpointing": bool(args.gradient_checkpointing)},
         }
-        sys.stdout.flush()
-        os.dup2(result_fd, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
         if args.profile_phases:
             print(json.dumps(phase), file=sys.stderr)
             for row in trace:
                 print("phase %-15s %7.3fs  decoded %7d  prefilled %7d" % row, file=sys.stderr)
+    mark("teardown")
     rollout.destroy()
     if engine is not None:
         engine.destroy()
@@ -551,6 +679,61 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if (not decoupled and args.gpus >= 2 and args.gpus % 2 == 0 and not args.no_decoupled_pass
+            and not (args.share_gpu and on_gpu)):
+        # the reference's own allocation (half the ranks serve, half train) as a short second pass in fresh child
+        # processes, one per rank: the headline value above stays the colocated one
+        del actor, rollout, engine, workflow
+        import gc
+
+        gc.collect()
+        if on_gpu:
+            torch.cuda.empty_cache()
+        mark("decoupled pass")
+        second = decoupled_second_pass(args, rank)
+        if out is not None:
+            out["decoupled"] = second
+    if out is not None:
+        sys.stdout.flush()
+        os.dup2(result_fd, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+
+
+def decoupled_second_pass(args, rank):
+    """Run ``--mode decoupled`` on the same ranks in one fresh child process per rank and return rank 0's
+    summary of its result line ({"error": ...} if the pass failed or overran its budget: the headline result
+    must not depend on it)."""
+    import subprocess
+
+    steps = max(1, min(args.steps, args.decoupled_steps))
+    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 16),
+               TORCHELASTIC_USE_AGENT_STORE="False")
+    cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--mode", "decoupled", "--steps", str(steps),
+           "--warmup", "1", "--no-decoupled-pass", "--stall-timeout", str(args.decoupled_budget)]
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=True)
+    try:
+        stdout, _ = p.communicate(timeout=args.decoupled_budget)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        return {"error": f"no result within {args.decoupled_budget:.0f} s"}
+    if rank != 0:
+        return None
+    if p.returncode != 0:
+        return {"error": f"exit status {p.returncode}"}
+    try:
+        res = json.loads([l for l in stdout.splitlines() if l.startswith("{")][-1])
+    except (IndexError, ValueError):
+        return {"error": "no result line"}
+    upd = res.get("phase_s_per_step_rank0", {}).get("update_weights")
+    return {"value": res["value"], "unit": res["unit"], "gen_tokens_per_s": res["gen_tokens_per_s"],
+            "weight_update_ms": None if upd is None else round(1000.0 * upd, 1),
+            "transport": res["weight_update"]["transport"], "fallback": res["weight_update"]["fallback"],
+            "steps": res["steps"], "warmup": res["warmup"], "ms_per_step": res["ms_per_step"],
+            "layout": res["config"]["parallelism"], "rccl_ranks_seen": res.get("rccl_ranks_seen"),
+            "wall_s": round(time.perf_counter() - t0, 1)}
 
 
 if __name__ == "__main__":

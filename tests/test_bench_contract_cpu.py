@@ -1,7 +1,8 @@
 """The benchmark entry point's contract, rehearsed on CPU (gloo): launched the way the scaling runs launch it
 (one rank per device through torch.distributed.run), it prints exactly ONE line on stdout - the JSON result -
 with the whole-job aggregate, on 1 and on 4 ranks (the trainer pads its flat parameter buffer per data-parallel
-size, which the colocated weight copy must tolerate)."""
+size, which the colocated weight copy must tolerate); launched as plain ``python bench.py --gpus N`` it starts the
+N ranks itself."""
 import json
 import os
 import socket
@@ -16,13 +17,22 @@ ARGS = ["--device", "cpu", "--model", "tiny", "--steps", "2", "--warmup", "1", "
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+    """A port whose neighbours (+1, +2: trainer group and host store of the decoupled mode) are free as well."""
+    for _ in range(64):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            base = s.getsockname()[1]
+        try:
+            for off in (1, 2):
+                with socket.socket() as t:
+                    t.bind(("127.0.0.1", base + off))
+            return base
+        except OSError:
+            continue
+    raise RuntimeError("no free port block")
 
 
-@pytest.mark.parametrize("n,mode", [(1, "colocated"), (4, "colocated"), (2, "decoupled"), (4, "decoupled"),
-                                    (8, "decoupled")])
+@pytest.mark.parametrize("n,mode", [(1, "colocated"), (4, "colocated"), (2, "decoupled"), (8, "decoupled")])
 def test_bench_prints_one_json_line(n, mode):
     env = dict(os.environ, AREAL_PLATFORM="cpu", OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AREAL_LLM_SERVER_ADDRS"):
@@ -31,7 +41,7 @@ def test_bench_prints_one_json_line(n, mode):
         cmd = [sys.executable, "bench.py", *ARGS]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
-               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), "--mode", mode, *ARGS]
+               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), "--mode", mode, "--no-decoupled-pass", *ARGS]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
@@ -49,6 +59,38 @@ def test_bench_prints_one_json_line(n, mode):
     if mode == "decoupled":
         assert out["weight_update"]["transport"] == "ipc" and out["weight_update"]["fallback"] is None
         assert len(out["rollout_servers"]) == n // 2 and all(sv["gen_tokens"] > 0 for sv in out["rollout_servers"])
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_plain_invocation_spawns_its_own_ranks(n):
+    """``python bench.py --gpus N`` with no torchrun environment starts N rank processes itself, prints ONE line,
+    proves the rank count through a collective (``rccl_ranks_seen``) and, N being even, appends the short
+    decoupled pass."""
+    env = dict(os.environ, AREAL_PLATFORM="cpu", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "AREAL_LLM_SERVER_ADDRS"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), *ARGS], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and out["rccl_ranks_seen"] == n and len(out["devices"]) == n
+    assert out["mode"] == "colocated" and out["config"]["global_batch"] == 3 * n
+    assert out["value"] == pytest.approx(3 * 2 * n / (out["ms_per_step"] / 1000.0), rel=0.02)
+    dec = out["decoupled"]
+    assert "error" not in dec, dec
+    assert dec["value"] > 0 and dec["gen_tokens_per_s"] > 0 and dec["transport"] == "ipc" and dec["rccl_ranks_seen"] == n
+    assert dec["layout"].startswith(f"decoupled: {n // 2} rollout server")
+
+
+def test_a_failing_rank_fails_the_self_spawned_run():
+    env = dict(os.environ, AREAL_PLATFORM="cpu", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--mode", "decoupled", *ARGS], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not p.stdout.strip() and "even --gpus" in p.stderr
 
 
 def test_decoupled_mode_refuses_an_odd_rank_count():
