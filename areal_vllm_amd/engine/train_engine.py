@@ -574,8 +574,11 @@ class NativeTrainEngine(TrainEngine):
             e.copy_(total)
             self.optimizer.apply(lr)
             self.expert_optimizer.apply(lr)
-        return dict(update_successful=float(self.optimizer.update_successful()), grad_norm=self.optimizer.grad_norm(),
-                    lr=lr)
+        if hasattr(self.optimizer, "step_stats"):
+            norm, ok = self.optimizer.step_stats()
+        else:
+            norm, ok = self.optimizer.grad_norm(), self.optimizer.update_successful()
+        return dict(update_successful=float(ok), grad_norm=norm, lr=lr)
 
     @torch.no_grad()
     def eval_batch(self, input_: Dict[str, Any], loss_fn: Callable, loss_weight_fn: Callable) -> Optional[torch.Tensor]:

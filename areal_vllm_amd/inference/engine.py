@@ -87,6 +87,7 @@ class NativeInferenceEngine:
         self._wake = threading.Event()
         self._stop = threading.Event()
         self._thread: Optional[threading.Thread] = None
+        self.failed: Optional[str] = None  # why the engine loop died, if it did
         self._version = 0
         self._paused = False
         self.stats = dict(prefill_steps=0, decode_steps=0, prefill_time=0.0, decode_time=0.0, gen_tokens=0,
@@ -255,8 +256,11 @@ class NativeInferenceEngine:
                     self._deliver()
                 else:
                     self._launch_decode(plan)
-        except Exception:
+        except Exception as e:
             traceback.print_exc()
+            # the engine is dead from here on: running requests end as aborted, new ones are refused and
+            # `/health` reports it, so a supervisor (launcher/server_wrapper.py) restarts the server
+            self.failed = f"{type(e).__name__}: {e}"
             self._fail_all("engine loop crashed")
         finally:
             if self.tp_size > 1:
@@ -289,6 +293,9 @@ class NativeInferenceEngine:
             if cont["kind"] == 2:
                 self._attach_slot_clears(cont)
                 self._tp_bcast("decode", cont)
+                # a penalised request queued while the batch is full gets its count row here (the followers zero
+                # it when they receive this plan): zero it on this rank too, before its prefill samples from it
+                self.runner.clear_penalty_slots(cont["clear_penalty_slots"])
                 nxt = dict(plan=cont, handle=self.runner.decode_launch(cont), t0=time.perf_counter())
                 self.stats["pipelined_plans"] += 1
         toks, lps = self.runner.decode_wait(cur["handle"])
@@ -453,6 +460,8 @@ class NativeInferenceEngine:
                   stop_sequences=[[int(t) for t in seq] for seq in (stop_sequences or []) if len(seq)],
                   frequency_penalty=float(frequency_penalty), presence_penalty=float(presence_penalty),
                   on_tokens=on_tokens)
+        if self.failed is not None:
+            raise RuntimeError(f"the rollout engine has stopped ({self.failed})")
         with self._lock:
             if rid in self._waiters:
                 raise ValueError(f"duplicate request id {rid}")

@@ -318,7 +318,10 @@ class ModelRunner:
         tok, lp = ops.sample(logits, temp, top_k if filt else None, top_p if filt else None, self.seed,
                              self.step_counter, **pen)
         self._sync_tokens(tok, lp)
-        return tok.cpu().numpy(), lp.cpu().numpy()
+        tok_h, lp_h = tok.cpu().numpy(), lp.cpu().numpy()
+        if self.ipc_ar is not None:
+            self.ipc_ar.raise_if_error()
+        return tok_h, lp_h
 
     # ------------------------------------------------------------------ penalty count table
     def token_counts(self) -> "ops.TokenCounts":
@@ -383,6 +386,7 @@ class ModelRunner:
                                bt=torch.zeros(Bp, self.max_pages, dtype=torch.int32).pin_memory(),
                                out_tokens=torch.zeros(k, Bp, dtype=torch.int64).pin_memory(),
                                out_logprobs=torch.zeros(k, Bp, dtype=torch.float32).pin_memory(),
+                               ar_err=torch.zeros(1, dtype=torch.int32).pin_memory(),
                                done=torch.cuda.Event()) for _ in range(2)]
         return st
 
@@ -542,12 +546,17 @@ class ModelRunner:
         st["active"].zero_()
         st["penalty_slot"].fill_(-1)
         step_saved = self.step_counter.clone()
-        s = torch.cuda.Stream()
+        # (one side stream per runner, and waits on that stream only: a device-wide synchronisation would also wait
+        # for whatever other threads of the process - a colocated trainer - have queued)
+        if getattr(self, "_warm_stream", None) is None:
+            self._warm_stream = torch.cuda.Stream(device=self.device)
+        s = self._warm_stream
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._decode_body(st, filtered, penalized)
         torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
+        s.synchronize()
+        torch.cuda.current_stream().synchronize()
         for k, v in saved.items():
             st[k].copy_(v)
         g = torch.cuda.CUDAGraph()
@@ -679,6 +688,8 @@ class ModelRunner:
         if cuda:
             host["out_tokens"].copy_(st["out_tokens"], non_blocking=True)
             host["out_logprobs"].copy_(st["out_logprobs"], non_blocking=True)
+            if self.ipc_ar is not None:  # did every peer-memory all-reduce of this plan see its peers?
+                self.ipc_ar.read_error_async(host["ar_err"])
             host["done"].record()
             return dict(host=host)
         return dict(tokens=st["out_tokens"].numpy().copy(), logprobs=st["out_logprobs"].numpy().copy())
@@ -691,6 +702,11 @@ class ModelRunner:
         if host is None:
             return handle["tokens"], handle["logprobs"]
         host["done"].synchronize()
+        if int(host["ar_err"][0]) != 0:
+            from ..ops.ipc_allreduce import AllReduceTimeout
+
+            raise AllReduceTimeout("a tensor-parallel peer did not arrive in a decode plan's all-reduce: its tokens "
+                                   "are void")
         return host["out_tokens"].numpy(), host["out_logprobs"].numpy()
 
     def decode(self, plan: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray]:

@@ -114,6 +114,9 @@ class InferenceServer:
         r.add_post("/set_version", self.set_version)
 
     async def health(self, req):
+        failed = getattr(self.engine, "failed", None)
+        if failed is not None:
+            return web.Response(status=503, text=f"engine stopped: {failed}")
         return web.Response(text="OK")
 
     async def model_info(self, req):

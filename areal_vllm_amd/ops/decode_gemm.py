@@ -148,6 +148,50 @@ def dgemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
     return out
 
 
+def swiglu_plan(M: int, F: int) -> Optional[Tuple[int, int]]:
+    """-> (columns per workgroup, row blocks) of the balanced gate|up kernel for M rows and F gate columns, or None
+    where it has no instantiation: column ranges x row blocks as close to the number of CUs as the width allows
+    (a multiple of 4, at most 80 columns)."""
+    if M > 512 or F % 4 != 0:
+        return None
+    mblocks = 1 if M <= 256 else 2
+    target = max(1, N_CU // mblocks)
+    w = (-(-F // target) + 3) // 4 * 4
+    if w > 80:
+        return None
+    return w, mblocks
+
+
+def dgemm_swiglu_balanced(x: torch.Tensor, w_gate_up: torch.Tensor, out: Optional[torch.Tensor] = None, *,
+                          cols: Optional[int] = None, mblocks: Optional[int] = None, stages: int = 4,
+                          nt: bool = True) -> torch.Tensor:
+    """``silu(x @ gate.T) * (x @ up.T)`` with ``w_gate_up = [gate; up]`` ``[2F, K]`` -> bf16 ``[M, F]``, one workgroup
+    per CU: column ranges of ``cols`` columns each (``csrc/hip/decode_swiglu.hip``). Same rounding points as
+    ``dgemm(..., epilogue=EPI_SWIGLU)``."""
+    M, K = x.shape
+    F2 = w_gate_up.shape[0]
+    Fc = F2 // 2
+    if out is None:
+        out = torch.empty(M, Fc, dtype=x.dtype, device=x.device)
+    if not L.use_hip(x):
+        y = F.linear(x, w_gate_up)
+        y = y.to(x.dtype)
+        out.copy_((F.silu(y[:, :Fc].float()) * y[:, Fc:].float()).to(x.dtype))
+        return out
+    plan = swiglu_plan(M, Fc)
+    if cols is None or mblocks is None:
+        assert plan is not None, f"no balanced gate|up decomposition for M={M}, F={Fc}"
+        cols = plan[0] if cols is None else cols
+        mblocks = plan[1] if mblocks is None else mblocks
+    assert x.dtype == torch.bfloat16 and w_gate_up.dtype == torch.bfloat16 and x.stride(1) == 1
+    assert w_gate_up.is_contiguous() and out.stride(1) == 1 and K % 64 == 0
+    L.check(L.lib().areal_dswiglu(L.ptr(x), L.c_int64(x.stride(0)), L.ptr(w_gate_up), L.ptr(out),
+                                  L.c_int64(out.stride(0)), L.c_int(M), L.c_int(Fc), L.c_int(K), L.c_int(int(cols)),
+                                  L.c_int(int(mblocks)), L.c_int(int(stages)), L.c_int(int(bool(nt))), L.stream_ptr()),
+            "dswiglu")
+    return out
+
+
 def splitk_residual_rmsnorm(slab: torch.Tensor, n_split: int, M: int, N: int, *, bias: Optional[torch.Tensor] = None,
                             residual: Optional[torch.Tensor] = None, weight: Optional[torch.Tensor] = None,
                             eps: float = 1e-6, gemma: bool = False, res_out: Optional[torch.Tensor] = None,

@@ -27,6 +27,14 @@ MAX_RANKS = 8
 # bytes over the links as one-shot and only adds a flag round trip)
 TWO_SHOT_MIN_BYTES = int(os.environ.get("AREAL_AR_TWO_SHOT_BYTES", 1 << 20))
 TWO_SHOT_MIN_RANKS = 4
+# seconds a kernel waits for a peer's flag before it raises the error word (a host stall of a few seconds on one rank,
+# e.g. a follower that is late to launch its plan, must not trip it)
+TIMEOUT_S = float(os.environ.get("AREAL_AR_TIMEOUT_S", "60"))
+
+
+class AllReduceTimeout(RuntimeError):
+    """A peer did not arrive within the time limit: the data of the affected call (and everything computed from it)
+    is garbage, the ranks' sequence numbers may have diverged. The engine that owns the group must stop."""
 
 
 class IpcAllReduce:
@@ -38,11 +46,22 @@ class IpcAllReduce:
         self.cap = (int(max_elems) + 7) // 8 * 8
         lib = L.lib()
         lib.areal_ipc_allreduce_region_bytes.restype = ctypes.c_long
+        lib.areal_ipc_allreduce_state_offset.restype = ctypes.c_long
+        lib.areal_ipc_allreduce_set_timeout.restype = None
+        lib.areal_ipc_allreduce_set_timeout(ctypes.c_double(TIMEOUT_S))
+        self.uncached = True
         self.nbytes = int(lib.areal_ipc_allreduce_region_bytes(ctypes.c_long(self.cap)))
         with torch.cuda.device(device):
             p = ctypes.c_void_p(0)
             # uncached: peers store into this region (flags, result slots) while this device's kernels read it
             if lib.areal_ipc_alloc_uncached(ctypes.c_long(self.nbytes), ctypes.byref(p)) != 0:
+                # ordinary memory: a peer's stores are not guaranteed to be seen through this device's L2. The
+                # start-up self-check decides whether the kernel may be used at all; say so either way
+                import logging
+
+                logging.getLogger("ipc-allreduce").warning(
+                    "uncached device memory is unavailable: the peer-memory all-reduce region is an ordinary allocation")
+                self.uncached = False
                 p = ctypes.c_void_p(0)
                 L.check(lib.areal_ipc_alloc(ctypes.c_long(self.nbytes), ctypes.byref(p)), "ipc_alloc")
             self._ptr = p.value
@@ -104,15 +123,28 @@ class IpcAllReduce:
         dist.all_gather_object(votes, ok, group=self.group)
         return all(votes)
 
+    def _error_word_ptr(self) -> int:
+        return self._ptr + int(L.lib().areal_ipc_allreduce_state_offset(ctypes.c_long(self.cap))) + 8  # third state word
+
     def error(self) -> bool:
         """True if a call gave up waiting for a peer (its result is then garbage). Synchronises the stream."""
         word = torch.empty(1, dtype=torch.int32, device=self.device)
-        lib = L.lib()
-        lib.areal_ipc_allreduce_state_offset.restype = ctypes.c_long
-        off = int(lib.areal_ipc_allreduce_state_offset(ctypes.c_long(self.cap))) + 8  # third state word
-        L.check(L.lib().areal_memcpy_d2d_async(ctypes.c_void_p(word.data_ptr()), ctypes.c_void_p(self._ptr + off),
+        L.check(L.lib().areal_memcpy_d2d_async(ctypes.c_void_p(word.data_ptr()), ctypes.c_void_p(self._error_word_ptr()),
                                                ctypes.c_long(4), L.stream_ptr()), "memcpy_d2d_async")
         return bool(word.item())
+
+    def read_error_async(self, pinned: torch.Tensor):
+        """Queue a copy of the error word into `pinned` (int32[1], pinned host memory) on the current stream: whoever
+        waits for the work queued so far (a decode plan's completion event) then reads it without another
+        synchronisation."""
+        assert pinned.dtype == torch.int32 and pinned.is_pinned()
+        L.check(L.lib().areal_memcpy_async(ctypes.c_void_p(pinned.data_ptr()), ctypes.c_void_p(self._error_word_ptr()),
+                                           ctypes.c_long(4), L.stream_ptr()), "memcpy_async")
+
+    def raise_if_error(self):
+        if self.error():
+            raise AllReduceTimeout("tensor-parallel all-reduce: a peer did not arrive within "
+                                   f"{TIMEOUT_S:.0f} s (AREAL_AR_TIMEOUT_S)")
 
     def close(self):
         for b in self._mapped:

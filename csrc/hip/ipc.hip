@@ -63,6 +63,14 @@ extern "C" int areal_ipc_close(void* base) {
   return 0;
 }
 
+// Copy between any two addresses of the unified address space (device, peer-mapped or pinned host memory): the
+// runtime works out the direction.
+extern "C" int areal_memcpy_async(void* dst, const void* src, long bytes, hipStream_t st) {
+  if (bytes <= 0) return 0;
+  IPC_RET(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDefault, st));
+  return 0;
+}
+
 extern "C" int areal_memcpy_d2d_async(void* dst, const void* src, long bytes, hipStream_t st) {
   if (bytes <= 0) return 0;
   IPC_RET(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, st));

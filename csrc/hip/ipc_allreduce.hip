@@ -14,8 +14,8 @@
 // closing barrier: slot s & 1 is rewritten by call s + 2, which starts after this rank's call s + 1 has seen every peer's
 // flag s + 1, i.e. after every peer has finished call s (stream order on the peer). The sequence number lives in device
 // memory and is advanced by the last workgroup to finish, so a captured graph replays correctly.
-// A peer that never arrives makes the spin give up after a few seconds and raises the region's error word instead of hanging
-// the device.
+// A peer that has not arrived within the time limit (60 s by default) makes the wait give up and raises the region's error
+// word instead of hanging the device; the host checks that word with every plan.
 //
 // Two-shot (ipc_allreduce_two_shot_kernel): after step 3 workgroup b of rank r sums only the r-th of the nranks parts of
 // chunk b, writes the rounded sums into the RESULT slot of every rank (16-byte stores over xGMI), publishes s in flags2, waits
@@ -37,11 +37,26 @@ struct ArPeers {
   int* flags[AR_MAX_RANKS];          // base of every rank's flag table
 };
 
+
+// Wait until `*f` has reached `seq` (a peer's release store), at most `timeout_ticks` of the 100 MHz wall clock: a peer
+// that never arrives raises the region's error word instead of hanging the device. The caller's result is garbage then;
+// the host reads the error word with every plan and fails the engine (ops/ipc_allreduce.py).
+DEVINL void wait_flag(const int* f, unsigned seq, unsigned* state, long timeout_ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (int)seq) < 0) {
+    __builtin_amdgcn_s_sleep(16);
+    if ((long)(__builtin_amdgcn_s_memrealtime() - t0) > timeout_ticks) {
+      atomicExch(&state[2], 1u);
+      break;
+    }
+  }
+}
+
 // state: [0] sequence number of the last completed call, [1] finished-workgroup ticket, [2] error word
 __global__ __launch_bounds__(AR_THREADS) void ipc_allreduce_kernel(ArPeers peers, bf16_t* my_data, int* my_flags,
                                                                   unsigned* state, const bf16_t* __restrict__ in,
                                                                   bf16_t* __restrict__ out, long n, long cap, int nranks,
-                                                                  int rank) {
+                                                                  int rank, long timeout_ticks) {
   const int tid = threadIdx.x, b = blockIdx.x;
   const unsigned seq = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   const int slot = (int)(seq & 1u);
@@ -68,15 +83,7 @@ __global__ __launch_bounds__(AR_THREADS) void ipc_allreduce_kernel(ArPeers peers
     __hip_atomic_store(peers.flags[tid] + fidx + rank * AR_MAX_BLOCKS, (int)seq, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   if (tid < nranks) {
-    const int* f = my_flags + fidx + tid * AR_MAX_BLOCKS;
-    long spins = 0;
-    while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (int)seq) < 0) {
-      __builtin_amdgcn_s_sleep(16);
-      if (++spins > (1L << 21)) {  // the peer is gone: report, do not hang
-        atomicExch(&state[2], 1u);
-        break;
-      }
-    }
+    wait_flag(my_flags + fidx + tid * AR_MAX_BLOCKS, seq, state, timeout_ticks);
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -112,21 +119,13 @@ __global__ __launch_bounds__(AR_THREADS) void ipc_allreduce_kernel(ArPeers peers
 }
 // Lanes 0 .. nranks-1 of the workgroup: publish `seq` in every peer's flag table, then wait for every peer's flag in mine.
 DEVINL void signal_and_wait(int* const* peer_flags, int* my_flags, int fidx, int rank, int nranks, unsigned seq,
-                            unsigned* state) {
+                            unsigned* state, long timeout_ticks) {
   const int tid = threadIdx.x;
   if (tid < nranks)
     __hip_atomic_store(peer_flags[tid] + fidx + rank * AR_MAX_BLOCKS, (int)seq, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   if (tid < nranks) {
-    const int* f = my_flags + fidx + tid * AR_MAX_BLOCKS;
-    long spins = 0;
-    while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (int)seq) < 0) {
-      __builtin_amdgcn_s_sleep(16);
-      if (++spins > (1L << 21)) {  // the peer is gone: report, do not hang
-        atomicExch(&state[2], 1u);
-        break;
-      }
-    }
+    wait_flag(my_flags + fidx + tid * AR_MAX_BLOCKS, seq, state, timeout_ticks);
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
@@ -142,7 +141,7 @@ struct ArPeers2 {
 __global__ __launch_bounds__(AR_THREADS) void ipc_allreduce_two_shot_kernel(ArPeers2 peers, unsigned* state,
                                                                            const bf16_t* __restrict__ in,
                                                                            bf16_t* __restrict__ out, long n, long cap,
-                                                                           int nranks, int rank) {
+                                                                           int nranks, int rank, long timeout_ticks) {
   const int tid = threadIdx.x, b = blockIdx.x;
   const unsigned seq = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
   const int slot = (int)(seq & 1u);
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(AR_THREADS) void ipc_allreduce_two_shot_kernel(ArPe
   __threadfence_system();
   __syncthreads();
   const int fidx = (slot * AR_MAX_RANKS) * AR_MAX_BLOCKS + b;
-  signal_and_wait(peers.flags1, peers.flags1[rank], fidx, rank, nranks, seq, state);
+  signal_and_wait(peers.flags1, peers.flags1[rank], fidx, rank, nranks, seq, state, timeout_ticks);
   // reduce-scatter: this rank's part of the chunk, summed in rank order, pushed into every rank's result slot
   const long part = (v1 - v0 + nranks - 1) / nranks;
   const long p0 = v0 + rank * part < v1 ? v0 + rank * part : v1;
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(AR_THREADS) void ipc_allreduce_two_shot_kernel(ArPe
   }
   __threadfence_system();
   __syncthreads();
-  signal_and_wait(peers.flags2, peers.flags2[rank], fidx, rank, nranks, seq, state);
+  signal_and_wait(peers.flags2, peers.flags2[rank], fidx, rank, nranks, seq, state, timeout_ticks);
   // all-gather: every part of the chunk has landed in this rank's result slot
   const bf16_t* res = peers.result[rank] + (long)slot * cap;
   for (long v = v0 + tid; v < v1; v += AR_THREADS) {
@@ -223,6 +222,13 @@ struct ArLayout {
 };
 }  // namespace
 
+// how long a workgroup waits for a peer before it raises the error word, in ticks of the 100 MHz wall clock
+static long g_ar_timeout_ticks = 60L * 100000000L;
+extern "C" void areal_ipc_allreduce_set_timeout(double seconds) {
+  g_ar_timeout_ticks = (long)(seconds * 1e8);
+  if (g_ar_timeout_ticks < 1000) g_ar_timeout_ticks = 1000;
+}
+
 extern "C" long areal_ipc_allreduce_region_bytes(long cap_elems) { return ArLayout(cap_elems).total; }
 // offset of the state words (sequence number, ticket, error word) inside a region
 extern "C" long areal_ipc_allreduce_state_offset(long cap_elems) { return ArLayout(cap_elems).state; }
@@ -250,7 +256,7 @@ extern "C" int areal_ipc_allreduce(const void* in, void* out, long n, void* cons
   if (blocks < 1) blocks = 1;
   if (blocks > AR_MAX_BLOCKS) blocks = AR_MAX_BLOCKS;
   hipLaunchKernelGGL(ipc_allreduce_kernel, dim3((unsigned)blocks), dim3(AR_THREADS), 0, st, peers, (bf16_t*)mine, my_flags,
-                     state, (const bf16_t*)in, (bf16_t*)out, n, cap_elems, nranks, rank);
+                     state, (const bf16_t*)in, (bf16_t*)out, n, cap_elems, nranks, rank, g_ar_timeout_ticks);
   return (int)hipGetLastError();
 }
 
@@ -277,6 +283,6 @@ extern "C" int areal_ipc_allreduce_two_shot(const void* in, void* out, long n, v
   if (blocks < 1) blocks = 1;
   if (blocks > AR_MAX_BLOCKS) blocks = AR_MAX_BLOCKS;
   hipLaunchKernelGGL(ipc_allreduce_two_shot_kernel, dim3((unsigned)blocks), dim3(AR_THREADS), 0, st, peers, state,
-                     (const bf16_t*)in, (bf16_t*)out, n, cap_elems, nranks, rank);
+                     (const bf16_t*)in, (bf16_t*)out, n, cap_elems, nranks, rank, g_ar_timeout_ticks);
   return (int)hipGetLastError();
 }

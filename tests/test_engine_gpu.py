@@ -5,6 +5,7 @@ the driver's smoke entry. Mirrors ``areal/tests/test_train_engine.py``,
 ``test_packed_vs_padded_consistency.py`` and ``test_sglang_engine.py`` of the reference."""
 import math
 import os
+import time
 import sys
 
 import pytest
@@ -788,6 +789,68 @@ def test_tp2_serving_on_one_gpu_with_peer_memory_all_reduce(tmp_path):
         assert la == pytest.approx(lb, abs=1e-6)
 
 
+def _tp_stalled_peer_worker(rank, port, out_path):
+    import argparse
+    import json
+
+    os.environ.update(GLOO_SOCKET_IFNAME="lo", AREAL_TP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      AREAL_CUSTOM_ALL_REDUCE="1", AREAL_PIPELINE_DECODE="0", AREAL_AR_TIMEOUT_S="2")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from areal_vllm_amd.api.cli_args import InferenceServerConfig
+    from areal_vllm_amd.inference.tp_worker import build_tp_engine
+
+    cfg = InferenceServerConfig(model_path="tiny", dtype="bfloat16", context_length=256, max_running_requests=8,
+                                num_continuous_decode_steps=2, random_seed=7, disable_cuda_graph=True)
+    args = argparse.Namespace(tp_size=2, base_gpu_id=0, device="cuda", num_pages=64, kv_cache_gb=None)
+    eng = build_tp_engine(args, cfg, rank, f"127.0.0.1:{port}", initialize=False)
+    eng.initialize(load_weights=False)
+    assert eng.runner.ipc_ar is not None
+    if rank > 0:
+        # a peer that stops launching its plans (a stalled host, a dead process whose sockets are still open):
+        # it takes the prefill, then never runs the first decode plan
+        real = eng.runner.decode_launch
+        eng.runner.decode_launch = lambda plan: time.sleep(3600)
+        eng.run_follower()
+        return
+    t0 = time.time()
+    res = eng.generate_blocking([[5, 6, 7, 8, 9], [11, 12, 13]], max_new_tokens=40, greedy=True)
+    took = time.time() - t0
+    refused = False
+    try:
+        eng.submit("after", [1, 2, 3], max_new_tokens=4)
+    except RuntimeError:
+        refused = True
+    with open(out_path, "w") as f:
+        json.dump(dict(reasons=[r.finish_reason for r in res], failed=eng.failed, took=took, refused=refused), f)
+    os._exit(0)  # the follower never answers a shutdown broadcast
+
+
+def test_tp2_engine_stops_instead_of_decoding_garbage_when_a_peer_stalls(tmp_path):
+    """The peer-memory all-reduce gives up on a peer that does not arrive (2 s here); the leader sees the error word
+    with the plan's tokens, ends the running requests as aborted, refuses new ones and reports why."""
+    import json
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "out.json")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_tp_stalled_peer_worker, args=(r, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    procs[0].join(150)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert procs[0].exitcode == 0, procs[0].exitcode
+    got = json.load(open(out))
+    assert got["reasons"] == ["abort", "abort"] and got["refused"]
+    assert "AllReduceTimeout" in got["failed"] and got["took"] < 60
+
+
 # ------------------------------------------------------------------ multi-rank layouts on ONE GPU
 _LAYOUT_LENS = [257, 64, 300, 129, 33, 512, 77, 90]
 
@@ -834,7 +897,8 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
     ev = float(eng.eval_batch(local, _sft_loss, _weight))
     fw = eng.forward(local, post_hook=_logp_hook).float().cpu()
     if dp > 1 and eng.grid.pp == 1 and eng.zero3 is None and eng.expert_optimizer is None:
-        assert eng.optimizer.overlapped_buckets >= len(eng.optimizer.buckets)  # the bucketed reduce ran on the device
+        assert len(eng.optimizer.buckets) > 1
+        assert eng.optimizer.overlapped_buckets >= 2 * (len(eng.optimizer.buckets) - 1)  # bucketed reduce during backward
     torch.save(dict(norms=norms, ev=ev, fw=fw, dpr=dpr), f"{out_path}.r{rank}")
     eng.destroy()
 

@@ -57,6 +57,37 @@ def test_frequency_penalty_suppresses_repeats(eng):
     assert again.output_tokens == pen.output_tokens
 
 
+def test_penalty_row_reused_while_the_batch_is_full_starts_from_zero():
+    """A penalised request that arrives while the batch is at max_running_requests gets its count row attached to a
+    CONTINUATION plan (no prefill is possible): the row must be zeroed there too, or the request samples with its
+    previous owner's counts."""
+    e = _engine(max_running=2, decode_steps=2)
+    try:
+        first = _greedy(e, n=40, frequency_penalty=1000.0)  # leaves counts behind in its row
+        started = threading.Event()
+        results = {}
+        done = threading.Event()
+
+        def cb(name):
+            def f(res):
+                results[name] = res
+                if len(results) == 3:
+                    done.set()
+            return f
+
+        for i in range(2):  # fill the batch with unpenalised requests
+            e.submit(f"fill-{i}", [11 + i, 3, 90, 41], max_new_tokens=120, greedy=True, callback=cb(f"fill-{i}"),
+                     on_tokens=lambda *a: started.set())
+        assert started.wait(60)  # decode plans are in flight now, every further plan is a continuation
+        before = e.stats["pipelined_plans"]
+        e.submit("late", PROMPT, max_new_tokens=40, greedy=True, frequency_penalty=1000.0, callback=cb("late"))
+        assert done.wait(120)
+        assert e.stats["pipelined_plans"] > before
+        assert results["late"].output_tokens == first.output_tokens
+    finally:
+        e.destroy()
+
+
 def test_mild_penalty_shifts_the_reported_logprob(eng):
     base = _greedy(eng, n=32)
     first_repeat = next(i for i, t in enumerate(base.output_tokens) if t in base.output_tokens[:i])

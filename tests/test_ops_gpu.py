@@ -8,6 +8,7 @@ import math
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import areal_vllm_amd.ops as ops
 from areal_vllm_amd.ops import attention as A
@@ -906,6 +907,39 @@ def test_dgemm_qkv_rope_matches_unfused(Hq, Hkv, D, K, cfg, lw, T):
         _close(q, qkv[:, :Hq], 3e-2, 2e-2, f"q cfg={cfg} stages={stages}")
         _close(kc, kc2, 3e-2, 2e-2, f"k cache cfg={cfg} stages={stages}")
         _close(vc, vc2, 3e-2, 2e-2, f"v cache cfg={cfg} stages={stages}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Fc,K,cols,mblocks", [
+    (256, 8960, 1536, 36, 1),   # Qwen2-1.5B decode: 249 workgroups
+    (384, 8960, 1536, 72, 2),   # two row blocks of 192 rows, ranges paired on one XCD
+    (512, 8960, 1536, 72, 2),
+    (100, 8960, 1536, 36, 1),   # ragged rows
+    (130, 1000, 256, 44, 1),    # last range narrower than the others, few K steps
+    (300, 1000, 256, 20, 2),    # more blocks than ranges need (rounded up to the XCD pairing)
+    (256, 18944, 3584, 76, 1),  # Qwen2.5-7B shapes: five 16-column tiles per half
+    (64, 128, 64, 4, 1),        # a single K step, the narrowest range
+])
+def test_balanced_swiglu_gemm_matches_fp32(M, Fc, K, cols, mblocks):
+    """gate|up GEMM + SwiGLU with one column range of arbitrary width per workgroup (decode_swiglu.hip) against
+    fp32, with the rounding points of the unfused bf16 path, for every instantiated row-tile / column-tile count."""
+    from areal_vllm_amd.ops import decode_gemm as DG
+
+    torch.manual_seed(M + Fc)
+    dev = torch.device("cuda")
+    x = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(2 * Fc, K, device=dev) * (1.0 / K ** 0.5)).bfloat16()
+    y = x.float() @ w.float().t()
+    y = y.bfloat16().float()
+    want = F.silu(y[:, :Fc]) * y[:, Fc:]
+    for stages in (2, 3, 4):
+        out = torch.full((M + 3, Fc), float("nan"), dtype=torch.bfloat16, device=dev)
+        DG.dgemm_swiglu_balanced(x, w, out[:M], cols=cols, mblocks=mblocks, stages=stages)
+        assert torch.isnan(out[M:].float()).all()  # rows past M untouched
+        _close(out[:M], want, 3e-2, 2e-2, f"stages={stages}")
+    plan = DG.swiglu_plan(M, Fc)
+    if plan is not None:
+        _close(DG.dgemm_swiglu_balanced(x, w), want, 3e-2, 2e-2, "default plan")
 
 
 def _ipc_allreduce_worker(rank, world, port, out_dir):
