@@ -92,7 +92,7 @@ class ModelRunner:
         if fused_decode is None:
             fused_decode = self.device.type == "cuda" and os.environ.get("AREAL_FUSED_DECODE", "1") != "0"
         self.fused_decode = bool(fused_decode) and fusable
-        self._gate_up_choice: Dict[int, bool] = {}  # batch bucket -> fused gate|up GEMM wins (timed once)
+        self._gate_up_choice: Dict[int, str] = {}  # batch bucket -> fastest gate|up kernel (timed once)
         # qkv projection with bias + RoPE + KV-cache write in its epilogue (head sizes that are multiples of 64)
         self.fused_qkv_rope = cfg.head_dim % 64 == 0 and os.environ.get("AREAL_FUSED_QKV_ROPE", "1") != "0"
 
@@ -237,8 +237,11 @@ class ModelRunner:
     def _sync_tokens(self, tok: torch.Tensor, lp: torch.Tensor):
         """Tensor-parallel ranks sample from identical logits with identical Philox keys; broadcasting the
         leader's draw (a few hundred bytes per step) makes agreement unconditional, so a rounding
-        difference between ranks can never fork the KV caches."""
-        if self.model.tp_size > 1:
+        difference between ranks can never fork the KV caches. With the peer-memory all-reduce the broadcast is
+        left out: that kernel sums every rank's data in rank order on every rank, so the ranks hold bit-identical
+        activations by construction, and a decode plan then contains no collective that could wait for a missing
+        peer without a time limit."""
+        if self.model.tp_size > 1 and self.ipc_ar is None:
             import torch.distributed as dist
 
             src = dist.get_global_rank(self.model.tp_group, 0) if self.model.tp_group is not None else 0
@@ -272,7 +275,7 @@ class ModelRunner:
         cu_q = torch.from_numpy(plan["cu_q"]).to(dev, non_blocking=True)
         cu_k = torch.from_numpy(plan["cu_k"]).to(dev, non_blocking=True)
         has_prefix = bool(plan["has_prefix"])
-        ctx_slots = torch.from_numpy(plan["ctx_slots"]).to(dev, non_blocking=True) if has_prefix else None
+        bt = torch.from_numpy(plan["block_tables"]).to(dev, non_blocking=True) if has_prefix else None
         max_q = int(plan["max_q"])
         B = len(plan["req_ids"])
         T = ids.numel()
@@ -296,9 +299,8 @@ class ModelRunner:
                 qkv = qkv2d.view(T, hq + 2 * hkv, D)
                 ops.rope_and_cache_write_(qkv, pos, slots, rope, kc, vc, hq, hkv)
                 q = qkv[:, :hq]
-                if has_prefix:
-                    k, v = ops.cache_gather(kc, vc, ctx_slots)
-                    out, _ = ops.flash_attn_varlen(q, k, v, cu_q, cu_k, max_q)
+                if has_prefix:  # some row has context in the cache: attention reads the pages directly
+                    out = ops.flash_attn_paged_prefill(q, kc, vc, bt, cu_q, cu_k, max_q)
                 else:
                     out, _ = ops.flash_attn_varlen(q, qkv[:, hq:hq + hkv], qkv[:, hq + hkv:], cu_q, cu_q, max_q)
                 return out
@@ -398,36 +400,40 @@ class ModelRunner:
         if self.fused_decode and self.device.type == "cuda":
             for b in self.buckets:
                 if b >= self.FUSED_MIN_BATCH:
-                    self._gate_up_fused(b)
+                    self._gate_up_mode(b)
 
-    def _gate_up_fused(self, Bp: int) -> bool:
-        """Does the widest GEMM of the layer (gate|up with the SwiGLU epilogue) beat the library GEMM followed by
-        the activation kernel at this batch bucket? Depends on the model's shapes (Qwen2-1.5B: fused up to 384 rows;
-        Qwen2.5-7B: only up to ~128), so it is timed once per bucket on the model's own weights, rotating over
-        the layers so that neither arm streams from a warm cache. The other three GEMMs stay fused either way."""
+    def _gate_up_mode(self, Bp: int) -> str:
+        """Which kernel runs the widest GEMM of the layer (gate|up + SwiGLU) at this batch bucket: "balanced" (one
+        column range per CU, ``decode_swiglu.hip``), "tiled" (``decode_gemm.hip`` with the SwiGLU epilogue) or
+        "library" (library GEMM followed by the activation kernel). Depends on the model's shapes (the hand-written
+        kernels win where the GEMM waits for its loads: Qwen2-1.5B at every bucket; compute-bound shapes such as
+        Qwen2.5-7B from ~128 rows on go to the library), so the candidates are timed once per bucket on the model's
+        own weights, rotating over the layers so that no arm streams from a warm cache. The other three GEMMs stay
+        fused either way."""
         if Bp in self._gate_up_choice:
             return self._gate_up_choice[Bp]
         from ..ops import decode_gemm as dg
 
+        has_plan = dg.swiglu_plan(Bp, self.cfg.intermediate_size // max(1, self.model.tp_size)) is not None
         forced = os.environ.get("AREAL_FUSED_GATE_UP")
         if forced is not None or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
-            self._gate_up_choice[Bp] = forced != "0" if forced is not None else True
-            return self._gate_up_choice[Bp]
+            mode = {"0": "library", "1": "tiled"}.get(forced or "", "balanced" if has_plan else "tiled")
+            if mode == "balanced" and not has_plan:
+                mode = "tiled"
+            self._gate_up_choice[Bp] = mode
+            return mode
         layers = self.model.layers
         x = torch.randn(Bp, self.cfg.hidden_size, device=self.device, dtype=self.dtype)
-
-        def fused(i):
-            return dg.dgemm(x, layers[i % len(layers)].mlp.gate_up, epilogue=dg.EPI_SWIGLU)
-
-        def library(i):
-            blk = layers[i % len(layers)]
-            return ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)
-
-        times = []
-        for fn in (fused, library):
+        arms = {"tiled": lambda i: dg.dgemm(x, layers[i % len(layers)].mlp.gate_up, epilogue=dg.EPI_SWIGLU),
+                "library": lambda i: ops.swiglu(F.linear(x, layers[i % len(layers)].mlp.gate_up),
+                                                layers[i % len(layers)].mlp.act)}
+        if has_plan:
+            arms["balanced"] = lambda i: dg.dgemm_swiglu_balanced(x, layers[i % len(layers)].mlp.gate_up)
+        times = {}
+        for name, fn in arms.items():
             for i in range(2):
                 fn(i)
-            torch.cuda.synchronize(self.device)
+            torch.cuda.current_stream().synchronize()
             best = float("inf")
             n = max(8, len(layers))
             for _ in range(3):  # the smallest of three: other work on the device (a colocated trainer) only adds time
@@ -438,11 +444,12 @@ class ModelRunner:
                 e1.record()
                 e1.synchronize()
                 best = min(best, e0.elapsed_time(e1) / n)
-            times.append(best)
-        self._gate_up_choice[Bp] = times[0] <= times[1]
-        logger.info(f"decode batch bucket {Bp}: gate|up GEMM fused {times[0] * 1e3:.1f} us vs library + activation "
-                    f"{times[1] * 1e3:.1f} us -> {'fused' if self._gate_up_choice[Bp] else 'library'}")
-        return self._gate_up_choice[Bp]
+            times[name] = best
+        mode = min(times, key=times.get)
+        self._gate_up_choice[Bp] = mode
+        logger.info(f"decode batch bucket {Bp}: gate|up GEMM " + ", ".join(f"{k} {v * 1e3:.1f} us" for k, v in times.items())
+                    + f" -> {mode}")
+        return mode
 
     def _decode_layers_fused(self, st: Dict[str, torch.Tensor], h: torch.Tensor, rope_pos: torch.Tensor):
         """All decoder layers of one decode step on the fused path -> final-normed hidden states [Bp, H].
@@ -458,7 +465,7 @@ class ModelRunner:
         Bp, H = h.shape
         eps, gemma = cfg.rms_norm_eps, cfg.gemma_norm
         layers = self.model.layers
-        gate_up_fused = self._gate_up_fused(Bp)
+        gate_up_mode = self._gate_up_mode(Bp)
         x, residual = ops.rmsnorm(h, layers[0].ln1, eps, None, gemma)
         for li, blk in enumerate(layers):
             kc, vc = self.kv[li]
@@ -474,7 +481,9 @@ class ModelRunner:
             slab = dg.dgemm(attn.view(Bp, hq * D), blk.attn.o, epilogue=dg.EPI_SLAB)
             x, residual = dg.splitk_residual_rmsnorm(slab, slab.shape[0], Bp, H, residual=residual, weight=blk.ln2,
                                                      eps=eps, gemma=gemma, dtype=self.dtype)
-            if gate_up_fused:
+            if gate_up_mode == "balanced":
+                act = dg.dgemm_swiglu_balanced(x, blk.mlp.gate_up)
+            elif gate_up_mode == "tiled":
                 act = dg.dgemm(x, blk.mlp.gate_up, epilogue=dg.EPI_SWIGLU)
             else:
                 act = ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)

@@ -5,6 +5,8 @@ from .attention import (  # noqa: F401
     DecodeWorkspace,
     alloc_kv_cache,
     cache_gather,
+    context_slots,
+    flash_attn_paged_prefill,
     decode_num_splits,
     flash_attn_varlen,
     flash_attn_varlen_qkv,

@@ -326,6 +326,41 @@ def cache_gather(kcache, vcache, slots):
     return kcache[pg, :, off, :].contiguous(), vcache[pg, :, :, off].contiguous()
 
 
+def context_slots(block_tables: torch.Tensor, cu_k: torch.Tensor) -> torch.Tensor:
+    """Cache slot of every context token of every request, request after request (int64 [cu_k[-1]]): token t of
+    request b lives in page ``block_tables[b, t // 32]``."""
+    lens = (cu_k[1:] - cu_k[:-1]).long()
+    seq = torch.repeat_interleave(torch.arange(lens.numel(), device=cu_k.device), lens)
+    t = torch.arange(int(lens.sum()), device=cu_k.device) - cu_k[:-1].long()[seq]
+    return block_tables.long()[seq, t // PAGE_SIZE] * PAGE_SIZE + t % PAGE_SIZE
+
+
+def flash_attn_paged_prefill(q, kcache, vcache, block_tables, cu_q, cu_k, max_q: int, scale: Optional[float] = None,
+                             causal: bool = True) -> torch.Tensor:
+    """Attention of prefill queries ``q [T, Hq, D]`` (request b owns rows cu_q[b]:cu_q[b+1]) over their requests'
+    whole contexts in the paged cache (``cu_k``: cumulative context lengths, query rows included - their K/V must
+    have been written already; ``block_tables [B, max_pages]`` int32), causal mask aligned bottom-right. Head size
+    128 runs ``csrc/hip/flash_attn_paged.hip`` straight on the pages; other head sizes and CPU tensors gather the
+    context into contiguous tensors first. Role in the reference: ``flash_attn_with_kvcache``
+    (``realhf/impl/model/modules/attn.py:272``) / the serving engine's radix-cache prefill."""
+    T, Hq, D = q.shape
+    Hkv = kcache.shape[1]
+    scale = float(scale) if scale is not None else 1.0 / math.sqrt(D)
+    if L.use_hip(q) and D == 128 and q.dtype == torch.bfloat16 and q.stride(2) == 1 and q.stride(1) == D:
+        assert block_tables.dtype == torch.int32 and block_tables.is_contiguous()
+        assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
+        out = torch.empty(T, Hq, D, dtype=q.dtype, device=q.device)
+        L.check(L.lib().areal_flash_fwd_paged(
+            L.ptr(q), L.ptr(kcache), L.ptr(vcache), L.ptr(block_tables), L.c_int(block_tables.shape[1]), L.ptr(out),
+            None, L.ptr(cu_q), L.ptr(cu_k), L.c_int(cu_q.numel() - 1), L.c_int(int(max_q)), L.c_int(T), L.c_int(Hq),
+            L.c_int(Hkv), L.c_int(D), L.c_int64(q.stride(0)), L.c_int64(out.stride(0)), L.c_float(scale),
+            L.c_int(int(causal)), L.stream_ptr()), "flash_fwd_paged")
+        return out
+    k, v = cache_gather(kcache, vcache, context_slots(block_tables, cu_k))
+    out, _ = flash_attn_varlen(q, k, v, cu_q, cu_k, max_q, scale=scale, causal=causal)
+    return out
+
+
 def paged_decode_ref(q, kcache, vcache, block_tables, context_lens, scale):
     B, Hq, D = q.shape
     Hkv = kcache.shape[1]

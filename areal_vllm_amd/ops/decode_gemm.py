@@ -150,16 +150,18 @@ def dgemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
 
 def swiglu_plan(M: int, F: int) -> Optional[Tuple[int, int]]:
     """-> (columns per workgroup, row blocks) of the balanced gate|up kernel for M rows and F gate columns, or None
-    where it has no instantiation: column ranges x row blocks as close to the number of CUs as the width allows
-    (a multiple of 4, at most 80 columns)."""
+    where it has no instantiation. A workgroup stages (rows per block + 2 x columns) rows of K elements and the launch
+    takes about 7 us + 0.065 us per staged row at K = 1536 (``profiles/swiglu_probe_s1.log``), so with row blocks x
+    column ranges fixed at the number of CUs the best split has about twice as many block rows as columns: two row
+    blocks from 129 rows on, ranges as narrow as fill the chip (a multiple of 4, at most 80 columns)."""
     if M > 512 or F % 4 != 0:
         return None
-    mblocks = 1 if M <= 256 else 2
-    target = max(1, N_CU // mblocks)
-    w = (-(-F // target) + 3) // 4 * 4
-    if w > 80:
-        return None
-    return w, mblocks
+    for mblocks in ((2, 1) if 128 < M <= 256 else ((1,) if M <= 128 else (2,))):
+        target = max(1, N_CU // mblocks)
+        w = (-(-F // target) + 3) // 4 * 4
+        if w <= 80:
+            return w, mblocks
+    return None
 
 
 def dgemm_swiglu_balanced(x: torch.Tensor, w_gate_up: torch.Tensor, out: Optional[torch.Tensor] = None, *,

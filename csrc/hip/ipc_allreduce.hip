@@ -43,6 +43,9 @@ struct ArPeers {
 // the host reads the error word with every plan and fails the engine (ops/ipc_allreduce.py).
 DEVINL void wait_flag(const int* f, unsigned seq, unsigned* state, long timeout_ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  // once a call has given up, the calls queued behind it (the rest of a decode plan) do not wait again: the peer
+  // is gone, and every one of them waiting out the limit would hold the device for hours
+  if (__hip_atomic_load(&state[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) timeout_ticks = 0;
   while ((int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - (int)seq) < 0) {
     __builtin_amdgcn_s_sleep(16);
     if ((long)(__builtin_amdgcn_s_memrealtime() - t0) > timeout_ticks) {

@@ -45,7 +45,12 @@ static py::dict plan_to_dict(const Plan& p) {
     d["max_q"] = p.max_q;
     d["max_k"] = p.max_k;
     d["has_prefix"] = p.has_prefix;
-    d["ctx_slots"] = to_np(p.ctx_slots);
+    if (p.has_prefix) {
+      d["max_pages"] = p.max_pages;
+      py::array_t<int32_t> bt({(py::ssize_t)p.req_ids.size(), (py::ssize_t)p.max_pages});
+      std::memcpy(bt.mutable_data(), p.block_tables.data(), p.block_tables.size() * sizeof(int32_t));
+      d["block_tables"] = bt;
+    }
     d["chunk_end"] = to_np(p.chunk_end);
     d["sample"] = to_np(p.sample);
   } else if (p.kind == 2) {

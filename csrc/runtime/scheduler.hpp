@@ -94,7 +94,6 @@ struct Plan {
   std::vector<int32_t> input_ids, positions;
   std::vector<int32_t> cu_q, cu_k;
   std::vector<int64_t> slot_mapping;  // where the new tokens' K/V go
-  std::vector<int64_t> ctx_slots;     // slots of ALL context tokens (only when a prefix was reused)
   std::vector<int32_t> chunk_end;     // per request: context length after this plan
   std::vector<int32_t> sample;        // per request: 1 = the chunk reaches the end of the prompt, sample a token
   bool has_prefix = false;
@@ -103,7 +102,7 @@ struct Plan {
   int n_steps = 0;
   bool continuation = false;          // rows and device state carried over from the previous decode plan
   std::vector<int32_t> context_lens;
-  std::vector<int32_t> block_tables;  // [B, max_pages]
+  std::vector<int32_t> block_tables;  // [B, max_pages]; prefill plans carry it when a row has context in the cache
   int max_pages = 0;
   std::vector<int32_t> remaining;      // tokens the row may still generate (max_new_tokens and context cap)
   std::vector<int32_t> min_remaining;  // tokens until stop tokens count (min_new_tokens)
@@ -446,9 +445,15 @@ class Scheduler {
     p.kind = 1;
     for (auto& [id, end] : rows) emit_prefill_rows(p, *reqs_[id], end);
     if (p.has_prefix) {
+      // some row attends to context that is in the cache already (a reused prefix, earlier chunks): the attention
+      // kernel reads every row's context through its page table
+      p.max_pages = pages_for(p.max_k);
+      p.block_tables.assign(rows.size() * (size_t)p.max_pages, 0);
+      size_t row = 0;
       for (auto& [id, end] : rows) {
         Request& r = *reqs_[id];
-        for (int t = 0; t < end; ++t) p.ctx_slots.push_back((int64_t)r.pages[t / PAGE] * PAGE + t % PAGE);
+        std::copy(r.pages.begin(), r.pages.begin() + pages_for(end), p.block_tables.begin() + row * p.max_pages);
+        ++row;
       }
     }
     // rows whose last chunk is in this plan start decoding after it

@@ -100,7 +100,16 @@ int main(int argc, char** argv) {
           if (p.sample[i]) chunk_pos.erase(p.req_ids[i]); else { chunk_pos[p.req_ids[i]] = p.chunk_end[i]; ++total_chunks; }
           if (!p.sample[i]) CHECK(p.penalty_slot[i] == -1, "a non-sampling chunk must not touch the count table");
         }
-        if (p.has_prefix) CHECK((int)p.ctx_slots.size() == p.cu_k.back(), "ctx slots %zu vs %d", p.ctx_slots.size(), p.cu_k.back());
+        if (p.has_prefix) {
+          CHECK(p.max_pages * 32 >= p.max_k && p.block_tables.size() == p.req_ids.size() * (size_t)p.max_pages,
+                "page table of a prefill plan: %zu entries for %zu rows of %d pages", p.block_tables.size(),
+                p.req_ids.size(), p.max_pages);
+          for (size_t i = 0; i < p.req_ids.size(); ++i) {
+            // the slots the plan writes lie in the pages its table names
+            for (int t = p.cu_q[i]; t < p.cu_q[i + 1]; ++t)
+              CHECK(p.slot_mapping[t] / 32 == p.block_tables[i * p.max_pages + p.positions[t] / 32], "slot outside its page");
+          }
+        }
         s.process_prefill(p, tok.data(), lp.data());
       } else if (p.kind == 2) {
         // a chain of decode plans: each successor is scheduled before its predecessor is processed

@@ -909,6 +909,51 @@ def test_dgemm_qkv_rope_matches_unfused(Hq, Hkv, D, K, cfg, lw, T):
         _close(vc, vc2, 3e-2, 2e-2, f"v cache cfg={cfg} stages={stages}")
 
 
+@pytest.mark.parametrize("prefix,chunk", [(0, 70), (31, 5), (32, 200), (4096, 130), (100, 1), (650, 300)])
+@pytest.mark.parametrize("Hq,Hkv", [(12, 2), (4, 4)])
+def test_paged_prefill_attention_matches_fp32(prefix, chunk, Hq, Hkv):
+    """Prefill queries against the paged cache (flash_attn_paged.hip): several requests with different prefix /
+    chunk lengths in one launch, pages scattered over the pool, stale non-finite values behind the end of every
+    context, against fp32 attention over the gathered context."""
+    torch.manual_seed(prefix + chunk)
+    dev, D = torch.device("cuda"), 128
+    reqs = [(prefix, chunk), (max(0, prefix // 2), chunk + 3), (prefix + 17, max(1, chunk // 2))]
+    n_pages = sum((p + c + 31) // 32 for p, c in reqs) + 4
+    kc, vc = A.alloc_kv_cache(n_pages, Hkv, D, torch.bfloat16, dev)
+    kc.fill_(float("nan"))
+    vc.fill_(float("nan"))
+    perm = torch.randperm(n_pages)[: n_pages - 4].tolist()
+    max_pages = max((p + c + 31) // 32 for p, c in reqs)
+    bt = torch.zeros(len(reqs), max_pages, dtype=torch.int32)
+    qs, ks, vs, cu_q, cu_k = [], [], [], [0], [0]
+    for i, (p, c) in enumerate(reqs):
+        n = p + c
+        npg = (n + 31) // 32
+        pages, perm = perm[:npg], perm[npg:]
+        bt[i, :npg] = torch.tensor(pages, dtype=torch.int32)
+        k = torch.randn(n, Hkv, D, device=dev).bfloat16()
+        v = torch.randn(n, Hkv, D, device=dev).bfloat16()
+        t = torch.arange(n)
+        pg = torch.tensor(pages)[t // 32].to(dev)
+        kc[pg, :, (t % 32).to(dev), :] = k
+        vc[pg, :, :, (t % 32).to(dev)] = v
+        qs.append(torch.randn(c, Hq, D, device=dev).bfloat16())
+        ks.append(k)
+        vs.append(v)
+        cu_q.append(cu_q[-1] + c)
+        cu_k.append(cu_k[-1] + n)
+    q = torch.cat(qs)
+    cq = torch.tensor(cu_q, dtype=torch.int32, device=dev)
+    ck = torch.tensor(cu_k, dtype=torch.int32, device=dev)
+    out = A.flash_attn_paged_prefill(q, kc, vc, bt.to(dev), cq, ck, max(c for _, c in reqs))
+    want, _ = A.attention_varlen_ref(q.float(), torch.cat(ks).float(), torch.cat(vs).float(), cq, ck, 1.0 / math.sqrt(D))
+    _close(out, want, 2e-2, 2e-2, f"prefix={prefix} chunk={chunk}")
+    # the slot list the fallback path gathers with names the same tokens
+    slots = A.context_slots(bt.to(dev), ck)
+    kg, vg = A.cache_gather(kc, vc, slots)
+    assert torch.equal(kg, torch.cat(ks)) and torch.equal(vg, torch.cat(vs))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,Fc,K,cols,mblocks", [
     (256, 8960, 1536, 36, 1),   # Qwen2-1.5B decode: 249 workgroups

@@ -209,7 +209,11 @@ def test_prompt_longer_than_the_prefill_budget_is_prefilled_in_chunks():
         assert plan["positions"].tolist() == list(range(len(seen) - len(plan["input_ids"]), len(seen)))
         assert int(plan["cu_k"][1]) == len(seen) == int(plan["chunk_end"][0])
         # later chunks attend to the earlier ones through the page table
-        assert bool(plan["has_prefix"]) == (len(seen) > 32) and (len(plan["ctx_slots"]) == len(seen)) == (len(seen) > 32)
+        assert bool(plan["has_prefix"]) == (len(seen) > 32)
+        if plan["has_prefix"]:  # the row's whole context so far is reachable through its page table
+            assert plan["block_tables"].shape == (1, plan["max_pages"]) and plan["max_pages"] * 32 >= len(seen)
+            assert [int(x) // 32 for x in plan["slot_mapping"]] == [
+                int(plan["block_tables"][0, int(p) // 32]) for p in plan["positions"]]
         if len(seen) < 100:
             assert s.num_running() == 1 and not s.take_finished()
         s.process_prefill([7], [-0.5], plan["plan_id"])
@@ -268,7 +272,7 @@ def test_prefix_cache_hit_is_checked_against_the_stored_tokens():
     _add(s, "b", prompt, 2)
     plan = s.schedule()
     assert plan["has_prefix"] and len(plan["input_ids"]) == 6  # both full pages come from the cache
-    first_page = int(plan["ctx_slots"][0]) // rt.PAGE_SIZE
+    first_page = int(plan["block_tables"][0, 0])
     s.process_prefill([5], [-1.0], plan["plan_id"])
     _drive(s, lambda rid, pos: 5)
     # same hash key, different tokens behind it (what a 64-bit collision would look like): no hit
