@@ -86,15 +86,20 @@ class ModelRunner:
         self.mm: Dict[int, Dict[str, Any]] = {}
         # Decode batches of FUSED_MIN_BATCH rows and more run the layer as seven launches (ops/decode_gemm.py);
         # smaller ones, and model variants its epilogues do not cover, take the library GEMMs.
-        fusable = (not self.plain_family and cfg.n_experts == 0 and not cfg.qk_norm and cfg.hidden_act == "silu"
-                   and model.tp_size == 1
-                   and cfg.hidden_size % 64 == 0 and cfg.intermediate_size % 64 == 0 and cfg.head_dim % 16 == 0)
+        # (tensor-parallel shards included: the row-parallel projections then hand their summed slabs to the group's
+        # all-reduce ahead of the residual + norm kernel; mixture-of-experts layers keep the library path)
+        fusable = (not self.plain_family and cfg.n_experts == 0 and cfg.hidden_act == "silu"
+                   and cfg.hidden_size % 64 == 0 and (cfg.intermediate_size // model.tp_size) % 64 == 0
+                   and cfg.head_dim % 16 == 0 and (self.hq * cfg.head_dim) % 64 == 0)
         if fused_decode is None:
-            fused_decode = self.device.type == "cuda" and os.environ.get("AREAL_FUSED_DECODE", "1") != "0"
+            env = os.environ.get("AREAL_FUSED_DECODE", "1")  # "force": also on the CPU fallbacks of the kernels (tests)
+            fused_decode = env == "force" or (self.device.type == "cuda" and env != "0")
+        self.FUSED_MIN_BATCH = int(os.environ.get("AREAL_FUSED_MIN_BATCH", self.FUSED_MIN_BATCH))
         self.fused_decode = bool(fused_decode) and fusable
         self._gate_up_choice: Dict[int, str] = {}  # batch bucket -> fastest gate|up kernel (timed once)
         # qkv projection with bias + RoPE + KV-cache write in its epilogue (head sizes that are multiples of 64)
-        self.fused_qkv_rope = cfg.head_dim % 64 == 0 and os.environ.get("AREAL_FUSED_QKV_ROPE", "1") != "0"
+        self.fused_qkv_rope = (cfg.head_dim % 64 == 0 and not cfg.qk_norm
+                               and os.environ.get("AREAL_FUSED_QKV_ROPE", "1") != "0")
 
     # ------------------------------------------------------------------- vision-language requests
     def _placeholder_mask(self, prompt_ids: List[int], grid_thw: torch.Tensor):
@@ -416,7 +421,10 @@ class ModelRunner:
 
         has_plan = dg.swiglu_plan(Bp, self.cfg.intermediate_size // max(1, self.model.tp_size)) is not None
         forced = os.environ.get("AREAL_FUSED_GATE_UP")
-        if forced is not None or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        # tensor-parallel ranks must run the SAME kernels (their roundings differ, and the ranks' activations have to
+        # stay bit-identical): no per-rank timing there
+        if (forced is not None or self.device.type != "cuda" or torch.cuda.is_current_stream_capturing()
+                or self.model.tp_size > 1):
             mode = {"0": "library", "1": "tiled"}.get(forced or "", "balanced" if has_plan else "tiled")
             if mode == "balanced" and not has_plan:
                 mode = "tiled"
@@ -466,6 +474,19 @@ class ModelRunner:
         eps, gemma = cfg.rms_norm_eps, cfg.gemma_norm
         layers = self.model.layers
         gate_up_mode = self._gate_up_mode(Bp)
+        tp = self.model.tp_size > 1
+
+        def finish(slab, residual, weight):
+            """Split-K slabs of a projection -> (normalised input of the next GEMM, new residual stream). A
+            row-parallel projection's slabs hold this rank's partial sums: they are summed to bf16, all-reduced over
+            the tensor-parallel group, and only then added to the residual and normalised."""
+            if not tp:
+                return dg.splitk_residual_rmsnorm(slab, slab.shape[0], Bp, H, residual=residual, weight=weight,
+                                                  eps=eps, gemma=gemma, dtype=self.dtype)
+            part, _ = dg.splitk_residual_rmsnorm(slab, slab.shape[0], Bp, H, dtype=self.dtype)
+            self._tp_all_reduce(part)
+            return ops.rmsnorm(part, weight, eps, residual, gemma)
+
         x, residual = ops.rmsnorm(h, layers[0].ln1, eps, None, gemma)
         for li, blk in enumerate(layers):
             kc, vc = self.kv[li]
@@ -475,12 +496,13 @@ class ModelRunner:
             else:
                 slab = dg.dgemm(x, blk.attn.qkv, epilogue=dg.EPI_SLAB)
                 q = dg.splitk_rope_cache_write(slab, slab.shape[0], blk.attn.qkv_bias, rope_pos, st["slots"],
-                                               self.rope, kc, vc, hq, hkv, D, dtype=self.dtype)
+                                               self.rope, kc, vc, hq, hkv, D, dtype=self.dtype,
+                                               q_norm=blk.attn.q_norm if cfg.qk_norm else None,
+                                               k_norm=blk.attn.k_norm if cfg.qk_norm else None, norm_eps=eps)
             attn = ops.paged_attention_decode(q, kc, vc, st["block_tables"], st["context_lens"], nsplit=st["nsplit"],
                                               workspace=st["ws"])
             slab = dg.dgemm(attn.view(Bp, hq * D), blk.attn.o, epilogue=dg.EPI_SLAB)
-            x, residual = dg.splitk_residual_rmsnorm(slab, slab.shape[0], Bp, H, residual=residual, weight=blk.ln2,
-                                                     eps=eps, gemma=gemma, dtype=self.dtype)
+            x, residual = finish(slab, residual, blk.ln2)
             if gate_up_mode == "balanced":
                 act = dg.dgemm_swiglu_balanced(x, blk.mlp.gate_up)
             elif gate_up_mode == "tiled":
@@ -489,8 +511,7 @@ class ModelRunner:
                 act = ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)
             slab = dg.dgemm(act, blk.mlp.down, epilogue=dg.EPI_SLAB)
             nw = layers[li + 1].ln1 if li + 1 < len(layers) else self.model.norm
-            x, residual = dg.splitk_residual_rmsnorm(slab, slab.shape[0], Bp, H, residual=residual, weight=nw,
-                                                     eps=eps, gemma=gemma, dtype=self.dtype)
+            x, residual = finish(slab, residual, nw)
         return x
 
     def _decode_body(self, st: Dict[str, torch.Tensor], filtered: bool, penalized: bool = False):

@@ -226,9 +226,12 @@ def splitk_residual_rmsnorm(slab: torch.Tensor, n_split: int, M: int, N: int, *,
 
 def splitk_rope_cache_write(slab: torch.Tensor, n_split: int, bias: Optional[torch.Tensor], positions, slots, table,
                             kcache, vcache, n_q_heads: int, n_kv_heads: int, head_dim: int,
-                            q_out: Optional[torch.Tensor] = None, do_rope: bool = True, dtype=torch.bfloat16):
-    """Finish a split-K qkv projection: sum the slabs (+bias), rotate q / k, write k / v into the paged caches
-    at ``slots`` and return the rotated q ``[T, Hq, D]``."""
+                            q_out: Optional[torch.Tensor] = None, do_rope: bool = True, dtype=torch.bfloat16,
+                            q_norm: Optional[torch.Tensor] = None, k_norm: Optional[torch.Tensor] = None,
+                            norm_eps: float = 1e-6):
+    """Finish a split-K qkv projection: sum the slabs (+bias), [RMS-normalise every q / k head with ``q_norm`` /
+    ``k_norm`` ``[D]`` (Qwen3),] rotate q / k, write k / v into the paged caches at ``slots`` and return the rotated
+    q ``[T, Hq, D]``."""
     T = positions.numel()
     Nq = (n_q_heads + 2 * n_kv_heads) * head_dim
     if q_out is None:
@@ -240,6 +243,13 @@ def splitk_rope_cache_write(slab: torch.Tensor, n_split: int, bias: Optional[tor
         if bias is not None:
             s = s + bias.float()
         qkv = s.to(dtype).view(T, n_q_heads + 2 * n_kv_heads, head_dim).contiguous()
+        if q_norm is not None:
+            def _n(x, w):
+                xf = x.float()
+                return (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + norm_eps) * w.float()).to(dtype)
+
+            qkv[:, :n_q_heads] = _n(qkv[:, :n_q_heads], q_norm)
+            qkv[:, n_q_heads:n_q_heads + n_kv_heads] = _n(qkv[:, n_q_heads:n_q_heads + n_kv_heads], k_norm)
         rope_and_cache_write_(qkv, positions, slots, table, kcache, vcache, n_q_heads, n_kv_heads, do_rope)
         q_out.copy_(qkv[:, :n_q_heads])
         return q_out
@@ -247,7 +257,8 @@ def splitk_rope_cache_write(slab: torch.Tensor, n_split: int, bias: Optional[tor
     L.check(L.lib().areal_splitk_rope_cache_write(
         L.ptr(slab), L.c_int(n_split), L.ptr(bias), L.ptr(positions), L.ptr(slots), L.ptr(table.cos), L.ptr(table.sin),
         L.ptr(q_out), L.ptr(kcache), L.ptr(vcache), L.c_int(T), L.c_int(n_q_heads), L.c_int(n_kv_heads),
-        L.c_int(head_dim), L.c_int(table.max_pos), L.c_int(int(do_rope)), L.stream_ptr()), "splitk_rope_cache_write")
+        L.c_int(head_dim), L.c_int(table.max_pos), L.c_int(int(do_rope)), L.ptr(q_norm), L.ptr(k_norm),
+        L.c_float(float(norm_eps)), L.stream_ptr()), "splitk_rope_cache_write")
     return q_out
 
 

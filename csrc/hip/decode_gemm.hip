@@ -602,7 +602,8 @@ __global__ __launch_bounds__(1024) void splitk_rope_cache_write_kernel(
     const float* __restrict__ slab, int S, const bf16_t* __restrict__ bias, const int* __restrict__ pos,
     const int64_t* __restrict__ slots, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
     bf16_t* __restrict__ q_out, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, int T, int Hq, int Hkv,
-    int D, int max_pos, int do_rope) {
+    int D, int max_pos, int do_rope, const bf16_t* __restrict__ q_norm, const bf16_t* __restrict__ k_norm,
+    float norm_eps) {
   extern __shared__ __attribute__((aligned(16))) float rowbuf[];
   const int t = blockIdx.x;
   const int half = D >> 1;
@@ -649,6 +650,22 @@ __global__ __launch_bounds__(1024) void splitk_rope_cache_write_kernel(
 #pragma unroll
       for (int j = 0; j < 4; ++j) { lo[4 * q + j] = a[j]; hi[4 * q + j] = b[j]; }
     }
+    if (q_norm) {
+      // per-head RMSNorm of q and k ahead of the rotation (Qwen3): the lph lanes that share a head are neighbours
+      // in one wave; normalised values are rounded to bf16 as the unfused norm kernel's output is
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += lo[j] * lo[j] + hi[j] * hi[j];
+      for (int o = 1; o < lph; o <<= 1) ss += __shfl_xor(ss, o, 64);
+      const float rstd = rsqrtf(ss / (float)D + norm_eps);
+      const bf16_t* wn = (head < Hq ? q_norm : k_norm) + sub * 8;
+      const bf16x8 wl = ld8(wn), wh = ld8(wn + half);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        lo[j] = bf2f(f2bf(lo[j] * rstd * bf2f(wl[j])));
+        hi[j] = bf2f(f2bf(hi[j] * rstd * bf2f(wh[j])));
+      }
+    }
     bf16x8 olo, ohi;
     if (do_rope) {
       const bool first = i == (int)threadIdx.x;  // the rows requested up front
@@ -691,15 +708,18 @@ __global__ __launch_bounds__(1024) void splitk_rope_cache_write_kernel(
 extern "C" int areal_splitk_rope_cache_write(const float* slab, int S, const void* bias, const int* pos,
                                              const int64_t* slots, const float* cos_t, const float* sin_t,
                                              void* q_out, void* kcache, void* vcache, int T, int Hq, int Hkv, int D,
-                                             int max_pos, int do_rope, hipStream_t st) {
+                                             int max_pos, int do_rope, const void* q_norm, const void* k_norm,
+                                             float norm_eps, hipStream_t st) {
   if (T <= 0) return 0;
   const size_t lds = (size_t)(Hq + 2 * Hkv) * D * sizeof(float);
   if (D % 16 != 0 || S < 1 || lds > 64 * 1024) return -1;
+  if ((q_norm == nullptr) != (k_norm == nullptr)) return -2;
+  if (q_norm && (D / 16 > 64 || ((D / 16) & (D / 16 - 1)) != 0)) return -3;  // lanes of a head: a power of two in one wave
   // one float4 chunk of the summed row per thread where the row allows it: all of a thread's slab loads are in
   // flight at once (a second pass over the row would wait for the first one's loads)
   const int threads = std::min(1024, std::max(256, (((Hq + 2 * Hkv) * D / 4 + 63) / 64) * 64));
   hipLaunchKernelGGL(splitk_rope_cache_write_kernel, dim3(T), dim3(threads), lds, st, slab, S, (const bf16_t*)bias, pos,
                      slots, cos_t, sin_t, (bf16_t*)q_out, (bf16_t*)kcache, (bf16_t*)vcache, T, Hq, Hkv, D, max_pos,
-                     do_rope);
+                     do_rope, (const bf16_t*)q_norm, (const bf16_t*)k_norm, norm_eps);
   return (int)hipGetLastError();
 }

@@ -27,17 +27,22 @@ def _plan(B, ctx, steps, V, seed):
                 top_k=np.full(B, 1 << 30, dtype=np.int64))
 
 
-@pytest.mark.parametrize("B", [48, 70])
-def test_fused_decode_matches_plain(B):
+@pytest.mark.parametrize("B,name", [(48, "tiny"), (70, "tiny"), (48, "tiny-qknorm")])
+def test_fused_decode_matches_plain(B, name):
+    """`tiny-qknorm`: per-head q / k RMSNorm (Qwen3) runs inside the RoPE + cache-write row kernel."""
     torch.manual_seed(0)
-    cfg = preset("tiny")
+    cfg = preset(name)
     model = Transformer(cfg, dtype=torch.float32, device="cpu")
     model.requires_grad_(False)
     model.eval()
     model.flatten()
     model.init_weights(seed=3)
-    for blk in model.layers:  # non-zero projection biases
-        blk.attn.qkv_bias.data.normal_(0, 0.1)
+    for blk in model.layers:  # non-zero projection biases, non-trivial norm weights
+        if blk.attn.qkv_bias is not None:
+            blk.attn.qkv_bias.data.normal_(0, 0.1)
+        if cfg.qk_norm:
+            blk.attn.q_norm.data.uniform_(0.5, 1.5)
+            blk.attn.k_norm.data.uniform_(0.5, 1.5)
     steps, ctx = 3, 70
     pages = B * ((ctx + steps + PAGE_SIZE - 1) // PAGE_SIZE + 1) + 4
     outs = []

@@ -628,8 +628,9 @@ def test_decoupled_server_process_with_disk_weight_updates(tmp_path, transport):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [64, 200, 330])
-def test_fused_decode_path_matches_library_path(B):
+@pytest.mark.parametrize("B,name", [(64, "small"), (200, "small"), (330, "small"), (64, "tiny-qknorm"),
+                                    (200, "tiny-qknorm")])
+def test_fused_decode_path_matches_library_path(B, name):
     """Decode steps through the fused layer path (decode GEMMs + slab row kernels, inside a captured graph)
     against the library-GEMM path on the same weights and KV cache: same greedy tokens except where the two
     best logits are within bf16 rounding of each other, log-probs within bf16 noise, same KV cache writes."""
@@ -641,14 +642,18 @@ def test_fused_decode_path_matches_library_path(B):
     from areal_vllm_amd.ops.attention import PAGE_SIZE
 
     dev = torch.device("cuda", 0)
-    cfg = preset("small")
+    cfg = preset(name)  # tiny-qknorm: per-head q / k RMSNorm (Qwen3) inside the RoPE + cache-write row kernel
     model = Transformer(cfg, dtype=torch.bfloat16, device=dev)
     model.requires_grad_(False)
     model.eval()
     model.flatten()
     model.init_weights(seed=3, std=0.05)
     for blk in model.layers:
-        blk.attn.qkv_bias.data.normal_(0, 0.1)
+        if blk.attn.qkv_bias is not None:
+            blk.attn.qkv_bias.data.normal_(0, 0.1)
+        if cfg.qk_norm:
+            blk.attn.q_norm.data.uniform_(0.5, 1.5)
+            blk.attn.k_norm.data.uniform_(0.5, 1.5)
     steps, ctx = 1, 300  # one step per plan: later steps depend on the sampled tokens, which may tie-break apart
     pps = (ctx + steps + PAGE_SIZE - 1) // PAGE_SIZE + 1
     rng = np.random.RandomState(0)
@@ -664,6 +669,7 @@ def test_fused_decode_path_matches_library_path(B):
     for fused in (False, True):
         r = ModelRunner(model, B * pps + 4, ctx + 64, B, decode_steps=steps, use_graph=True, buckets=[B],
                         fused_decode=fused)
+        assert r.fused_decode == fused
         g = torch.Generator(device=dev).manual_seed(5)
         for kc, vc in r.kv:
             kc.copy_((torch.randn(kc.shape, generator=g, device=dev) * 0.5).bfloat16())
@@ -739,7 +745,8 @@ def _tp_gpu_worker(rank, port, out_path, custom_ar):
     # continuation launched before the previous plan is read they end up waiting for each other (observed as a hang
     # of both ranks in the continuation's first collective); RCCL, the production backend, is stream-ordered
     os.environ.update(GLOO_SOCKET_IFNAME="lo", AREAL_TP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      AREAL_CUSTOM_ALL_REDUCE="1" if custom_ar else "0", AREAL_PIPELINE_DECODE="0")
+                      AREAL_CUSTOM_ALL_REDUCE="1" if custom_ar else "0", AREAL_PIPELINE_DECODE="0",
+                      AREAL_FUSED_MIN_BATCH="1")  # the hand-written decode layer also for these few rows
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from areal_vllm_amd.api.cli_args import InferenceServerConfig
     from areal_vllm_amd.inference.tp_worker import build_tp_engine
@@ -750,6 +757,7 @@ def _tp_gpu_worker(rank, port, out_path, custom_ar):
     eng = build_tp_engine(args, cfg, rank, f"127.0.0.1:{port}", initialize=False)
     eng.initialize(load_weights=False)
     assert (eng.runner.ipc_ar is not None) == custom_ar
+    assert eng.runner.fused_decode and eng.runner.model.tp_size == 2  # tensor-parallel shards on the fused decode layer
     if rank > 0:
         eng.run_follower()
         return

@@ -28,8 +28,10 @@ def _gen(eng, **kw):
     return [(r.output_tokens, [round(x, 4) for x in r.output_logprobs]) for r in res]
 
 
-def _worker(rank, port, ckpt, out_path):
+def _worker(rank, port, ckpt, out_path, fused=False):
     os.environ.update(GLOO_SOCKET_IFNAME="lo", AREAL_PLATFORM="cpu")
+    if fused:  # the fused decode layer (split-K slabs -> all-reduce -> residual + norm) on the kernels' CPU fallbacks
+        os.environ.update(AREAL_FUSED_DECODE="force", AREAL_FUSED_MIN_BATCH="1")
     sys.path.insert(0, ROOT)
     torch.set_num_threads(1)
     from areal_vllm_amd.api.cli_args import InferenceServerConfig
@@ -41,9 +43,11 @@ def _worker(rank, port, ckpt, out_path):
     args = argparse.Namespace(tp_size=2, base_gpu_id=0, device="cpu", num_pages=64, kv_cache_gb=None)
     eng = build_tp_engine(args, cfg, rank, f"127.0.0.1:{port}", initialize=False)
     eng.initialize(load_weights=False)
+    assert eng.runner.fused_decode == fused
     if rank > 0:
         eng.run_follower()
         return
+    os.environ["AREAL_FUSED_DECODE"] = "0"  # the single-rank reference runs the plain layer
     ref = NativeInferenceEngine(cfg, device=torch.device("cpu"), num_pages=64).initialize(load_weights=False)
     out = {}
     out["greedy_tp"], out["greedy_ref"] = _gen(eng, greedy=True), _gen(ref, greedy=True)
@@ -57,7 +61,8 @@ def _worker(rank, port, ckpt, out_path):
     eng.destroy()  # the loop's exit path tells the follower to shut down
 
 
-def test_tp2_engine_matches_single_rank(tmp_path):
+@pytest.mark.parametrize("fused", [False, True])
+def test_tp2_engine_matches_single_rank(tmp_path, fused):
     sys.path.insert(0, ROOT)
     from areal_vllm_amd.models import hf_io
     from areal_vllm_amd.models.config import preset
@@ -68,7 +73,7 @@ def test_tp2_engine_matches_single_rank(tmp_path):
     ckpt = str(tmp_path / "ckpt")
     hf_io.save_hf_checkpoint(other, ckpt)
     out_path = str(tmp_path / "out.pt")
-    mp.spawn(_worker, args=(_free_port(), ckpt, out_path), nprocs=2, join=True)
+    mp.spawn(_worker, args=(_free_port(), ckpt, out_path, fused), nprocs=2, join=True)
     out = torch.load(out_path)
     assert out["version"] == 3
     for k in ("greedy", "sampled", "greedy2"):
