@@ -105,6 +105,9 @@ class WeightUpdateMeta:
     ipc_buffers: List[Dict[str, Any]] = field(default_factory=list)
     ipc_layout: str = ""  # fingerprint of the flat parameter layout the buffers use
     ipc_used_bytes: int = 0  # bytes of parameters at the head of every buffer (the tail is shard padding)
+    # parallel layout of the exporting trainer: {dp, tp, pp, vpp, vocab_parallel, zero3}; `ipc_buffers[r]` belongs to
+    # trainer rank r. Servers derive from it which ranges of which buffers they pull.
+    ipc_src: Dict[str, Any] = field(default_factory=dict)
 
     def sender_port(self, s: int) -> int:
         return self.nccl_master_ports[s] if self.nccl_master_ports else self.nccl_master_port + s

@@ -222,11 +222,14 @@ def _update_from_disk(experiment_name, trial_name, model_version, addresses, pat
 
 def _update_from_ipc(meta: WeightUpdateMeta, experiment_name, trial_name, model_version, addresses, retries,
                      timeout, next_version):
-    """Wait until the trainer says its buffers are final, then let every server pull from the buffer of
-    trainer rank i % n (they all hold the full replica; spreading the sources spreads the links)."""
+    """Wait until the trainer says its buffers are final, then let every server pull: server i reads from the
+    trainer's data-parallel replica i % dp (spreading the sources spreads the links); with a sharded trainer or a
+    tensor-parallel server every server rank works out the ranges it needs from the trainer's layout."""
     key = names.update_weights_from_ipc(experiment_name, trial_name, model_version)
     name_resolve.wait(key, timeout=600)
     t0 = time.perf_counter()
+    src = dict(meta.ipc_src or {})
+    plain = not src or (src.get("tp", 1) == 1 and src.get("pp", 1) == 1 and src.get("zero3", 1) == 1)
     n = len(meta.ipc_buffers)
 
     async def go():
@@ -234,9 +237,10 @@ def _update_from_ipc(meta: WeightUpdateMeta, experiment_name, trial_name, model_
                                          connector=get_default_connector()) as session:
             return await asyncio.gather(*[
                 arequest_with_retry(addr=a, session=session, endpoint="/update_weights_from_ipc", method="POST",
-                                    payload=dict(buffer=meta.ipc_buffers[i % n], layout=meta.ipc_layout,
-                                                 used_bytes=meta.ipc_used_bytes, version=next_version,
-                                                 abort_all_requests=True),
+                                    payload=dict(buffer=meta.ipc_buffers[i % n] if plain else None,
+                                                 buffers=meta.ipc_buffers, src=src, replica=i,
+                                                 layout=meta.ipc_layout, used_bytes=meta.ipc_used_bytes,
+                                                 version=next_version, abort_all_requests=True),
                                     max_retries=retries, timeout=timeout)
                 for i, a in enumerate(addresses)])
 

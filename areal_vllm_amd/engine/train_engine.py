@@ -954,30 +954,38 @@ class NativeTrainEngine(TrainEngine):
         elif meta.type in ("nccl", "xgmi"):
             self._upload_collective(meta)
         elif meta.type == "ipc":
-            if self.zero3 is not None:
-                raise NotImplementedError("the peer-memory transport exports the whole flat parameter buffer, which a "
-                                          "ZeRO-3 trainer never holds: use the collective or disk transport")
             self._upload_ipc(meta)
         else:
             raise NotImplementedError(f"Unknown weight update type {meta.type}")
 
     def export_weight_buffers(self) -> Dict[str, Any]:
-        """Export the memory behind this rank's flat bf16 parameter buffer for peer-memory weight updates and
-        gather the descriptors of all data-parallel ranks (collective over the world group)."""
+        """Export the memory behind this rank's bf16 parameters for peer-memory weight updates and gather the
+        descriptors of ALL trainer ranks (collective over the world group). Every rank exports exactly what it holds -
+        its flat buffer (a tensor-parallel slice of a pipeline stage; the whole model for a plain data-parallel
+        replica) or, under ZeRO-3, its shard of that buffer - together with the layout the servers need to work out
+        which byte ranges of which rank make up their own parameters (``parallel/param_realloc.py::derive_pull_plan``):
+        every trainer GPU serves its own shard over its own links, nothing is gathered on the trainer
+        (replaces the funnel of ``areal/engine/fsdp_engine.py:399-433``)."""
         from ..ops import ipc
 
-        if self.grid.tp > 1 or self.grid.pp > 1 or self.model.flat_experts is not None:
-            raise NotImplementedError("peer-memory weight updates copy the flat buffer of an unsharded replica "
-                                      "(data-parallel trainers); use the collective or disk transport")
+        if self.model.flat_experts is not None:
+            raise NotImplementedError("peer-memory weight updates cover dense models; routed experts (their own flat "
+                                      "buffer, their own parallel groups) take the collective or disk transport")
+        g = self.grid
+        holds = self.zero3.param_shard if self.zero3 is not None else self.model.flat.flat
         if getattr(self, "_ipc_export", None) is None:
-            self._ipc_export = ipc.export_buffer(self.model.flat.flat)
+            self._ipc_export = ipc.export_buffer(holds)
         descs = [self._ipc_export.desc]
         if dist.is_initialized() and self.world_size > 1:
             descs = [None] * self.world_size
-            dist.all_gather_object(descs, self._ipc_export.desc, group=self.grid.group("world"))
+            dist.all_gather_object(descs, self._ipc_export.desc, group=g.group("world"))
         name, off, shape = self.model.flat.specs[-1]
         used = (off + int(math.prod(shape))) * self.model.flat.flat.element_size()
-        return dict(ipc_buffers=descs, ipc_layout=flat_layout_fingerprint(self.model), ipc_used_bytes=int(used))
+        replicas = g.dp * g.cp  # ranks that hold the same (pp, tp) slice; ZeRO-3 cuts the slice over them instead
+        src = dict(dp=replicas, tp=g.tp, pp=g.pp, vpp=g.vpp, vocab_parallel=bool(self.model.vocab_parallel),
+                   zero3=replicas if self.zero3 is not None else 1)
+        return dict(ipc_buffers=descs, ipc_layout=flat_layout_fingerprint(self.model), ipc_used_bytes=int(used),
+                    ipc_src=src)
 
     def _upload_ipc(self, meta: WeightUpdateMeta):
         """Peers pull; this side takes a snapshot of the flat buffer into the exported area (after the optimizer

@@ -340,6 +340,10 @@ class NativeInferenceEngine:
                 self._join_update_group(payload)
             elif cmd == "recv_weights":
                 self._recv_weights(payload)
+            elif cmd == "pull_ipc":  # stream order puts the switch behind every plan launched so far
+                self._pull_sharded(payload, wait=True)
+                name, off, shape = self.model.flat.specs[-1]
+                self._flip_staging((off + int(math.prod(shape))) * self.model.flat.flat.element_size())
             elif cmd == "shutdown":
                 return
             elif cmd != "noop":
@@ -616,47 +620,72 @@ class NativeInferenceEngine:
         self._control(f)
 
     # ------------------------------------------------------------ weight updates from peer memory
-    def update_weights_from_ipc(self, buffer: Dict[str, Any], layout: str, used_bytes: int,
-                                version: Optional[int] = None, abort_running: bool = True) -> Dict[str, float]:
-        """Pull the trainer's flat parameter buffer out of its exported snapshot.
+    def update_weights_from_ipc(self, buffer: Optional[Dict[str, Any]], layout: str, used_bytes: int,
+                                version: Optional[int] = None, abort_running: bool = True,
+                                buffers: Optional[List[Dict[str, Any]]] = None, src: Optional[Dict[str, Any]] = None,
+                                replica: int = 0) -> Dict[str, float]:
+        """Pull new weights out of the trainer's exported memory.
+
+        Same layout on both sides (`buffer`: the snapshot of ONE unsharded trainer replica): one copy of the flat
+        buffer. Different layouts (`buffers`: the snapshots of ALL trainer ranks, `src`: the trainer's layout -
+        tensor- / pipeline-parallel slices, ZeRO-3 shards - or a tensor-parallel server): every rank of this server
+        works out which element ranges of which trainer ranks make up ITS flat buffer
+        (``parallel/param_realloc.py::derive_pull_plan``) and copies exactly those, one kernel launch per source
+        piece; the trainer gathers nothing and every trainer GPU serves only what it owns.
 
         All device work is issued by the engine's loop thread. Phase 1: between two engine steps the loop maps
-        the snapshot (first time) and starts a device-to-device copy into a staging buffer on a side stream
-        (xGMI between two GPUs, a local copy when trainer and server share one) - decoding goes on while it
-        runs. Phase 2: the loop polls the copy's event between steps; once it has fired, running requests are
-        aborted (their KV cache belongs to the old weights; the client re-issues them), staging -> live
-        parameters (an on-device copy, ~2 ms for a 1.5B model), prefix cache flushed, version bumped.
+        the snapshots (first time) and starts the copies into a staging buffer on a side stream (xGMI between two
+        GPUs, local copies when trainer and server share one) - decoding goes on while they run. Phase 2: the loop
+        polls the copies' event between steps; once it has fired, running requests are aborted (their KV cache
+        belongs to the old weights; the client re-issues them), staging -> live parameters (an on-device copy,
+        ~2 ms for a 1.5B model; the live buffer's address is baked into the captured decode graphs, so the buffers
+        are not swapped), prefix cache flushed, version bumped. A tensor-parallel server does both phases in one
+        go on every rank, between two plans (its ranks must switch weights at the same plan boundary).
         Blocks the caller until the flip is done; returns timings."""
         from ..engine.train_engine import flat_layout_fingerprint
 
-        assert self.tp_size == 1, "the flat-buffer pull needs identical layouts; tensor-parallel servers load by name"
-        if layout and layout != flat_layout_fingerprint(self.model):
-            raise ValueError("the trainer's flat parameter layout differs from this server's (model config, dtype "
-                             "or tied-embedding setting)")
         flat = self.model.flat.flat
-        n = int(used_bytes) or min(int(buffer["nbytes"]), flat.numel() * flat.element_size())
-        assert n <= flat.numel() * flat.element_size(), "trainer buffer holds more parameters than this model"
+        sharded = bool(src) and (int(src.get("tp", 1)) > 1 or int(src.get("pp", 1)) > 1 or int(src.get("zero3", 1)) > 1
+                                 or self.tp_size > 1)
+        if not sharded:
+            if buffer is None:
+                buffer = buffers[replica % len(buffers)]
+            if layout and layout != flat_layout_fingerprint(self.model):
+                raise ValueError("the trainer's flat parameter layout differs from this server's (model config, dtype "
+                                 "or tied-embedding setting)")
+            n = int(used_bytes) or min(int(buffer["nbytes"]), flat.numel() * flat.element_size())
+            assert n <= flat.numel() * flat.element_size(), "trainer buffer holds more parameters than this model"
+        else:
+            assert buffers, "a sharded pull needs the exported buffers of all trainer ranks"
+            name, off, shape = self.model.flat.specs[-1]
+            n = (off + int(math.prod(shape))) * flat.element_size()
         done: "queue.Queue" = queue.Queue()
         t0 = time.perf_counter()
+        payload = dict(buffers=buffers, src=src, replica=replica)
 
         def start():
-            from ..ops import ipc
-
-            peers = self.__dict__.setdefault("_ipc_peers", {})
-            if buffer["key"] not in peers:
-                peers[buffer["key"]] = ipc.PeerBuffer(buffer)
-            if getattr(self, "_ipc_staging", None) is None:
-                self._ipc_staging = torch.empty_like(flat)
+            if self.tp_size > 1:  # every rank switches at this plan boundary: pull and flip now, everywhere
+                t1 = time.perf_counter()
+                self._tp_bcast("pull_ipc", payload)
+                self._pull_sharded(payload, wait=True)
+                if abort_running:
+                    self.sched.abort_all()
+                    self._deliver()
+                self._flip_staging(n)
+                self._after_weight_change(version)
+                t2 = time.perf_counter()
+                done.put((True, dict(pull_ms=(t2 - t1) * 1e3, flip_ms=0.0, total_ms=(t2 - t0) * 1e3, bytes=float(n))))
+                return
             event = None
             if self.device.type == "cuda":
                 if self._copy_stream is None:
                     self._copy_stream = torch.cuda.Stream(device=self.device)
                 with torch.cuda.stream(self._copy_stream):
-                    peers[buffer["key"]].copy_into(self._ipc_staging, n)
+                    self._issue_pull(buffer, n, payload if sharded else None)
                     event = torch.cuda.Event()
                     event.record(self._copy_stream)
             else:
-                peers[buffer["key"]].copy_into(self._ipc_staging, n)
+                self._issue_pull(buffer, n, payload if sharded else None)
             self._pending_pull = dict(event=event, n=n, version=version, abort=abort_running, done=done, t0=t0,
                                       t_issue=time.perf_counter())
 
@@ -665,6 +694,56 @@ class NativeInferenceEngine:
         if not ok:
             raise info
         return info
+
+    def _staging(self) -> torch.Tensor:
+        if getattr(self, "_ipc_staging", None) is None:
+            self._ipc_staging = torch.empty_like(self.model.flat.flat)
+        return self._ipc_staging
+
+    def _peer(self, desc: Dict[str, Any]):
+        from ..ops import ipc
+
+        peers = self.__dict__.setdefault("_ipc_peers", {})
+        if desc["key"] not in peers:
+            peers[desc["key"]] = ipc.PeerBuffer(desc)
+        return peers[desc["key"]]
+
+    def _issue_pull(self, buffer: Optional[Dict[str, Any]], n: int, payload: Optional[Dict[str, Any]]):
+        """Queue the copies of one weight pull into the staging buffer on the current stream."""
+        if payload is None:
+            self._peer(buffer).copy_into(self._staging(), n)
+        else:
+            self._pull_sharded(payload, wait=False)
+
+    def _pull_sharded(self, payload: Dict[str, Any], wait: bool):
+        """This rank's ranges of the trainer ranks' exported buffers -> staging (current stream). The plan depends
+        on the two layouts only: derived once, its device-side range lists kept for every later update."""
+        from ..parallel.param_realloc import Layout, derive_pull_plan
+
+        src, buffers, replica = payload["src"], payload["buffers"], int(payload.get("replica", 0))
+        key = (repr(sorted(src.items())), replica, tuple(b["key"] for b in buffers))
+        cache = self.__dict__.setdefault("_ipc_plans", {})
+        staging = self._staging()
+        if key not in cache:
+            lay = Layout(dp=int(src.get("dp", 1)), tp=int(src.get("tp", 1)), pp=int(src.get("pp", 1)),
+                         vocab_parallel=bool(src.get("vocab_parallel", int(src.get("tp", 1)) > 1)),
+                         vpp=int(src.get("vpp", 1) or 1))
+            assert lay.world == len(buffers), f"trainer layout {lay} does not match {len(buffers)} exported buffers"
+            plan = derive_pull_plan(self.model_config, lay, self.tp_size, self.tp_rank, replica,
+                                    dtype=self.dtype, zero3=int(src.get("zero3", 1)))
+            esz = staging.element_size()
+            cache[key] = [(self._peer(buffers[r]), self._peer(buffers[r]).prepare_moves(tri, esz, self.device))
+                          for r, tri in plan]
+        for peer, prepared in cache[key]:
+            peer.move_intervals(staging, prepared)
+        if wait and self.device.type == "cuda":
+            torch.cuda.current_stream().synchronize()
+
+    def _flip_staging(self, n: int):
+        flat = self.model.flat.flat
+        flat.view(torch.uint8).view(-1)[:n].copy_(self._staging().view(torch.uint8).view(-1)[:n])
+        if self.device.type == "cuda":
+            torch.cuda.current_stream().synchronize()
 
     def _poll_pull(self):
         """Loop thread, between steps: finish a peer-memory weight pull whose copy has completed."""
@@ -678,10 +757,8 @@ class NativeInferenceEngine:
             if p["abort"]:
                 self.sched.abort_all()
                 self._deliver()
-            flat, n = self.model.flat.flat, p["n"]
-            flat.view(torch.uint8).view(-1)[:n].copy_(self._ipc_staging.view(torch.uint8).view(-1)[:n])
-            if self.device.type == "cuda":
-                torch.cuda.current_stream().synchronize()
+            n = p["n"]
+            self._flip_staging(n)
             self._after_weight_change(p["version"])
             t2 = time.perf_counter()
             p["done"].put((True, dict(pull_ms=(t1 - p["t_issue"]) * 1e3, flip_ms=(t2 - t1) * 1e3,

@@ -307,9 +307,10 @@ class InferenceServer:
         body = await req.json()
         t0 = time.perf_counter()
         try:
-            info = await self._offload(self.engine.update_weights_from_ipc, body["buffer"], body.get("layout", ""),
+            info = await self._offload(self.engine.update_weights_from_ipc, body.get("buffer"), body.get("layout", ""),
                                        int(body.get("used_bytes", 0)), body.get("version"),
-                                       bool(body.get("abort_all_requests", True)))
+                                       bool(body.get("abort_all_requests", True)), body.get("buffers"),
+                                       body.get("src"), int(body.get("replica", 0)))
         except Exception as e:
             return web.json_response({"success": False, "message": repr(e)})
         return web.json_response({"success": True, "message": f"pulled in {time.perf_counter() - t0:.3f}s", **info})

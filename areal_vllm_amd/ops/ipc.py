@@ -12,8 +12,9 @@ Role in the reference: the NCCL broadcast funnel of ``areal/engine/fsdp_engine.p
 """
 import ctypes
 from multiprocessing import shared_memory
-from typing import Any, Dict, Optional
+from typing import Any, Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -125,6 +126,45 @@ class PeerBuffer:
             L.check(L.lib().areal_memcpy_d2d_async(ctypes.c_void_p(dst.data_ptr() + lo), ctypes.c_void_p(base),
                                                    ctypes.c_long(take), L.stream_ptr()), "memcpy_d2d_async")
             lo += take
+
+    def prepare_moves(self, triples: np.ndarray, elt_bytes: int, device) -> List[Tuple[int, Any, int, int]]:
+        """Turn ``[n, 3]`` (source offset, destination offset, length) ELEMENT ranges of the exporter's tensor into
+        what `move_intervals` launches: per mapped piece of the snapshot the byte ranges that fall into it (ranges
+        that straddle two pieces are cut), as a device array. Weight-pull plans are the same for every update, so
+        callers prepare once and replay."""
+        t = np.ascontiguousarray(triples, dtype=np.int64).reshape(-1, 3) * int(elt_bytes)
+        t = t[t[:, 2] > 0]
+        if self._shm is not None:
+            return [(-1, t, int(t.shape[0]), int(t[:, 2].max()) if len(t) else 0)]
+        out, lo = [], 0
+        for ci, (_base, size) in enumerate(self._maps):
+            hi = lo + size
+            s0, s1 = np.maximum(t[:, 0], lo), np.minimum(t[:, 0] + t[:, 2], hi)
+            keep = s1 > s0
+            if keep.any():
+                cut = np.stack([s0[keep] - lo, t[keep, 1] + (s0[keep] - t[keep, 0]), s1[keep] - s0[keep]], 1)
+                dev = torch.from_numpy(np.ascontiguousarray(cut)).to(device)
+                out.append((ci, dev, int(cut.shape[0]), int(cut[:, 2].max())))
+            lo = hi
+        return out
+
+    def move_intervals(self, dst: torch.Tensor, prepared: List[Tuple[int, Any, int, int]]):
+        """Copy the prepared ranges into `dst` (a contiguous local buffer) on the current stream: one kernel launch
+        per mapped piece of the snapshot (``csrc/hip/ipc.hip::interval_move_kernel``); plain memory copies for the
+        shared-memory backing."""
+        assert dst.is_contiguous()
+        if self._shm is not None:
+            src = torch.frombuffer(self._shm.buf, dtype=torch.uint8, count=self.nbytes)
+            flat = dst.view(torch.uint8).view(-1)
+            for _ci, t, _n, _m in prepared:
+                for so, do, ln in t.tolist():
+                    flat[do:do + ln].copy_(src[so:so + ln])
+            return
+        assert dst.is_cuda
+        for ci, dev, n, max_len in prepared:
+            L.check(L.lib().areal_interval_move(ctypes.c_void_p(self._maps[ci][0]), ctypes.c_void_p(dst.data_ptr()),
+                                                ctypes.c_void_p(dev.data_ptr()), ctypes.c_int(n), ctypes.c_long(max_len),
+                                                L.stream_ptr()), "interval_move")
 
     def close(self):
         for base, _ in self._maps:

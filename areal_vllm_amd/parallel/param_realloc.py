@@ -262,3 +262,46 @@ def realloc_parameters(plan: Sequence[Transfer], src_ranks: Sequence[int], dst_r
         ops.set_intervals(buf, dst_flat, div)
         n_recv += buf.numel()
     return n_recv
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Pull plans: what ONE shard of a rollout server copies out of the exported buffers of the trainer's ranks when the
+# two sides are laid out differently (peer-memory weight updates, ``ops/ipc.py``). Same piece algebra as above, but
+# nobody sends: the destination reads the source ranks' memory directly.
+# ------------------------------------------------------------------------------------------------------------------
+_PULL_PLANS: Dict[Tuple, List[Tuple[int, np.ndarray]]] = {}
+
+
+def derive_pull_plan(cfg: ModelConfig, src: Layout, dst_tp: int, dst_tp_rank: int, replica: int = 0,
+                     dtype=torch.bfloat16, zero3: int = 1) -> List[Tuple[int, np.ndarray]]:
+    """-> [(trainer rank in layout order, int64 [n, 3] (offset in that rank's exported buffer, offset in the
+    destination shard's flat buffer, length), in elements)] for tensor-parallel rank `dst_tp_rank` of a rollout
+    server with `dst_tp` ranks (unsharded vocabulary, no pipeline stages). The server pulls from data-parallel
+    replica ``replica % src.dp`` of the trainer, so that several servers spread over the trainer's replicas (and
+    their xGMI links). ``zero3 = n``: every (pp, tp) shard of the trainer is itself cut over the n ranks of its
+    data-parallel group (ZeRO-3, ``parallel/zero3.py``): all of them are sources, each for the part it holds.
+    Every trainer GPU thus serves exactly the bytes it owns: the role of the sharded push that replaces the
+    rank-0 funnel of ``areal/engine/fsdp_engine.py:399-433``."""
+    key = (repr(cfg), src, dst_tp, dst_tp_rank, replica % max(1, src.dp), str(dtype), zero3)
+    if key in _PULL_PLANS:
+        return _PULL_PLANS[key]
+    dst = Layout(dp=1, tp=dst_tp, pp=1, vocab_parallel=False)
+    src1 = dataclasses.replace(src, dp=1)
+    out: List[Tuple[int, np.ndarray]] = []
+    for t in derive_realloc_plan(cfg, src1, dst, dtype):
+        if t.dst != dst_tp_rank:
+            continue
+        p, tr = divmod(t.src, src.tp)
+        if zero3 <= 1:
+            siv, div = _merged(t.src_intervals, t.dst_intervals)
+            out.append((src.index_of(p, replica % src.dp, tr),
+                        np.stack([siv[:, 0], div[:, 0], siv[:, 1] - siv[:, 0]], 1).astype(np.int64)))
+            continue
+        assert zero3 == src.dp, "ZeRO-3 shards a (pp, tp) slice over ALL data-parallel ranks"
+        from .zero3 import shard_map
+
+        per_rank = shard_map(_meta_shard(cfg, src1, tr, p, dtype), zero3).translate(t.src_intervals, t.dst_intervals)
+        for z, tri in per_rank.items():
+            out.append((src.index_of(p, z, tr), tri))
+    _PULL_PLANS[key] = out
+    return out

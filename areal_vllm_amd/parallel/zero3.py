@@ -38,6 +38,58 @@ from . import comm
 ALIGN = 16  # elements: parameter offsets inside a unit stay 32-byte aligned for bf16
 
 
+class ShardMap:
+    """Where the elements of a model's (virtual) contiguous parameter buffer live once ZeRO-3 has cut every unit over
+    `n` ranks: computed from names and shapes alone (a model on the meta device will do), with the arithmetic of
+    `Zero3.__init__` - the test suite holds the two against each other."""
+
+    def __init__(self, model, n: int):
+        import numpy as np
+
+        self.n = n
+        units: Dict[str, List] = {}
+        order: List[str] = [f"layers.{i}" for i in range(len(model.layers))] + ["outer"]
+        sizes = {u: 0 for u in order}
+        rows = []  # (flat offset, numel, unit index, offset in unit)
+        seen = set()
+        for name, p in model.named_parameters():
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            parts = name.split(".")
+            u = ".".join(parts[:2]) if parts[0] == "layers" else "outer"
+            rows.append((model.flat.offsets[name][0], p.numel(), order.index(u), sizes[u]))
+            sizes[u] += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        quantum = n * ALIGN
+        self.unit_numel = [(sizes[u] + quantum - 1) // quantum * quantum for u in order]
+        self.shard_off = list(np.cumsum([0] + [x // n for x in self.unit_numel[:-1]]))
+        self.shard_numel = sum(x // n for x in self.unit_numel)
+        rows.sort()
+        self.rows = np.asarray(rows, dtype=np.int64)
+
+    def translate(self, src_intervals, dst_intervals):
+        """[n, 2] ranges of the contiguous buffer (each inside one parameter) with their destination ranges ->
+        {rank: int64 [m, 3] (offset in that rank's shard buffer, destination offset, length)}."""
+        import numpy as np
+
+        out: Dict[int, List] = {}
+        starts = self.rows[:, 0]
+        for (a, b), (d0, _d1) in zip(np.asarray(src_intervals).tolist(), np.asarray(dst_intervals).tolist()):
+            i = int(np.searchsorted(starts, a, side="right")) - 1
+            o_f, numel, ui, off = self.rows[i].tolist()
+            assert o_f <= a and b <= o_f + numel, "a source range must lie inside one parameter"
+            per = self.unit_numel[ui] // self.n
+            lo, hi = off + a - o_f, off + b - o_f
+            for z in range(lo // per, (hi - 1) // per + 1):
+                x0, x1 = max(lo, z * per), min(hi, (z + 1) * per)
+                out.setdefault(z, []).append((self.shard_off[ui] + x0 - z * per, d0 + (x0 - lo), x1 - x0))
+        return {z: np.asarray(v, dtype=np.int64) for z, v in out.items()}
+
+
+def shard_map(model, n: int) -> ShardMap:
+    return ShardMap(model, n)
+
+
 class _Unit:
     def __init__(self, name: str):
         self.name = name

@@ -52,15 +52,19 @@ def build_rollout_engines(config: GRPOConfig, actor: NativePPOActor, parallel_st
         eval_rollout.initialize()
         am = AllocationMode.from_str(config.allocation_mode)
         transport = config.rollout_weight_update
-        if transport != "disk" and parallel_strategy.pp_size > 1:
+        moe = getattr(actor.model_config, "n_experts", 0) > 0
+        if transport in ("nccl", "xgmi") and parallel_strategy.pp_size > 1:
             # a pipeline stage only holds its own layers: the collective push (whose senders need every
-            # parameter) would update the servers partially; checkpoint files carry all stages
-            logger.warning("trainer has pipeline stages: weights go to the rollout servers through checkpoint "
-                           "files (rollout_weight_update=disk)")
-            transport = "disk"
-        if transport == "ipc" and (parallel_strategy.tp_size > 1 or am.gen.tp_size > 1):
-            logger.warning("peer-memory weight updates need unsharded replicas on both sides; using the collective push")
-            transport = "xgmi"
+            # parameter) would update the servers partially. The peer-memory pull has no such limit (every server
+            # rank reads the ranges it needs from whichever trainer rank owns them); checkpoint files carry all
+            # stages as well
+            logger.warning("trainer has pipeline stages: the collective weight push does not cover them, using "
+                           + ("checkpoint files" if moe else "the peer-memory pull"))
+            transport = "disk" if moe else "ipc"
+        if transport == "ipc" and moe:
+            logger.warning("peer-memory weight updates cover dense models; using "
+                           + ("checkpoint files" if parallel_strategy.pp_size > 1 else "the collective push"))
+            transport = "disk" if parallel_strategy.pp_size > 1 else "xgmi"
         if transport == "disk":
             meta = WeightUpdateMeta.from_disk(config.experiment_name, config.trial_name, config.cluster.fileroot)
         elif transport == "ipc":

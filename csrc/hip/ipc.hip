@@ -76,3 +76,39 @@ extern "C" int areal_memcpy_d2d_async(void* dst, const void* src, long bytes, hi
   IPC_RET(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, st));
   return 0;
 }
+
+// ----------------------------------------------------------------------------------------------------------
+// Many (source offset, destination offset, length) byte ranges from one mapped peer region into a local buffer
+// in ONE launch: the copy of a weight pull between DIFFERENT parallel layouts (a tensor- / pipeline-parallel
+// trainer shard holds row blocks and row slices of the parameters a server rank needs: up to one range per
+// matrix row). A workgroup walks ranges; 16-byte vectors where both ends are 16-byte aligned, bytes otherwise.
+// Reads cross xGMI when the region lives on another GPU, writes are local.
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interval_move_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                            const long* __restrict__ triples, int n) {
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const long so = triples[3 * i], d_o = triples[3 * i + 1], len = triples[3 * i + 2];
+    const char* s = src + so;
+    char* d = dst + d_o;
+    if ((((unsigned long)s | (unsigned long)d) & 15) == 0) {
+      const long nv = len >> 4;
+      for (long k = (long)blockIdx.y * blockDim.x + threadIdx.x; k < nv; k += (long)gridDim.y * blockDim.x)
+        reinterpret_cast<uint4*>(d)[k] = reinterpret_cast<const uint4*>(s)[k];
+      for (long k = (nv << 4) + (long)blockIdx.y * blockDim.x + threadIdx.x; k < len; k += (long)gridDim.y * blockDim.x)
+        d[k] = s[k];
+    } else {
+      for (long k = (long)blockIdx.y * blockDim.x + threadIdx.x; k < len; k += (long)gridDim.y * blockDim.x) d[k] = s[k];
+    }
+  }
+}
+
+// triples: device array of n x (src byte offset, dst byte offset, byte length); max_len: the longest range.
+extern "C" int areal_interval_move(const void* src, void* dst, const long* triples, int n, long max_len, hipStream_t st) {
+  if (n <= 0) return 0;
+  long gy = (max_len / 16 + 256 * 4 - 1) / (256 * 4);  // ~4 vectors per thread before a second block row
+  gy = gy < 1 ? 1 : (gy > 128 ? 128 : gy);
+  const int gx = n > 2048 ? 2048 : n;
+  hipLaunchKernelGGL(interval_move_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, st, (const char*)src, (char*)dst,
+                     triples, n);
+  return (int)hipGetLastError();
+}

@@ -522,13 +522,16 @@ def test_vision_language_rollout_matches_trainer_on_gpu():
         eng.destroy()
 
 
-@pytest.mark.parametrize("transport", ["disk", "ipc"])
+@pytest.mark.parametrize("transport", ["disk", "ipc", "ipc_tp2_shards"])
 def test_decoupled_server_process_with_disk_weight_updates(tmp_path, transport):
     """Decoupled deployment on one GPU: the rollout engine runs as its own HTTP server process, the trainer
     talks to it through the remote client and publishes weights either as a HF checkpoint on disk or through
     peer memory (`ipc`: the server process maps the trainer's flat bf16 buffer with hipIpc and pulls it with an
     asynchronous device-to-device copy on a side stream); after every update the server's behaviour
-    log-probs must agree with the trainer's recomputation (which proves that the new weights arrived)."""
+    log-probs must agree with the trainer's recomputation (which proves that the new weights arrived).
+    `ipc_tp2_shards`: the weights are exported the way a tensor-parallel trainer of two ranks holds them (two shard
+    buffers with vocabulary-parallel embeddings) and the unsharded server assembles its parameters from ranges of
+    both, with the interval kernel reading the mapped peer memory."""
     import socket
     import subprocess
     import time
@@ -579,6 +582,31 @@ def test_decoupled_server_process_with_disk_weight_updates(tmp_path, transport):
         client.initialize(addr=f"127.0.0.1:{port}", train_data_parallel_size=1)
         meta = (WeightUpdateMeta.from_disk("dec", "t", str(tmp_path)) if transport == "disk"
                 else WeightUpdateMeta.from_ipc(actor))
+        refresh_shards = lambda: None  # noqa: E731
+        if transport == "ipc_tp2_shards":
+            import dataclasses
+
+            from areal_vllm_amd.inference.engine import assign_hf_named_tensors
+            from areal_vllm_amd.models.transformer import Transformer
+            from areal_vllm_amd.ops import ipc
+
+            shards = []
+            for r in range(2):
+                m = Transformer(actor.model_config, dtype=torch.bfloat16, device=actor.device, tp_size=2, tp_rank=r,
+                                vocab_parallel=True)
+                m.requires_grad_(False)
+                m.flatten()
+                shards.append(m)
+            exports = [ipc.export_buffer(m.flat.flat) for m in shards]
+
+            def refresh_shards():
+                full = dict(actor._iter_full_hf_params())
+                for m, e in zip(shards, exports):
+                    assign_hf_named_tensors(m, full)
+                    e.refresh()
+
+            meta = dataclasses.replace(meta, ipc_buffers=[e.desc for e in exports],
+                                       ipc_src=dict(dp=1, tp=2, pp=1, vpp=1, vocab_parallel=True, zero3=1))
         g = GenerationHyperparameters(n_samples=2, max_new_tokens=48, temperature=1.0, stop_token_ids=[1])
         wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: float(sum(ci) % 2), g, reward_in_process=True)
         gen = torch.Generator().manual_seed(11)
@@ -587,6 +615,7 @@ def test_decoupled_server_process_with_disk_weight_updates(tmp_path, transport):
 
         def publish(version):
             client.pause()
+            refresh_shards()
             fut = client.update_weights(meta)
             actor.upload_weights(meta)
             assert fut.result(timeout=300)

@@ -56,6 +56,22 @@ def _worker(rank, port, ckpt, out_path, fused=False):
     ref.load_weights_from_disk(ckpt, version=3)
     out["greedy2_tp"], out["greedy2_ref"] = _gen(eng, greedy=True), _gen(ref, greedy=True)
     out["version"] = eng.get_version()
+    # peer-memory update of the tensor-parallel server: an unsharded "trainer" buffer is exported (shared memory on
+    # this platform) and every server rank pulls the ranges of ITS slices out of it
+    from areal_vllm_amd.models import hf_io
+    from areal_vllm_amd.models.transformer import Transformer
+    from areal_vllm_amd.ops import ipc
+
+    trainer = Transformer(ref.model_config, dtype=torch.float32, device="cpu")
+    trainer.flatten()
+    trainer.init_weights(seed=1234)
+    exp = ipc.export_buffer(trainer.flat.flat)
+    exp.refresh()
+    eng.update_weights_from_ipc(None, "", 0, version=4, buffers=[exp.desc],
+                                src=dict(dp=1, tp=1, pp=1, vpp=1, vocab_parallel=False, zero3=1))
+    ref.load_weights_from_trainer(trainer, version=4)
+    out["greedy3_tp"], out["greedy3_ref"] = _gen(eng, greedy=True), _gen(ref, greedy=True)
+    out["version3"] = eng.get_version()
     torch.save(out, out_path)
     ref.destroy()
     eng.destroy()  # the loop's exit path tells the follower to shut down
@@ -75,8 +91,9 @@ def test_tp2_engine_matches_single_rank(tmp_path, fused):
     out_path = str(tmp_path / "out.pt")
     mp.spawn(_worker, args=(_free_port(), ckpt, out_path, fused), nprocs=2, join=True)
     out = torch.load(out_path)
-    assert out["version"] == 3
-    for k in ("greedy", "sampled", "greedy2"):
+    assert out["version"] == 3 and out["version3"] == 4
+    assert out["greedy3_tp"] != out["greedy2_tp"]
+    for k in ("greedy", "sampled", "greedy2", "greedy3"):
         tp, ref = out[k + "_tp"], out[k + "_ref"]
         assert [t for t, _ in tp] == [t for t, _ in ref], k
         for (_, a), (_, b) in zip(tp, ref):
