@@ -204,8 +204,16 @@ class NativeTrainEngine(TrainEngine):
         cfg = self.config
         dtype = getattr(torch, cfg.dtype)
         mc = _resolve_model_config(cfg.path, self.is_critic)
+        if cfg.disable_dropout:  # RL recipes train without dropout whatever the checkpoint's config says
+            mc = dataclasses.replace(mc, embd_pdrop=0.0, resid_pdrop=0.0, attn_pdrop=0.0)
         self.model_config = mc
         g = self.grid
+        from ..utils import rng
+
+        # dropout masks: different per data-parallel replica, shared inside a tensor-parallel group except where the
+        # activation is sharded over it (utils/rng.py)
+        rng.keys.configure(seed=int(getattr(cfg, "dropout_seed", 0) or 0) + 7919, replica=g.coord.dp * g.cp + g.coord.cp,
+                           tp_rank=g.coord.tp)
         tik = time.perf_counter()
         lr, chunks = (0, mc.n_layers), None
         if g.pp > 1:
@@ -539,7 +547,11 @@ class NativeTrainEngine(TrainEngine):
         return not (g.tp > 1 and (self._kv_replication() > 1 or self._partial_grad_ranges()))
 
     def _begin_mb(self):
-        """ZeRO-3: the parameters outside the decoder blocks become whole for this micro-batch."""
+        """ZeRO-3: the parameters outside the decoder blocks become whole for this micro-batch. Dropout masks move
+        on to the next micro-batch's keys."""
+        from ..utils import rng
+
+        rng.keys.advance()
         if self.zero3 is not None:
             self.zero3.begin_microbatch()
 

@@ -42,6 +42,21 @@ class ModelConfig:
     moe_intermediate_size: int = 0
     norm_topk_prob: bool = True
     router_aux_loss_coef: float = 0.0
+    # router options of the reference's native MoE (``realhf/api/core/model_api.py:302-335``,
+    # ``realhf/impl/model/modules/moe/router.py``): "aux_loss" (top-k of the softmax + load-balancing loss), "sinkhorn"
+    # (balanced assignment by Sinkhorn normalisation while training) or "none"; z-loss on the router logits; a capacity
+    # of capacity_factor * tokens * k / experts per expert, pairs beyond it dropped by lowest probability ("probs") or
+    # latest position ("position"); multiplicative input jitter in [1 - eps, 1 + eps] on the router's input
+    moe_routing_type: str = "aux_loss"
+    moe_z_loss_coef: float = 0.0
+    moe_capacity_factor: Optional[float] = None
+    moe_token_drop_policy: str = "probs"
+    moe_pad_to_capacity: bool = False  # accepted: dispatch here is shape-dynamic, padding would change no result
+    moe_input_jitter_eps: Optional[float] = None
+    # dropout (GPT-2 style checkpoints carry non-zero values; RL recipes switch it off with `disable_dropout`)
+    embd_pdrop: float = 0.0
+    resid_pdrop: float = 0.0
+    attn_pdrop: float = 0.0
     bos_token_id: Optional[int] = None
     eos_token_id: Optional[int] = None
     pad_token_id: Optional[int] = None
@@ -125,7 +140,9 @@ class ModelConfig:
                        rms_norm_eps=d.get("layer_norm_epsilon", 1e-5), max_position_embeddings=d.get("n_positions", 1024),
                        tie_word_embeddings=bool(d.get("tie_word_embeddings", True)), qkv_bias=True,
                        hidden_act="gelu_tanh", norm_type="layer", pos_embed="learned", mlp_gated=False,
-                       linear_bias=True, is_critic=is_critic, bos_token_id=d.get("bos_token_id"),
+                       linear_bias=True, is_critic=is_critic, embd_pdrop=float(d.get("embd_pdrop", 0.0) or 0.0),
+                       resid_pdrop=float(d.get("resid_pdrop", 0.0) or 0.0), attn_pdrop=float(d.get("attn_pdrop", 0.0) or 0.0),
+                       bos_token_id=d.get("bos_token_id"),
                        eos_token_id=d.get("eos_token_id"), pad_token_id=d.get("pad_token_id"))
         H = d["hidden_size"]
         nq = d["num_attention_heads"]
@@ -162,6 +179,9 @@ class ModelConfig:
             if (d.get("num_local_experts") or d.get("num_experts")) else 0,
             norm_topk_prob=bool(d.get("norm_topk_prob", True)),
             router_aux_loss_coef=float(d.get("router_aux_loss_coef", 0.0) or 0.0),
+            moe_z_loss_coef=float(d.get("router_z_loss_coef", 0.0) or 0.0),
+            moe_input_jitter_eps=d.get("router_jitter_noise") or None,
+            attn_pdrop=float(d.get("attention_dropout", 0.0) or 0.0),
             bos_token_id=d.get("bos_token_id"),
             eos_token_id=d.get("eos_token_id") if not isinstance(d.get("eos_token_id"), list) else d["eos_token_id"][0],
             pad_token_id=d.get("pad_token_id"),

@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..utils import rng
 from .config import ModelConfig
 
 ALIGN = 128  # elements; keeps every parameter 256-byte aligned inside the flat buffer
@@ -161,6 +162,13 @@ class Attention(nn.Module):
         qkv = qkv.view(T, self.hq + 2 * self.hkv, D)
         if sp is not None:
             attn = sp.attention(qkv, self.hq, self.hkv, cu_seqlens, max_seqlen)
+        elif self.cfg.attn_pdrop > 0 and self.training:
+            # dropout on the attention probabilities: the fused kernels have none, the per-sequence library path does
+            # (its masks come from the framework's generator, which activation recomputation saves and restores; the
+            # heads are sharded over the tensor-parallel group, whose ranks are seeded apart)
+            attn = ops.attention_varlen_sdpa(qkv[:, :self.hq], qkv[:, self.hq:self.hq + self.hkv],
+                                             qkv[:, self.hq + self.hkv:], cu_seqlens, cu_seqlens, 1.0 / math.sqrt(D),
+                                             dropout_p=self.cfg.attn_pdrop)
         else:
             attn = ops.flash_attn_varlen_qkv(qkv, cu_seqlens, max_seqlen, self.hq, self.hkv)
         out = ops.linear(attn.reshape(T, -1), self.o)
@@ -260,34 +268,100 @@ class MoE(nn.Module):
         out = self._route(xs, _AllReduceBwd.apply(self.router, tp_group), ep_group, valid, 1.0 / n)
         return tpar.GatherForReplicatedUse.apply(out, tp_group)[:T]
 
+    @staticmethod
+    def _sinkhorn(logits: torch.Tensor, iters: int = 64, tol: float = 1e-4) -> torch.Tensor:
+        """Sinkhorn-Knopp normalisation of exp(logits) [T, E]: rows and columns are rescaled alternately until every
+        token carries weight 1/T and every expert receives 1/E. Carried out on log-potentials (a router that
+        strongly favours one expert does not underflow the others); the convergence test runs every eight sweeps
+        (one host synchronisation each) instead of after every sweep."""
+        lk = logits.detach().float()
+        T, E = lk.shape
+        f = torch.zeros(T, device=lk.device)
+        g = torch.zeros(E, device=lk.device)
+        for it in range(iters):
+            prev = g
+            f = -torch.logsumexp(lk + g.unsqueeze(0), 1) - math.log(T)
+            g = -torch.logsumexp(lk + f.unsqueeze(1), 0) - math.log(E)
+            if it % 8 == 7 and float((prev - g).abs().max()) <= tol:
+                break
+        return torch.exp(lk + f.unsqueeze(1) + g.unsqueeze(0))
+
     def _route(self, x, router, ep_group, n_valid: int, aux_scale: float):
-        """Route the rows of `x` (the first `n_valid` are real tokens) to their experts and combine the outputs."""
+        """Route the rows of `x` (the first `n_valid` are real tokens) to their experts and combine the outputs.
+        Router options: see `ModelConfig.moe_*` (reference ``realhf/impl/model/modules/moe/router.py:53-161``,
+        ``realhf/impl/model/utils/moe.py:54-100,310-390``)."""
         cfg = self.cfg
         T, H = x.shape
-        logits = F.linear(x, router).float()
+        E, k = cfg.n_experts, cfg.n_experts_per_tok
+        xr = x
+        if cfg.moe_input_jitter_eps and self.training:  # the router alone sees the jittered input
+            eps = float(cfg.moe_input_jitter_eps)
+            xr = x * torch.empty_like(x).uniform_(1.0 - eps, 1.0 + eps)
+        logits = F.linear(xr, router).float()
+        aux = None
+        if cfg.moe_z_loss_coef > 0 and self.training and n_valid > 0:
+            aux = aux_scale * cfg.moe_z_loss_coef * torch.logsumexp(logits[:n_valid], -1).square().mean()
         probs = torch.softmax(logits, -1)
-        topv, topi = torch.topk(probs, cfg.n_experts_per_tok, -1)
-        if cfg.norm_topk_prob:
-            topv = topv / topv.sum(-1, keepdim=True)
-        if cfg.router_aux_loss_coef > 0 and self.training:
+        if cfg.moe_routing_type == "sinkhorn":
+            act = torch.sigmoid(logits) if k == 1 else probs
+            if self.training:
+                with torch.no_grad():
+                    topi = torch.topk(self._sinkhorn(logits.detach()), k, -1).indices
+                topv = torch.gather(act, 1, topi)
+            else:
+                topv, topi = torch.topk(act, k, -1)
+        else:
+            assert cfg.moe_routing_type in ("aux_loss", "none"), f"unknown MoE routing type {cfg.moe_routing_type}"
+            topv, topi = torch.topk(probs, k, -1)
+            if cfg.norm_topk_prob:
+                topv = topv / topv.sum(-1, keepdim=True)
+        if cfg.moe_routing_type == "aux_loss" and cfg.router_aux_loss_coef > 0 and self.training:
             ti, pr = topi[:n_valid], probs[:n_valid]
-            frac = torch.zeros(cfg.n_experts, device=x.device).index_add_(
+            frac = torch.zeros(E, device=x.device).index_add_(
                 0, ti.reshape(-1), torch.ones(ti.numel(), device=x.device)) / max(1, ti.numel())
             mean_p = pr.mean(0) if n_valid > 0 else probs.sum(0) * 0.0
-            self.aux_loss = aux_scale * cfg.router_aux_loss_coef * cfg.n_experts * (frac * mean_p).sum()
-        k = cfg.n_experts_per_tok
+            lb = aux_scale * cfg.router_aux_loss_coef * E * (frac * mean_p).sum()
+            aux = lb if aux is None else aux + lb
+        if self.training:
+            self.aux_loss = aux
         flat_e = topi.reshape(-1)
+        n_drop = 0
+        if cfg.moe_capacity_factor is not None:
+            # at most `cap` (token, choice) pairs per expert; the rest are dropped: they get weight zero and the
+            # sentinel expert E, which sorts them behind every real expert's slab, where no expert touches them
+            cap = max(1, math.ceil(max(1, n_valid) * k / E * float(cfg.moe_capacity_factor)))
+            if cfg.moe_token_drop_policy == "probs":
+                prio = torch.argsort(topv.detach().reshape(-1), descending=True, stable=True)
+            else:
+                assert cfg.moe_token_drop_policy == "position", cfg.moe_token_drop_policy
+                prio = torch.arange(T * k, device=x.device)
+            by_e = prio[torch.argsort(flat_e[prio], stable=True)]  # pairs grouped by expert, best first inside
+            e_sorted = flat_e[by_e]
+            start = torch.searchsorted(e_sorted, torch.arange(E, device=x.device))
+            rank_in_e = torch.arange(T * k, device=x.device) - start[e_sorted]
+            dropped = torch.zeros(T * k, dtype=torch.bool, device=x.device)
+            dropped[by_e] = rank_in_e >= cap
+            if n_valid < T:  # padding rows never occupy capacity
+                dropped[n_valid * k:] = True
+            topv = topv.masked_fill(dropped.view(T, k), 0.0)
+            flat_e = flat_e.masked_fill(dropped, E)
         order = torch.argsort(flat_e, stable=True)  # expert-sorted position -> (token, choice) pair t*k + j
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=order.device)
         xs = ops.moe_permute(x, order, inv, k)
-        counts = torch.bincount(flat_e, minlength=cfg.n_experts)
+        counts = torch.bincount(flat_e, minlength=E + 1)
+        if cfg.moe_capacity_factor is not None:
+            n_drop = int(counts[E])
+        counts = counts[:E]
+        n_keep = T * k - n_drop
         if ep_group is not None and self.ep_size > 1:
             from ..parallel.expert_parallel import ep_dispatch_combine
 
-            ys = ep_dispatch_combine(self, xs, counts, ep_group)
+            ys = ep_dispatch_combine(self, xs[:n_keep], counts, ep_group)
         else:
-            ys = self._experts(xs, counts.tolist())
+            ys = self._experts(xs[:n_keep], counts.tolist())
+        if n_drop:
+            ys = torch.cat([ys, ys.new_zeros(n_drop, ys.shape[1])])
         # every token gathers its k expert outputs (no scatter-add: each output row is written once)
         return ops.moe_combine(ys, topv, order, inv)
 
@@ -306,6 +380,7 @@ class Block(nn.Module):
     def __init__(self, cfg: ModelConfig, tp_size, dtype, device, ep_size=1, ep_rank=0, etp_size=None):
         super().__init__()
         self.cfg = cfg
+        self.layer_id = 0  # global layer index (keys the dropout masks); set by the Transformer
         etp_size = tp_size if etp_size is None else etp_size
         self.ln1 = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
         self.attn = Attention(cfg, tp_size, dtype, device)
@@ -325,11 +400,15 @@ class Block(nn.Module):
         cfg = self.cfg
         x, residual = add_norm(cfg, h, self.ln1, getattr(self, "ln1_bias", None), residual)
         h = self.attn(x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp, seq_par)
+        if cfg.resid_pdrop > 0:  # the residual stream is token-sharded under sequence parallelism, replicated otherwise
+            h = rng.dropout(h, cfg.resid_pdrop, self.layer_id, 1, sharded=seq_par, training=self.training)
         x, residual = add_norm(cfg, h, self.ln2, getattr(self, "ln2_bias", None), residual)
         if cfg.n_experts > 0:
             h = self.mlp(x, tp_group, ep_group)
         else:
             h = self.mlp(x, tp_group, seq_par)
+        if cfg.resid_pdrop > 0:
+            h = rng.dropout(h, cfg.resid_pdrop, self.layer_id, 2, sharded=seq_par, training=self.training)
         return h, residual
 
 
@@ -391,6 +470,8 @@ class Transformer(nn.Module):
         self.layers = nn.ModuleList(
             [Block(cfg, tp_size, dtype, device, ep_size, ep_rank, etp_size) for _ in self.layer_ids]
         )
+        for blk, gid in zip(self.layers, self.layer_ids):
+            blk.layer_id = gid
         if has_head:
             self.norm = nn.Parameter(torch.ones(cfg.hidden_size, dtype=dtype, device=device))
             if cfg.norm_type == "layer":
@@ -474,6 +555,8 @@ class Transformer(nn.Module):
             h = h * math.sqrt(self.cfg.hidden_size)
         if self.cfg.pos_embed == "learned":
             h = h + ops.embedding(positions.long(), self.pos_embed)
+        if self.cfg.embd_pdrop > 0:
+            h = rng.dropout(h, self.cfg.embd_pdrop, -1, 0, sharded=scatter, training=self.training)
         return h
 
     def embed_multimodal(self, input_ids: torch.Tensor, pixel_values: Optional[torch.Tensor],

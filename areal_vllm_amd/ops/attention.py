@@ -48,7 +48,7 @@ def attention_varlen_ref(q, k, v, cu_q, cu_k, scale, causal=True):
     return out.to(q.dtype), lse
 
 
-def attention_varlen_sdpa(q, k, v, cu_q, cu_k, scale, causal=True):
+def attention_varlen_sdpa(q, k, v, cu_q, cu_k, scale, causal=True, dropout_p: float = 0.0):
     """Head sizes the MFMA kernels do not take on the GPU (they are built for D = 128, the head size of the
     Qwen2 / Llama-3 8B+ families, and D = 256 of Gemma; other sizes that are multiples of 8 run on them
     zero-padded, see `_pad_heads`; what is left - above 256, or no multiple of 8 - comes here): PyTorch's fused
@@ -72,7 +72,7 @@ def attention_varlen_sdpa(q, k, v, cu_q, cu_k, scale, causal=True):
             j = torch.arange(Lk, device=q.device).unsqueeze(0)
             mask = j <= i + (Lk - Lq)
         o = F.scaled_dot_product_attention(qs, ks, vs, attn_mask=mask, is_causal=causal and mask is None, scale=scale,
-                                           enable_gqa=Hq != Hkv)
+                                           enable_gqa=Hq != Hkv, dropout_p=float(dropout_p))
         outs.append(o[0].transpose(0, 1))
     return torch.cat(outs, 0)
 
