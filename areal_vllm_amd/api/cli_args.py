@@ -263,9 +263,28 @@ class InferenceServerConfig:
     enable_metrics: bool = True
     decode_log_interval: int = 1
 
+    def reject_unsupported(self) -> None:
+        """Options that change what the server computes or where its memory lives, and that this engine
+        does not implement, are errors - never silently ignored. (Options that only pick between
+        third-party kernel back ends stay accepted: there is one HIP implementation.)"""
+        if str(self.kv_cache_dtype) not in ("auto", "bfloat16", "bf16"):
+            raise ValueError(f"kv_cache_dtype={self.kv_cache_dtype!r}: the paged KV cache is stored in the model "
+                             "dtype (bf16) only; use kv_cache_dtype=auto")
+        if self.cpu_offload_gb and float(self.cpu_offload_gb) > 0:
+            raise ValueError(f"cpu_offload_gb={self.cpu_offload_gb}: weights are resident in HBM (288 GB per GPU); "
+                             "host offload of server weights is not implemented - use tensor parallelism instead")
+        if self.enable_memory_saver:
+            raise ValueError("enable_memory_saver: releasing and re-mapping the server's KV cache and weights is not "
+                             "implemented; colocated runs size the KV cache with `kv_cache_gb` / mem_fraction_static")
+        if str(self.dtype) not in ("bfloat16", "float32"):
+            raise ValueError(f"dtype={self.dtype!r}: the server computes in bfloat16 (or float32 on the CPU platform)")
+        if self.torchao_config:
+            raise ValueError(f"torchao_config={self.torchao_config!r}: weight quantisation is not implemented")
+
     @staticmethod
     def build_args(config: "InferenceServerConfig", tp_size, base_gpu_id, host, port,
                    dist_init_addr: Optional[str] = None, n_nodes: int = 1, node_rank: int = 0) -> Dict[str, Any]:
+        config.reject_unsupported()
         args = dict(
             host=host, port=port, tokenizer_path=config.model_path, tp_size=tp_size, base_gpu_id=base_gpu_id,
             nnodes=n_nodes, node_rank=node_rank, dist_init_addr=dist_init_addr,

@@ -126,6 +126,7 @@ class NativeInferenceEngine:
     # ------------------------------------------------------------------------------ set-up
     def initialize(self, load_weights: bool = True):
         cfg, mc = self.config, self.model_config
+        cfg.reject_unsupported()
         self.model = Transformer(mc, dtype=self.dtype, device=self.device, tp_size=self.tp_size, tp_rank=self.tp_rank,
                                  tp_group=self.tp_group)
         self.model.requires_grad_(False)

@@ -95,6 +95,9 @@ class LocalLauncher:
             if gpu > 0:
                 if not self._devices:
                     logger.warning("no GPU visible to the local launcher: children run on the CPU platform")
+                    # many ranks share the host's cores: one math thread each (what torchrun does for its
+                    # workers), or every process spins a full OpenMP team
+                    env.setdefault("OMP_NUM_THREADS", "1")
                 else:
                     ids = []
                     for _ in range(gpu):
