@@ -71,6 +71,11 @@ class ModelRunner:
         self.plain_family = cfg.norm_type != "rms" or not cfg.mlp_gated or cfg.linear_bias or cfg.pos_embed != "rope"
         self.step_counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._gloo_group = None  # lazily: is the tp group a host backend (one-GPU rehearsal)
+        # do the projections' outputs go through the tp group's all-reduce (and the sampled tokens through its
+        # broadcast)? Also for a group of one when collectives are forced: RCCL calls inside the decode graph
+        from ..parallel import comm as _comm
+
+        self.tp_comm = model.tp_size > 1 or (_comm.FORCE_COLLECTIVES and torch.distributed.is_initialized())
         self.ipc_ar = None  # peer-memory all-reduce of the tp group (ops/ipc_allreduce.py), set by the engine
         self.graphs: Dict[int, Any] = {}
         self.static: Dict[int, Dict[str, torch.Tensor]] = {}
@@ -174,14 +179,14 @@ class ModelRunner:
         qkv = blk.attn.project_qkv(x)
         attn = attn_fn(blk, qkv)
         h = F.linear(attn.reshape(attn.shape[0], -1), blk.attn.o)
-        if self.model.tp_size > 1:
+        if self.tp_comm:
             self._tp_all_reduce(h)
         x, residual = ops.rmsnorm(h, blk.ln2, cfg.rms_norm_eps, residual, cfg.gemma_norm)
         if cfg.n_experts > 0:
             h = blk.mlp(x, None, self.model.ep_group)
         else:
             h = F.linear(ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act), blk.mlp.down)
-        if self.model.tp_size > 1:
+        if self.tp_comm:
             self._tp_all_reduce(h)
         return h, residual
 
@@ -192,7 +197,7 @@ class ModelRunner:
         from ..models.transformer import add_norm
 
         cfg = self.cfg
-        tp = self.model.tp_size > 1
+        tp = self.tp_comm
         x, residual = add_norm(cfg, h, blk.ln1, getattr(blk, "ln1_bias", None), residual)
         attn = attn_fn(blk, blk.attn.project_qkv(x))
         h = F.linear(attn.reshape(attn.shape[0], -1), blk.attn.o)
@@ -246,7 +251,7 @@ class ModelRunner:
         left out: that kernel sums every rank's data in rank order on every rank, so the ranks hold bit-identical
         activations by construction, and a decode plan then contains no collective that could wait for a missing
         peer without a time limit."""
-        if self.model.tp_size > 1 and self.ipc_ar is None:
+        if self.tp_comm and self.ipc_ar is None:
             import torch.distributed as dist
 
             src = dist.get_global_rank(self.model.tp_group, 0) if self.model.tp_group is not None else 0
@@ -474,7 +479,7 @@ class ModelRunner:
         eps, gemma = cfg.rms_norm_eps, cfg.gemma_norm
         layers = self.model.layers
         gate_up_mode = self._gate_up_mode(Bp)
-        tp = self.model.tp_size > 1
+        tp = self.tp_comm
 
         def finish(slab, residual, weight):
             """Split-K slabs of a projection -> (normalised input of the next GEMM, new residual stream). A

@@ -3,10 +3,18 @@
 gloo lacks reduce_scatter_tensor, so the CPU path emulates it with an all-reduce and a slice; the
 numerical result is the same, which is what the gloo fake-cluster tests rely on.
 """
+import os
 from typing import Optional
 
 import torch
 import torch.distributed as dist
+
+# A group of ONE rank normally short-cuts every collective into a local copy. With this switch the data-parallel
+# collectives (ZeRO-1 bucket reduce-scatter / all-gather, ZeRO-3 gathers and reductions, norm all-reduces) go
+# through the backend anyway: on a single MI355X that runs the real RCCL enqueue path - stream ordering against
+# the compute stream, asynchronous work handles, bucket order, graph capture - which the host-backend rehearsals
+# of multi-rank layouts cannot show.
+FORCE_COLLECTIVES = os.environ.get("AREAL_FORCE_COLLECTIVES", "0") == "1"
 
 
 def group_size(group) -> int:
@@ -21,6 +29,13 @@ def group_rank(group) -> int:
     return dist.get_rank(group)
 
 
+def trivial(group) -> bool:
+    """True when collectives over `group` may be replaced by local copies."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size(group) == 1 and not FORCE_COLLECTIVES
+
+
 def _is_nccl(t: torch.Tensor) -> bool:
     return t.is_cuda
 
@@ -28,7 +43,7 @@ def _is_nccl(t: torch.Tensor) -> bool:
 def reduce_scatter_sum(out_shard: torch.Tensor, full: torch.Tensor, group) -> None:
     """out_shard = sum over ranks of full[rank_slice]."""
     n = group_size(group)
-    if n == 1:
+    if trivial(group):
         if out_shard.data_ptr() != full.data_ptr():
             out_shard.copy_(full[: out_shard.numel()])
         return
@@ -44,7 +59,7 @@ def reduce_scatter_sum(out_shard: torch.Tensor, full: torch.Tensor, group) -> No
 def all_gather_flat(full: torch.Tensor, shard: torch.Tensor, group) -> None:
     """full = concat over ranks of shard (shard may alias full's own slice)."""
     n = group_size(group)
-    if n == 1:
+    if trivial(group):
         if shard.data_ptr() != full.data_ptr():
             full[: shard.numel()].copy_(shard)
         return
@@ -58,13 +73,13 @@ def all_gather_flat(full: torch.Tensor, shard: torch.Tensor, group) -> None:
 
 
 def all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
-    if group_size(group) > 1:
+    if not trivial(group):
         dist.all_reduce(t, group=group)
     return t
 
 
 def all_reduce_max(t: torch.Tensor, group) -> torch.Tensor:
-    if group_size(group) > 1:
+    if not trivial(group):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t
 

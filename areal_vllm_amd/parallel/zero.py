@@ -51,12 +51,13 @@ class ShardedAdamW:
         self.mp_groups = [g for g in mp_groups if g is not None and comm.group_size(g) > 1]
         self.n = comm.group_size(dp_group)
         self.rank = comm.group_rank(dp_group)
+        self.solo = comm.trivial(dp_group)  # nothing to reduce or gather: the fp32 gradient buffer is the shard
         assert flat.numel % self.n == 0, "flat buffer must be padded to a multiple of the dp size"
         self.shard_numel = flat.numel // self.n
         # ---- block-cyclic layout: bucket g = flat[n * cut[g] : n * cut[g + 1]], this rank's piece of it starts
         # `rank` piece lengths into the bucket; in the rank's shard (master, moments, reduced gradients) the pieces
         # follow each other, piece g at shard[cut[g] : cut[g + 1]]
-        G = 1 if self.n == 1 else max(1, min(int(n_buckets or N_BUCKETS), self.shard_numel // 8 or 1))
+        G = 1 if self.solo else max(1, min(int(n_buckets or N_BUCKETS), self.shard_numel // 8 or 1))
         cuts = sorted({min(self.shard_numel, (g * self.shard_numel // G + 7) // 8 * 8) for g in range(G)} | {0})
         self.cuts: List[int] = cuts + [self.shard_numel]
         self.buckets: List[Tuple[int, int]] = [(self.n * a, self.n * b) for a, b in zip(self.cuts, self.cuts[1:])]
@@ -68,7 +69,7 @@ class ShardedAdamW:
         self.v = torch.zeros_like(self.master)
         self.state = torch.zeros(ops.optim.STATE_SIZE, dtype=torch.float32, device=dev)
         self.grad_shard = (torch.empty(self.shard_numel, dtype=torch.float32, device=dev)
-                           if self.n > 1 else None)
+                           if not self.solo else None)
         self.replicated_ranges = sorted(replicated_ranges or [])
         self._norm_buf = torch.zeros(2, dtype=torch.float32, device=dev)
         self.lr = cfg.lr
@@ -82,7 +83,7 @@ class ShardedAdamW:
         self._works: List = []
         self._next = -1  # next bucket to launch (descending)
         self.overlapped_buckets = 0  # buckets that left during a backward pass (all steps so far)
-        if self.n > 1:
+        if not self.solo:
             starts = [b[0] for b in self.buckets]
             for name, (o, numel) in flat.offsets.items():
                 p = flat._named[name]
@@ -112,7 +113,7 @@ class ShardedAdamW:
         """Call right before the LAST backward pass of a step: from now on a bucket's reduce-scatter leaves as
         soon as every parameter touching it - and every bucket above it - has folded its gradient into the fp32
         buffer."""
-        if self.n == 1:
+        if self.solo:
             return
         self._armed = True
         self._pending = list(self._bucket_params)
@@ -158,7 +159,7 @@ class ShardedAdamW:
     # ------------------------------------------------------------------ gradient reduction
     def reduce_gradients(self):
         g = self.flat.main_grad
-        if self.n == 1:
+        if self.solo:
             return g
         if self._armed:
             # buckets some of whose parameters got no gradient in the last backward (a vision tower on a rank

@@ -118,6 +118,7 @@ class Zero3:
         self.group = group
         self.tp_group = tp_group if comm.group_size(tp_group) > 1 else None
         self.n = comm.group_size(group)
+        self.solo = comm.trivial(group)
         self.rank = comm.group_rank(group)
         self.reshard_after_forward = reshard_after_forward
         self.offload = offload_optimizer
@@ -290,7 +291,7 @@ class Zero3:
         if g is None:
             return
         dst = self.grad_shard[u.shard_off:u.shard_off + u.numel // self.n]
-        if self.cuda and self.n > 1:
+        if self.cuda and not self.solo:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 tmp = torch.empty_like(dst)
@@ -300,7 +301,7 @@ class Zero3:
                 ev.record(self.comm_stream)
             g.record_stream(self.comm_stream)
             self._events.append(ev)
-        elif self.n > 1:
+        elif not self.solo:
             tmp = torch.empty_like(dst)
             comm.reduce_scatter_sum(tmp, g, self.group)
             dst.add_(tmp)

@@ -1,11 +1,21 @@
-"""GRPO / PPO training loop shared by the RL example scripts.
+"""GRPO / PPO trainer shared by the RL example scripts.
 
-One SPMD process per train GPU. Per step: collect a batch (asynchronously with bounded staleness, or
-synchronously), recompute proximal log-probs, reference log-probs and critic values when configured,
-compute advantages, update, then pause rollouts -> push weights -> bump versions -> save / evaluate /
-write recover info -> log -> resume. The control flow is the reference's
-``examples/math/gsm8k_grpo.py:33-295``; it is a library function here so that every example (math,
-multi-turn, vision, PPO with a critic) reuses one loop.
+One SPMD process per train GPU runs an `RLTrainer`. A training step is five phases, each a method:
+
+1. ``collect``       a batch of finished rollouts (asynchronously with bounded staleness, or synchronously),
+                     handed from the data-parallel head to the ranks of its replica;
+2. ``score``         proximal / reference log-probs and critic values where configured, then advantages;
+3. ``update``        critic and actor mini-batch updates, learning-rate schedules;
+4. ``publish``       rollouts paused -> weights pushed (in-process copy, peer-memory pull, collective push or
+                     files) -> versions bumped; generation RESUMES here unless an evaluation is due;
+5. ``housekeeping``  periodic checkpoint, evaluation, recover checkpoint, statistics - with the servers already
+                     generating the next batches underneath (the reference keeps them paused until the step's
+                     log line is written, ``examples/math/gsm8k_grpo.py:218-292``; a checkpoint of a 7B model
+                     is seconds of idle rollout GPUs per save).
+
+What a step computes and the order of its side effects on versions follow the reference's
+``examples/math/gsm8k_grpo.py:33-295``; every example (math, multi-turn, vision, PPO with a critic, search
+agent) drives this one class through `run_grpo`.
 
 Rollout deployment is chosen from the launch environment:
 
@@ -24,17 +34,12 @@ import torch.distributed as dist
 
 from ..api.alloc_mode import AllocationMode
 from ..api.cli_args import GRPOConfig, InferenceEngineConfig, PPOConfig, load_expr_config
-from ..api.io_struct import FinetuneSpec, StepInfo, WeightUpdateMeta
-from ..dataset import get_custom_dataset
+from ..api.io_struct import StepInfo, WeightUpdateMeta
 from ..engine.ppo.actor import NativePPOActor
-from ..platforms import current_platform
 from ..utils import logging, seeding, stats_tracker
 from ..utils.data import broadcast_tensor_container, to_device
-from ..utils.dataloader import StatefulDataLoader
-from ..utils.evaluator import Evaluator
-from ..utils.recover import RecoverHandler
-from ..utils.saver import Saver
 from ..utils.stats_logger import StatsLogger
+from .common import PeriodicActions, StepBudget, build_dataloaders, sync_ranks
 
 logger = logging.getLogger("rl-trainer")
 
@@ -100,190 +105,203 @@ def build_rollout_engines(config: GRPOConfig, actor: NativePPOActor, parallel_st
     return rollout, eval_rollout, WeightUpdateMeta.from_inproc(), engine
 
 
+class RLTrainer:
+    """Owns the engines, data and periodic actions of one trainer rank; `run()` steps until the budget is spent."""
+
+    def __init__(self, argv, reward_fn: Optional[Callable] = None,
+                 workflow_builder: Optional[Callable[[Any, Any, Callable, str], Tuple[Any, Any]]] = None,
+                 config_cls=GRPOConfig, load_tokenizer: bool = True):
+        self.config, _ = load_expr_config(argv, config_cls)
+        config = self.config
+        self.rank = int(os.getenv("RANK", "0"))
+        self.tokenizer = None
+        if load_tokenizer and config.tokenizer_path and os.path.isdir(config.tokenizer_path):
+            from ..utils.hf_utils import load_hf_tokenizer
+
+            self.tokenizer = load_hf_tokenizer(config.tokenizer_path)
+        seeding.set_random_seed(config.seed, key=f"trainer{self.rank}")
+        self.parallel_strategy = AllocationMode.from_str(config.allocation_mode).train
+
+        self.actor = NativePPOActor(config=config.actor)
+        self.actor.create_process_group(parallel_strategy=self.parallel_strategy)
+        self.train_dataloader, self.valid_dataloader, self.ft_spec = build_dataloaders(config, self.actor, "rl",
+                                                                                       self.tokenizer)
+        self._build_models()
+        self.rollout, self.eval_rollout, self.weight_update_meta, self.local_engine = build_rollout_engines(
+            config, self.actor, self.parallel_strategy)
+        self._build_workflows(reward_fn, workflow_builder)
+        self.periodic = PeriodicActions(config, self.ft_spec)
+        recovered = self.periodic.load(self.actor, self.train_dataloader, inference_engine=self.rollout,
+                                       weight_update_meta=self.weight_update_meta)
+        self.budget = StepBudget(config, len(self.train_dataloader), recovered)
+        self._sync_batches = itertools.cycle(self.train_dataloader)
+        self._generating = True  # rollout engines start un-paused
+
+    # ------------------------------------------------------------------------------ set-up
+    def _build_models(self):
+        config = self.config
+        self.actor.initialize(None, self.ft_spec)
+        self.ref = None
+        if config.actor.kl_ctl > 0 and config.ref is not None and config.ref.path:
+            self.ref = NativePPOActor(config=config.ref)
+            self.ref.create_process_group(parallel_strategy=self.parallel_strategy)
+            self.ref.initialize(None, self.ft_spec)
+        self.critic = None
+        if isinstance(config, PPOConfig) and config.critic.path:
+            from ..engine.ppo.critic import NativePPOCritic
+
+            self.critic = NativePPOCritic(config=config.critic)
+            self.critic.create_process_group(parallel_strategy=self.parallel_strategy)
+            self.critic.initialize(None, self.ft_spec)
+
+    def _build_workflows(self, reward_fn, workflow_builder):
+        config, tokenizer = self.config, self.tokenizer
+        if reward_fn is None:
+            from ..reward import get_custom_reward_fn
+
+            reward_fn = get_custom_reward_fn(config.train_dataset.reward_fn or config.train_dataset.path)
+        if tokenizer is not None:
+            for t in (tokenizer.pad_token_id, tokenizer.eos_token_id):
+                if t is not None and t not in config.gconfig.stop_token_ids:
+                    config.gconfig.stop_token_ids.append(t)
+        log_dir = StatsLogger.get_log_path(config.stats_logger)
+        if workflow_builder is not None:
+            self.workflow, self.eval_workflow = workflow_builder(config, tokenizer, reward_fn, log_dir)
+            return
+        from ..workflow.rlvr import RLVRWorkflow
+
+        in_proc = config.train_dataset.path.startswith("synthetic:")
+        self.workflow = RLVRWorkflow(reward_fn, config.gconfig, tokenizer, dump_dir=os.path.join(log_dir, "generated"),
+                                     reward_in_process=in_proc)
+        self.eval_workflow = RLVRWorkflow(reward_fn, config.gconfig.new(temperature=0.6), tokenizer,
+                                          rollout_stat_scope="eval-rollout", reward_in_process=in_proc,
+                                          dump_dir=os.path.join(log_dir, "generated-eval"))
+
+    # ------------------------------------------------------------------------------ helpers
+    def _pause_generation(self):
+        if self.rollout is not None and self._generating:
+            self.rollout.pause()
+        self._generating = False
+
+    def _resume_generation(self):
+        if self.rollout is not None and not self._generating:
+            self.rollout.resume()
+        self._generating = True
+
+    # ------------------------------------------------------------------------------ phases
+    def collect(self) -> Dict[str, Any]:
+        """The data-parallel head of every replica takes a batch from its rollout engine; the other ranks of the
+        replica (tensor / pipeline / context parallel) receive it."""
+        actor = self.actor
+        with stats_tracker.record_timing("rollout"):
+            batch = None
+            if actor.is_data_parallel_head():
+                if self.config.async_training:
+                    batch = self.rollout.prepare_batch(self.train_dataloader, workflow=self.workflow)
+                else:
+                    batch = self.rollout.rollout_batch(next(self._sync_batches), workflow=self.workflow)
+                batch = to_device(batch, actor.device)
+            batch = broadcast_tensor_container(batch, src_rank=actor.current_data_parallel_head(),
+                                               group=actor.context_and_model_parallel_group)
+        sync_ranks()
+        return batch
+
+    def score(self, batch: Dict[str, Any]) -> None:
+        """Everything the loss needs that is not a gradient: log-probs under the current policy (the proximal
+        policy of the decoupled objective; skipped when the update computes it in its own forward), under the
+        reference policy, critic values, and the advantages made from them."""
+        ac = self.config.actor
+        fused_prox = ac.fuse_proximal_logp and ac.use_decoupled_loss and ac.ppo_n_minibatches == 1
+        if (ac.recompute_logprob or ac.use_decoupled_loss) and not fused_prox:
+            with stats_tracker.record_timing("recompute_logp"):
+                batch["prox_logp"] = self.actor.compute_logp(batch)
+        if self.ref is not None:
+            with stats_tracker.record_timing("ref_logp"):
+                batch["ref_logp"] = self.ref.compute_logp(batch)
+        if self.critic is not None:
+            with stats_tracker.record_timing("critic_values"):
+                batch["values"] = self.critic.compute_values(batch)
+        with stats_tracker.record_timing("compute_advantage"):
+            self.actor.compute_advantages(batch)
+
+    def update(self, batch: Dict[str, Any]):
+        critic_stats = []
+        if self.critic is not None:
+            with stats_tracker.record_timing("critic_train_step"), stats_tracker.scope("ppo_critic"):
+                critic_stats = self.critic.ppo_update(batch)
+                self.critic.step_lr_scheduler()
+        with stats_tracker.record_timing("train_step"), stats_tracker.scope("grpo_actor"):
+            stats = self.actor.ppo_update(batch)
+            self.actor.step_lr_scheduler()
+        if critic_stats:
+            stats[0].update(critic_stats[0])
+        return stats
+
+    def publish(self, version: int) -> None:
+        """New weights to the rollout engines, under a pause; every engine then stamps tokens with `version`."""
+        meta = self.weight_update_meta
+        self._pause_generation()
+        with stats_tracker.record_timing("update_weights"):
+            pending = None
+            if self.rollout is not None and (meta.type == "inproc" or self.rank == 0):
+                pending = self.rollout.update_weights(meta)  # the servers' side of the hand-over
+            self.actor.upload_weights(meta)  # the trainer's side
+            if pending is not None:
+                pending.result()
+            sync_ranks()
+            self.actor.set_version(version)
+            if self.rollout is not None:
+                self.rollout.set_version(version)
+                self.eval_rollout.set_version(version)
+
+    def _evaluate(self):
+        if self.valid_dataloader is None or self.eval_rollout is None:
+            return
+        self.eval_rollout.resume()
+        n = 0
+        for data in self.valid_dataloader:
+            for item in data:
+                self.eval_rollout.submit(item, self.eval_workflow)
+                n += 1
+        self.eval_rollout.wait(n, timeout=None)
+        self.eval_rollout.pause()
+
+    def housekeeping(self, info: StepInfo, stats) -> None:
+        """Checkpoint / evaluation / recover checkpoint / statistics. Training rollouts resume before any of it
+        unless an evaluation is due (its prompts have the engines to themselves), and at the end otherwise."""
+        self.periodic.after_step(self.actor, info, stats, self.train_dataloader, evaluate_fn=self._evaluate,
+                                 on_no_eval=self._resume_generation, tokenizer=self.tokenizer)
+        self._resume_generation()
+
+    # ------------------------------------------------------------------------------ driver
+    def step(self, info: StepInfo) -> None:
+        batch = self.collect()
+        self.score(batch)
+        stats = self.update(batch)
+        self.publish(info.global_step + 1)
+        self.housekeeping(info, stats)
+
+    def run(self) -> None:
+        for info in self.budget:
+            self.step(info)
+
+    def close(self) -> None:
+        self.periodic.close()
+        if self.rollout is not None:
+            self.eval_rollout.destroy()
+            self.rollout.destroy()
+        if self.local_engine is not None:
+            self.local_engine.destroy()
+        for e in (self.ref, self.critic, self.actor):
+            if e is not None:
+                e.destroy()
+
+
 def run_grpo(argv, reward_fn: Optional[Callable] = None,
              workflow_builder: Optional[Callable[[Any, Any, Callable, str], Tuple[Any, Any]]] = None,
              config_cls=GRPOConfig, load_tokenizer: bool = True):
     """`workflow_builder(config, tokenizer, reward_fn, log_dir) -> (train_workflow, eval_workflow)`;
     defaults to single-turn RLVR."""
-    config, _ = load_expr_config(argv, config_cls)
-    rank = int(os.getenv("RANK", "0"))
-    tokenizer = None
-    if load_tokenizer and config.tokenizer_path and os.path.isdir(config.tokenizer_path):
-        from ..utils.hf_utils import load_hf_tokenizer
-
-        tokenizer = load_hf_tokenizer(config.tokenizer_path)
-    seeding.set_random_seed(config.seed, key=f"trainer{rank}")
-    allocation_mode = AllocationMode.from_str(config.allocation_mode)
-    parallel_strategy = allocation_mode.train
-
-    actor = NativePPOActor(config=config.actor)
-    actor.create_process_group(parallel_strategy=parallel_strategy)
-    ds_kw = dict(rank=actor.data_parallel_rank, world_size=actor.data_parallel_world_size, tokenizer=tokenizer)
-    train_dataset = get_custom_dataset(path=config.train_dataset.path, split="train",
-                                       max_length=config.train_dataset.max_length, type=config.train_dataset.type or "rl",
-                                       **ds_kw)
-    valid_dataset = None
-    if config.valid_dataset is not None and config.valid_dataset.path:
-        valid_dataset = get_custom_dataset(path=config.valid_dataset.path, split="test",
-                                           max_length=config.valid_dataset.max_length,
-                                           type=config.valid_dataset.type or "rl", **ds_kw)
-    dp = actor.data_parallel_world_size
-    train_dataloader = StatefulDataLoader(train_dataset, batch_size=max(1, config.train_dataset.batch_size // dp),
-                                          shuffle=config.train_dataset.shuffle, drop_last=config.train_dataset.drop_last,
-                                          seed=config.seed)
-    valid_dataloader = None
-    if valid_dataset is not None:
-        valid_dataloader = StatefulDataLoader(valid_dataset, batch_size=max(1, config.valid_dataset.batch_size // dp),
-                                              shuffle=False, drop_last=config.valid_dataset.drop_last)
-    ft_spec = FinetuneSpec(total_train_epochs=config.total_train_epochs,
-                           dataset_size=len(train_dataloader) * config.train_dataset.batch_size,
-                           train_batch_size=config.train_dataset.batch_size)
-
-    actor.initialize(None, ft_spec)
-    ref = None
-    if config.actor.kl_ctl > 0 and config.ref is not None and config.ref.path:
-        ref = NativePPOActor(config=config.ref)
-        ref.create_process_group(parallel_strategy=parallel_strategy)
-        ref.initialize(None, ft_spec)
-    critic = None
-    if isinstance(config, PPOConfig) and config.critic.path:
-        from ..engine.ppo.critic import NativePPOCritic
-
-        critic = NativePPOCritic(config=config.critic)
-        critic.create_process_group(parallel_strategy=parallel_strategy)
-        critic.initialize(None, ft_spec)
-
-    rollout, eval_rollout, weight_update_meta, local_engine = build_rollout_engines(config, actor, parallel_strategy)
-
-    if reward_fn is None:
-        from ..reward import get_custom_reward_fn
-
-        reward_fn = get_custom_reward_fn(config.train_dataset.reward_fn or config.train_dataset.path)
-    if tokenizer is not None:
-        for t in (tokenizer.pad_token_id, tokenizer.eos_token_id):
-            if t is not None and t not in config.gconfig.stop_token_ids:
-                config.gconfig.stop_token_ids.append(t)
-    log_dir = StatsLogger.get_log_path(config.stats_logger)
-    if workflow_builder is None:
-        from ..workflow.rlvr import RLVRWorkflow
-
-        in_proc = config.train_dataset.path.startswith("synthetic:")
-        workflow = RLVRWorkflow(reward_fn, config.gconfig, tokenizer, dump_dir=os.path.join(log_dir, "generated"),
-                                reward_in_process=in_proc)
-        eval_workflow = RLVRWorkflow(reward_fn, config.gconfig.new(temperature=0.6), tokenizer,
-                                     rollout_stat_scope="eval-rollout", reward_in_process=in_proc,
-                                     dump_dir=os.path.join(log_dir, "generated-eval"))
-    else:
-        workflow, eval_workflow = workflow_builder(config, tokenizer, reward_fn, log_dir)
-
-    saver = Saver(config.saver, ft_spec)
-    stats_logger = StatsLogger(config.stats_logger, ft_spec)
-    evaluator = Evaluator(config.evaluator, ft_spec)
-    recover_handler = RecoverHandler(config.recover, ft_spec)
-    recover_info = recover_handler.load(actor, saver, evaluator, stats_logger, train_dataloader,
-                                        inference_engine=rollout, weight_update_meta=weight_update_meta)
-    start_step = recover_info.last_step_info.next().global_step if recover_info is not None else 0
-
-    steps_per_epoch = len(train_dataloader)
-    max_steps = config.total_train_epochs * steps_per_epoch
-    if config.total_train_steps is not None:
-        max_steps = min(max_steps, config.total_train_steps)
-    data_generator = itertools.cycle(train_dataloader)
-
-    def sync():
-        if dist.is_initialized():
-            dist.barrier()
-        current_platform.synchronize()
-
-    for global_step in range(start_step, max_steps):
-        epoch, step = divmod(global_step, steps_per_epoch)
-        step_info = StepInfo(global_step=global_step, epoch=epoch, epoch_step=step, steps_per_epoch=steps_per_epoch)
-
-        with stats_tracker.record_timing("rollout"):
-            batch = None
-            if actor.is_data_parallel_head():
-                if config.async_training:
-                    batch = rollout.prepare_batch(train_dataloader, workflow=workflow)
-                else:
-                    batch = rollout.rollout_batch(next(data_generator), workflow=workflow)
-                batch = to_device(batch, actor.device)
-            batch = broadcast_tensor_container(batch, src_rank=actor.current_data_parallel_head(),
-                                               group=actor.context_and_model_parallel_group)
-        sync()
-
-        fused_prox = (config.actor.fuse_proximal_logp and config.actor.use_decoupled_loss
-                      and config.actor.ppo_n_minibatches == 1)
-        if (config.actor.recompute_logprob or config.actor.use_decoupled_loss) and not fused_prox:
-            with stats_tracker.record_timing("recompute_logp"):
-                batch["prox_logp"] = actor.compute_logp(batch)
-        if ref is not None:
-            with stats_tracker.record_timing("ref_logp"):
-                batch["ref_logp"] = ref.compute_logp(batch)
-        if critic is not None:
-            with stats_tracker.record_timing("critic_values"):
-                batch["values"] = critic.compute_values(batch)
-        with stats_tracker.record_timing("compute_advantage"):
-            actor.compute_advantages(batch)
-        critic_stats = []
-        if critic is not None:
-            with stats_tracker.record_timing("critic_train_step"), stats_tracker.scope("ppo_critic"):
-                critic_stats = critic.ppo_update(batch)
-                critic.step_lr_scheduler()
-        with stats_tracker.record_timing("train_step"), stats_tracker.scope("grpo_actor"):
-            stats = actor.ppo_update(batch)
-            actor.step_lr_scheduler()
-        if critic_stats:
-            stats[0].update(critic_stats[0])
-
-        if rollout is not None:
-            rollout.pause()
-        with stats_tracker.record_timing("update_weights"):
-            future = None
-            if rollout is not None and (weight_update_meta.type == "inproc" or rank == 0):
-                future = rollout.update_weights(weight_update_meta)
-            actor.upload_weights(weight_update_meta)
-            if future is not None:
-                future.result()
-            sync()
-            actor.set_version(global_step + 1)
-            if rollout is not None:
-                rollout.set_version(global_step + 1)
-                eval_rollout.set_version(global_step + 1)
-
-        with stats_tracker.record_timing("save"):
-            saver.save(actor, epoch, step, global_step, tokenizer=tokenizer)
-
-        with stats_tracker.record_timing("eval"):
-            def evaluate_fn():
-                if valid_dataloader is None or eval_rollout is None:
-                    return
-                eval_rollout.resume()
-                cnt = 0
-                for data in valid_dataloader:
-                    for item in data:
-                        eval_rollout.submit(item, eval_workflow)
-                        cnt += 1
-                eval_rollout.wait(cnt, timeout=None)
-                eval_rollout.pause()
-
-            evaluator.evaluate(evaluate_fn, epoch, step, global_step)
-
-        with stats_tracker.record_timing("checkpoint_for_recover"):
-            recover_handler.dump(actor, step_info, saver, evaluator, stats_logger, train_dataloader,
-                                 tokenizer=tokenizer)
-        sync()
-        stats[0].update(actor.share_pipeline_stats(stats_tracker.export_all(reduce_group=actor.data_parallel_group)))
-        stats_logger.commit(epoch, step, global_step, stats)
-        sync()
-        if rollout is not None:
-            rollout.resume()
-
-    stats_logger.close()
-    if rollout is not None:
-        eval_rollout.destroy()
-        rollout.destroy()
-    if local_engine is not None:
-        local_engine.destroy()
-    for e in (ref, critic, actor):
-        if e is not None:
-            e.destroy()
+    trainer = RLTrainer(argv, reward_fn, workflow_builder, config_cls, load_tokenizer)
+    trainer.run()
+    trainer.close()

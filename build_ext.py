@@ -57,8 +57,12 @@ def build_hip(verbose=True) -> Path:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(_run, jobs))
     lib = OUT_DIR / "libareal_hip.so"
-    if jobs or not lib.exists() or any(o.stat().st_mtime > lib.stat().st_mtime for o in objs):
+    manifest = BUILD_DIR / "libareal_hip.objs"  # what the library was linked from: a deleted source must relink it
+    linked_from = "\n".join(o.name for o in objs)
+    stale = not manifest.exists() or manifest.read_text() != linked_from
+    if jobs or stale or not lib.exists() or any(o.stat().st_mtime > lib.stat().st_mtime for o in objs):
         _run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(lib), *map(str, objs)])
+        manifest.write_text(linked_from)
         if verbose:
             print(f"[build_ext] linked {lib}")
     return lib

@@ -29,19 +29,44 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 DEVINL float bf2f(bf16_t x) { return (float)x; }
 DEVINL bf16_t f2bf(float x) { return (bf16_t)x; }
 
+// Exchanges across 16- and 32-lane rows in the VALU (v_permlane16_swap / v_permlane32_swap of gfx950) instead of
+// through the LDS crossbar (`__shfl_xor(v, 16 | 32)` compiles to ds_bpermute_b32: an LDS-pipe round trip of ~100
+// cycles on the dependent path, and LDS traffic in kernels that otherwise use none). Fed the same register twice
+// the swap leaves, in every lane, the value of the lane's even row in [0] and of its odd row in [1]: own value and
+// partner's value, in an order that is the same for both partners - op([0], [1]) is bit-identical on both lanes.
+DEVINL f32x2 rows16_pair(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return (f32x2){__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+DEVINL f32x2 rows32_pair(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return (f32x2){__uint_as_float(r[0]), __uint_as_float(r[1])};
+}
+DEVINL float sum_xor16(float v) { const f32x2 r = rows16_pair(v); return r[0] + r[1]; }
+DEVINL float sum_xor32(float v) { const f32x2 r = rows32_pair(v); return r[0] + r[1]; }
+DEVINL float max_xor16(float v) { const f32x2 r = rows16_pair(v); return fmaxf(r[0], r[1]); }
+DEVINL float max_xor32(float v) { const f32x2 r = rows32_pair(v); return fmaxf(r[0], r[1]); }
+DEVINL float min_xor16(float v) { const f32x2 r = rows16_pair(v); return fminf(r[0], r[1]); }
+DEVINL float min_xor32(float v) { const f32x2 r = rows32_pair(v); return fminf(r[0], r[1]); }
+
 DEVINL float wave_sum(float v) {
+  v = sum_xor16(sum_xor32(v));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);  // within a 16-lane row: DPP
   return v;
 }
 DEVINL float wave_max(float v) {
+  v = max_xor16(max_xor32(v));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
 DEVINL float wave_min(float v) {
+  v = min_xor16(min_xor32(v));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  for (int o = 8; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
 }
 

@@ -643,12 +643,20 @@ __global__ __launch_bounds__(1024) void splitk_rope_cache_write_kernel(
     // 16-byte LDS / global reads: dword reads at this 32-byte lane stride would be 8-way bank conflicts
     const f32x4* lo4 = reinterpret_cast<const f32x4*>(rowbuf + head * D + sub * 8);
     const f32x4* hi4 = reinterpret_cast<const f32x4*>(rowbuf + head * D + sub * 8 + half);
+    // A lane's two 16-byte halves sit 32 bytes from its neighbour's: read in the same order by all lanes, the 16
+    // lanes that ds_read_b128 serves together ({0-3, 12-15, 20-27}, ...) would use only every other 16-byte slot of
+    // the 256-byte bank row, twice each. Lanes 16-31 and 48-63 take their halves in the opposite order instead.
+    const int sel = (threadIdx.x >> 4) & 1;
     float lo[8], hi[8];
+    {
+      const f32x4 a0 = lo4[sel], a1 = lo4[sel ^ 1], b0 = hi4[sel], b1 = hi4[sel ^ 1];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const f32x4 a = lo4[q], b = hi4[q];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { lo[4 * q + j] = a[j]; hi[4 * q + j] = b[j]; }
+      for (int j = 0; j < 4; ++j) {
+        lo[j] = sel ? a1[j] : a0[j];
+        lo[4 + j] = sel ? a0[j] : a1[j];
+        hi[j] = sel ? b1[j] : b0[j];
+        hi[4 + j] = sel ? b0[j] : b1[j];
+      }
     }
     if (q_norm) {
       // per-head RMSNorm of q and k ahead of the rotation (Qwen3): the lph lanes that share a head are neighbours

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_paged_kernel(
         sacc[kb][j] = sv;
         mx = fmaxf(mx, sv);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor32(mx);
     const float mn = fmaxf(m, mx);
     const float alpha = (mn == -INFINITY) ? 1.f : fast_exp2(m - mn);
     m = mn;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_paged_kernel(
     if (t + 1 < ntile_k) store_tile(t + 1);
     __syncthreads();
   }
-  l += __shfl_xor(l, 32, 64);
+  l = sum_xor32(l);
   const float inv_l = l > 0.f ? 1.f / l : 0.f;
   if (my_q < q_len) {
     bf16_t* op = o + (size_t)(q_beg + my_q) * o_stride + (size_t)head * D;

@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void paged_decode_kernel(
       s[r] = (key0 + r < ctx) ? v : -INFINITY;
       mx = fmaxf(mx, s[r]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor16(mx);
+    mx = max_xor32(mx);
     const float mn = fmaxf(m, mx);
     if (__any(mn > m)) {
       const float alpha = (m == -INFINITY) ? 0.f : fast_exp2(m - mn);
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void paged_decode_kernel(
     for (int i = 0; i < DB; ++i) o[i] = mfma16(vt[i], pf, o[i]);
   }
   // l is a per-lane partial over this lane's keys: sum the 4 lanes that share a q
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
+  l = sum_xor16(l);
+  l = sum_xor32(l);
 
   // combine the 4 waves through LDS: per wave [16 q][D] fp32 O + [16] m + [16] l
   // Rows are DP = D + 4 floats apart: with a stride of D floats the 16 q rows of a store fall on the same banks

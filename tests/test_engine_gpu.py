@@ -896,6 +896,11 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", AREAL_HOST_STAGED_COLLECTIVES="1",
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
+    rccl1 = dict(layout).get("_rccl1", False)
+    if rccl1:  # ONE rank on RCCL, every data-parallel collective really issued
+        assert world == 1
+        os.environ.pop("AREAL_HOST_STAGED_COLLECTIVES")
+        os.environ.update(AREAL_FORCE_COLLECTIVES="1", AREAL_ZERO_BUCKETS="6")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from areal_vllm_amd.api.alloc_mode import ParallelStrategy
     from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
@@ -904,6 +909,7 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
     from areal_vllm_amd.utils import host_staged
 
     layout = dict(layout)
+    layout.pop("_rccl1", None)
     preset_name = layout.pop("_model", "small")
     cfg = TrainEngineConfig(experiment_name="t", trial_name="lay", path=ckpt_in or preset_name, init_from_scratch=ckpt_in is None,
                             dtype="bfloat16", gradient_checkpointing=False,
@@ -917,6 +923,10 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
     eng = NativeTrainEngine(cfg)
     eng.create_process_group(ParallelStrategy(**layout))
     assert world == 1 or (host_staged.installed() and eng.device.type == "cuda")
+    if rccl1:
+        import torch.distributed as dist
+
+        assert not host_staged.installed() and "cuda:nccl" in dist.get_backend_config()
     eng.initialize(None, FinetuneSpec(1, 64, 8))
     if ckpt_in is None:
         eng.save(SaveLoadMeta(path=out_path, weight_format="hf", with_optim=False))
@@ -933,7 +943,9 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
         norms.append(st["grad_norm"])
     ev = float(eng.eval_batch(local, _sft_loss, _weight))
     fw = eng.forward(local, post_hook=_logp_hook).float().cpu()
-    if dp > 1 and eng.grid.pp == 1 and eng.zero3 is None and eng.expert_optimizer is None:
+    if rccl1 and eng.zero3 is not None:
+        assert not eng.zero3.solo
+    if (dp > 1 or rccl1) and eng.grid.pp == 1 and eng.zero3 is None and eng.expert_optimizer is None:
         assert len(eng.optimizer.buckets) > 1
         assert eng.optimizer.overlapped_buckets >= 2 * (len(eng.optimizer.buckets) - 1)  # bucketed reduce during backward
     torch.save(dict(norms=norms, ev=ev, fw=fw, dpr=dpr), f"{out_path}.r{rank}")
@@ -993,6 +1005,98 @@ def test_two_rank_layouts_on_one_gpu_follow_the_single_process(tmp_path):
             valid[i, :n - 1] = True
         diff = (fw[:, :S] - ref["fw"][:, :S]).abs()[valid]
         assert float(diff.mean()) < 0.03 and float(diff.max()) < 0.5, (name, float(diff.mean()), float(diff.max()))
+
+
+def test_one_rank_rccl_group_runs_the_sharded_optimizers_collectives(tmp_path):
+    """The ZeRO-1 bucket pipeline (asynchronous reduce-scatters leaving in descending order during the last backward,
+    per-bucket all-gathers after the update) and ZeRO-3 (gathers / reductions on the communication stream) on a real
+    RCCL communicator: one rank, collectives forced on instead of short-cut into copies. With one rank every
+    collective is the identity, so ZeRO-1 must reproduce the plain single-process run up to the summation order of
+    the gradient-norm kernel (atomics: 1e-6 relative) - a bucket that left before its last gradient was folded in, or
+    an update that read a shard before its reduce-scatter landed, shows up in the norms at the percent level."""
+    init = str(tmp_path / "init")
+    _run_layout(1, dict(), False, None, init)
+    ref_path = str(tmp_path / "ref")
+    _run_layout(1, dict(), False, init, ref_path)
+    ref = torch.load(ref_path + ".r0", weights_only=True)
+    out = str(tmp_path / "z1")
+    _run_layout(1, dict(_rccl1=True), False, init, out)
+    z1 = torch.load(out + ".r0", weights_only=True)
+    assert z1["norms"][0] == pytest.approx(ref["norms"][0], rel=1e-5)
+    # the second step starts from bf16 weights some of whose roundings flipped
+    assert z1["norms"] == pytest.approx(ref["norms"], rel=1e-3) and z1["ev"] == pytest.approx(ref["ev"], rel=1e-3)
+    d = (z1["fw"] - ref["fw"]).abs()  # bf16 roundings that flip after a 1e-6 change of the clipping factor
+    assert float(d.max()) < 0.1 and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))
+    out = str(tmp_path / "z3")
+    _run_layout(1, dict(_rccl1=True, _zero=3), False, init, out)
+    z3 = torch.load(out + ".r0", weights_only=True)
+    assert z3["norms"] == pytest.approx(ref["norms"], rel=2e-2) and z3["ev"] == pytest.approx(ref["ev"], abs=2e-2)
+
+
+def _rccl_graph_worker(port, force, out_path):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", AREAL_FORCE_COLLECTIVES="1" if force else "0")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+
+    from areal_vllm_amd.api.cli_args import InferenceServerConfig
+    from areal_vllm_amd.inference.engine import NativeInferenceEngine
+    from areal_vllm_amd.models.config import preset
+    from areal_vllm_amd.parallel.grid import init_distributed
+
+    init_distributed()
+    assert "cuda:nccl" in dist.get_backend_config()
+    dev = torch.device("cuda", 0)
+    if force:  # a collective captured on its own: replays must re-run it
+        x, y = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
+        dist.all_reduce(x)  # communicator set-up happens outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            x.mul_(2.0)
+            dist.all_reduce(x)
+            dist.all_gather_into_tensor(y, x)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert float(y[0]) == 16.0 and float(y[-1]) == 16.0  # capture ran it once, three replays
+    srv = InferenceServerConfig(model_path="small", dtype="bfloat16", context_length=512, max_running_requests=16,
+                                num_continuous_decode_steps=4, random_seed=3)
+    eng = NativeInferenceEngine(srv, model_config=preset("small"), device=dev, num_pages=256)
+    eng.initialize(load_weights=False)
+    assert eng.runner.tp_comm == force and eng.runner.use_graph
+    gen = torch.Generator().manual_seed(9)
+    prompts = [torch.randint(2, 4000, (n,), generator=gen).tolist() for n in (7, 40, 33, 90, 130, 17)]
+    res = eng.generate_blocking(prompts, max_new_tokens=24, greedy=True)
+    assert eng.stats["decode_steps"] > 0
+    torch.save([(r.output_tokens, r.output_logprobs) for r in res], out_path)
+    eng.destroy()
+    dist.destroy_process_group()
+
+
+def test_decode_graph_with_rccl_collectives_in_it_replays_like_the_plain_graph(tmp_path):
+    """Tensor-parallel decode keeps its all-reduces (two per layer) and the token broadcast INSIDE the captured
+    decode graph. One rank, RCCL, collectives forced on: capture and replay must work on this stack, and - the sums
+    being over one rank - produce exactly the tokens and log-probs of the graph without collectives."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    outs = []
+    for force in (True, False):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"gen{int(force)}.pt")
+        p = mp.get_context("spawn").Process(target=_rccl_graph_worker, args=(port, force, out))
+        p.start()
+        p.join(240)
+        if p.is_alive():
+            p.kill()
+            pytest.fail("decode with RCCL collectives inside the graph did not finish")
+        assert p.exitcode == 0, p.exitcode
+        outs.append(torch.load(out, weights_only=True))
+    assert outs[0] == outs[1]
 
 
 def test_expert_parallel_layout_on_one_gpu_follows_the_single_process(tmp_path):

@@ -654,71 +654,6 @@ def test_decode_advance_and_begin_kernels_match_their_cpu_twins():
     assert 0 < int(cpu["active"].sum()) < B or int(cpu["active"].sum()) == 0
 
 
-# ------------------------------------------------------------------------------ skinny GEMM
-@pytest.mark.gpu
-@pytest.mark.parametrize("M", [1, 7, 16, 40, 128, 200])
-@pytest.mark.parametrize("N,K", [(256, 512), (1536, 1536), (2048, 8960)])
-@pytest.mark.parametrize("ksplit,nt", [(1, 1), (1, 2), (4, 1), (3, 2)])
-def test_skinny_linear_plain(M, N, K, ksplit, nt):
-    from areal_vllm_amd import ops
-
-    torch.manual_seed(M + N)
-    dev = torch.device("cuda")
-    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
-    w = torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.05
-    b = torch.randn(N, device=dev, dtype=torch.bfloat16)
-    ws = ops.SkinnyWorkspace(256, N, dev)
-    for _ in range(2):  # second call checks that the workspace / counters were left clean
-        out = ops.skinny_linear(x, w, b, ksplit=ksplit, nt=nt, workspace=ws)
-        ref = x.float() @ w.float().t() + b.float()
-        torch.testing.assert_close(out.float(), ref, atol=0.06, rtol=0.02)
-    assert ws.ws.abs().max().item() == 0 and ws.counters.abs().max().item() == 0
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("M", [5, 64, 128])
-@pytest.mark.parametrize("ksplit", [1, 4])
-def test_skinny_linear_fused_layer(M, ksplit):
-    """norm prologue -> swiglu epilogue -> residual epilogue against the fp32 definition."""
-    from areal_vllm_amd import ops
-
-    torch.manual_seed(M)
-    dev = torch.device("cuda")
-    H, Fi = 1536, 8960
-    xres = torch.randn(M, H, device=dev, dtype=torch.bfloat16)
-    nw = (1 + 0.1 * torch.randn(H, device=dev)).bfloat16()
-    wgu = torch.randn(2 * Fi, H, device=dev, dtype=torch.bfloat16) * 0.03
-    wd = torch.randn(H, Fi, device=dev, dtype=torch.bfloat16) * 0.02
-    ws = ops.SkinnyWorkspace(256, 2 * Fi, dev)
-    rss = xres.float().pow(2).sum(-1)
-    act = ops.skinny_linear(xres, wgu, norm=(rss, nw, 1e-6, False), swiglu=True, ksplit=ksplit, workspace=ws)
-    xn = (xres.float() * torch.rsqrt(rss / H + 1e-6).unsqueeze(-1) * nw.float()).bfloat16()
-    gu = (xn.float() @ wgu.float().t())
-    ref_act = torch.nn.functional.silu(gu[:, :Fi]) * gu[:, Fi:]
-    torch.testing.assert_close(act.float(), ref_act, atol=0.05, rtol=0.03)
-    rss_out = torch.zeros(M, device=dev)
-    new_res = ops.skinny_linear(act, wd, residual=(xres, rss_out), ksplit=ksplit, workspace=ws)
-    ref_res = act.float() @ wd.float().t() + xres.float()
-    torch.testing.assert_close(new_res.float(), ref_res, atol=0.08, rtol=0.03)
-    torch.testing.assert_close(rss_out, new_res.float().pow(2).sum(-1), rtol=1e-3, atol=1e-2)
-    assert ws.ws.abs().max().item() == 0
-
-
-@pytest.mark.gpu
-def test_embed_rowsumsq():
-    from areal_vllm_amd import ops
-
-    dev = torch.device("cuda")
-    table = torch.randn(1000, 1536, device=dev, dtype=torch.bfloat16)
-    ids = torch.randint(0, 1000, (37,), device=dev)
-    out = torch.empty(64, 1536, device=dev, dtype=torch.bfloat16)
-    rss_all = torch.ones(5, 64, device=dev)
-    ops.embed_rowsumsq(ids, table, out, rss_all[0], rss_all[1:])
-    torch.testing.assert_close(out[:37], table[ids])
-    torch.testing.assert_close(rss_all[0, :37], table[ids].float().pow(2).sum(-1), rtol=1e-4, atol=1e-3)
-    assert rss_all[1:].abs().max().item() == 0
-
-
 @pytest.mark.gpu
 def test_linear_accumulates_wgrad_into_fp32_main_grad():
     """ops.linear: dW is summed by the GEMM into the fp32 main-grad view over two micro-batches."""

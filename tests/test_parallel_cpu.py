@@ -49,6 +49,9 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
                       LOCAL_RANK=str(rank), GLOO_SOCKET_IFNAME="lo")
     sys.path.insert(0, ROOT)
     torch.set_num_threads(1)
+    forced = dict(strategy_kwargs).get("_force", False)
+    if forced:  # a one-rank group whose collectives are really issued (read when the package is imported)
+        os.environ.update(AREAL_FORCE_COLLECTIVES="1", AREAL_ZERO_BUCKETS="5")
     from areal_vllm_amd.api.alloc_mode import ParallelStrategy
     from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
     from areal_vllm_amd.api.io_struct import FinetuneSpec, SaveLoadMeta
@@ -60,6 +63,7 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
                                                       warmup_steps_proportion=0.0, lr_scheduler_type="constant"),
                             mb_spec=MicroBatchSpec(n_mbs=n_mbs, max_tokens_per_mb=4096))
     strategy_kwargs = dict(strategy_kwargs)
+    strategy_kwargs.pop("_force", None)
     cfg.native.context_parallel_mode = strategy_kwargs.pop("_cp_mode", "ulysses")
     cfg.native.sequence_parallel = strategy_kwargs.pop("_seq_par", False)
     reshard_from = strategy_kwargs.pop("_reshard_from", None)
@@ -98,7 +102,8 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
     for _ in range(2):
         stats.append(eng.train_batch(local, _sft_loss, _weight))
         eng.step_lr_scheduler()
-    if eng.zero3 is None and eng.grid.pp == 1 and eng.grid.dp * eng.grid.cp > 1 and eng.expert_optimizer is None \
+    if eng.zero3 is None and eng.grid.pp == 1 and (eng.grid.dp * eng.grid.cp > 1 or forced) \
+            and eng.expert_optimizer is None \
             and eng._can_overlap_grad_reduce():
         # both steps sent (almost) all gradient buckets on their way while the last backward was still running
         # (all but the lowest bucket, which holds the embedding table that reports after the backward)
@@ -198,6 +203,7 @@ def _compare(ref, out, atol=2e-5):
     ("zigzag2", 2, dict(context_parallel_size=2, _cp_mode="zigzag"), 2),
     ("zigzag4", 4, dict(context_parallel_size=4, _cp_mode="zigzag"), 1),
     ("zigzag2tp2", 4, dict(context_parallel_size=2, tensor_parallel_size=2, _cp_mode="zigzag"), 2),
+    ("dp1-collectives-forced", 1, dict(_force=True), 2),
 ])
 def test_layout_matches_single_process(dense_reference, name, world, kw, n_mbs):
     d, init, ref = dense_reference
@@ -312,6 +318,7 @@ def test_interleaved_pipeline_stages_match_single_process():
     ("z3dp2offload", 2, dict(data_parallel_size=2, _zero3=dict(offload=True, ckpt=True)), 2),
     ("z3cp2", 2, dict(context_parallel_size=2, _zero3={}), 2),
     ("z3dp1", 1, dict(_zero3={}), 2),
+    ("z3dp1-collectives-forced", 1, dict(_zero3={}, _force=True), 2),
     ("z3tp2", 2, dict(tensor_parallel_size=2, _zero3={}), 2),
     ("z3tp2sp", 2, dict(tensor_parallel_size=2, _seq_par=True, _zero3=dict(ckpt=True)), 2),
     ("z3dp2tp2", 4, dict(data_parallel_size=2, tensor_parallel_size=2, _zero3={}), 1),
