@@ -28,6 +28,8 @@
 //     columns of one row and stores 8 bytes.
 //   * block id -> tile: contiguous id ranges per XCD (ids are dealt round-robin to the 8 XCDs), walked in bands of 4
 //     tile rows so that the blocks running together on an XCD share A and B panels in its L2.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
 
   // ---- tile sequence number -> output tile
   const int ntiles = a.tiles_m * a.tiles_n;
-  auto tile_origin = [&](int id, int& m0, int& n0) {
+  auto tile_origin = [&](int id, int& m0, int& n0) __attribute__((always_inline)) {
     const int q = ntiles >> 3, r = ntiles & 7, x = id & 7;
     const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
     const int per_band = TG_GROUP_M * a.tiles_n;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
   const int schunk = (lane & 7) ^ ((srow >> 1) & 7);  // logical chunk whose data lands at physical chunk lane & 7
   const bf16_t* srcA[2][2];  // [piece][issue]
   const bf16_t* srcB[2][2];
-  auto set_sources = [&](int m0, int n0) {
+  auto set_sources = [&](int m0, int n0) __attribute__((always_inline)) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
         srcB[h][i] = a.B + (size_t)col * a.ldb + schunk * 8;
       }
   };
-  auto stage = [&](int buf, int piece, int kt) {
+  auto stage = [&](int buf, int piece, int kt) __attribute__((always_inline)) {
     char* dst = smem + buf * TG_BUF + piece * TG_PIECE + wave * 1024;
     const bf16_t* s0 = piece < 2 ? srcA[piece][0] : srcB[piece - 2][0];
     const bf16_t* s1 = piece < 2 ? srcA[piece][1] : srcB[piece - 2][1];
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
   const int a_off = (wr * 64 + fr) * 128, b_off = (wc * 32 + fr) * 128;
   bf16x8 af[4][2];
   tg_bfrag bf0, bf1;
-  auto read_a = [&](int buf, int h) {
+  auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
     const char* p = smem + buf * TG_BUF + h * TG_PIECE + a_off;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
       af[mt][1] = *reinterpret_cast<const bf16x8*>(p + mt * 2048 + cb1);
     }
   };
-  auto read_b = [&](int buf, int h, tg_bfrag& bf) {
+  auto read_b = [&](int buf, int h, tg_bfrag& bf) __attribute__((always_inline)) {
     const char* p = smem + buf * TG_BUF + (2 + h) * TG_PIECE + b_off;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
     }
   };
   tg_acc acc00, acc01, acc10, acc11;  // [m half][n half]
-  auto mma = [&](tg_acc& acc, tg_bfrag& bf) {
+  auto mma = [&](tg_acc& acc, tg_bfrag& bf) __attribute__((always_inline)) {
     tg_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -159,6 +161,44 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
     tg_barrier();
   };
 
+  // ---- result stores. Lane (row fr, column quad fq) of tile (mt, nt) holds 4 consecutive columns; the two 16-column
+  // tiles of a quadrant exchange halves between neighbouring 16-lane rows (v_permlane16_swap), after which a lane holds
+  // 8 consecutive columns of one of them: 16-byte stores, the four lanes of a row write 64 contiguous bytes.
+  auto put = [&](tg_acc& acc, int m0, int n0, int mh, int nh) __attribute__((always_inline)) {
+    const int n = n0 + wc * 64 + nh * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wr * 128 + mh * 64 + mt * 16 + fr;
+      unsigned pk[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 v = acc[mt][nt];
+        if (a.bias) {
+          const int nb = n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4;
+          if (nb < a.N) {
+            const bf16x4 bb = *reinterpret_cast<const bf16x4*>(a.bias + nb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bf2f(bb[j]);
+          }
+        }
+        bf16x2 lo = {f2bf(v[0]), f2bf(v[1])}, hi = {f2bf(v[2]), f2bf(v[3])};
+        pk[nt][0] = __builtin_bit_cast(unsigned, lo);
+        pk[nt][1] = __builtin_bit_cast(unsigned, hi);
+      }
+      const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+      const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+      if (m < a.M && n < a.N) {
+        if (n + 8 <= a.N) {
+          *reinterpret_cast<u32x4*>(a.C + (size_t)m * a.ldc + n) = o;
+        } else {  // the last 4 columns of a width that is not a multiple of 8
+          *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + n) = (u32x2){o[0], o[1]};
+        }
+      }
+    }
+  };
+  int cm0 = 0, cn0 = 0;  // origin of the output tile being computed
+
   // One K tile = four phases. The K tiles of the block's successive output tiles form ONE stream: the pieces staged
   // while the last two K tiles of an output tile are computed are K tiles 0 and 1 of the NEXT output tile, so the
   // prologue's load latency is paid once per block and the result stores run under the next tile's loads.
@@ -168,7 +208,7 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
   // and the loads still in flight are drained.
   int nm0 = 0, nn0 = 0;
   bool has_next = false;
-  auto tile = [&](auto buf_c, int t, auto mode_c) {
+  auto tile = [&](auto buf_c, int t, auto mode_c) __attribute__((always_inline)) {
     constexpr int buf = decltype(buf_c)::value, MODE = decltype(mode_c)::value;
     const bool go = MODE == 0 || has_next;
     const int t1 = MODE == 2 ? 0 : t + 1, t2 = MODE == 0 ? t + 2 : MODE - 1;
@@ -181,15 +221,20 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
     // from now, when the staggered wave group has only just passed that barrier
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
     mma(acc00, bf0);
+    // last K tile: a quadrant is final once its phase is over; its stores are issued while the other wave group
+    // computes
+    if (MODE == 2) put(acc00, cm0, cn0, 0, 0);
     if (MODE == 1 && go) set_sources(nm0, nn0);
     // phase 2: quadrant (0, 1)
     read_b(buf, 1, bf1);
     if (go) stage(buf, PB0, t2);
     mma(acc01, bf1);
+    if (MODE == 2) put(acc01, cm0, cn0, 0, 1);
     // phase 3: quadrant (1, 1)
     read_a(buf, 1);
     if (go) stage(buf, PA0, t2);
     mma(acc11, bf1);
+    if (MODE == 2) put(acc11, cm0, cn0, 1, 1);
     // phase 4: quadrant (1, 0); the next K tile of the stream becomes readable
     if (go) {
       stage(buf, PB1, t2);
@@ -198,36 +243,13 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
       tg_vmcnt<0>();
     }
     mma(acc10, bf0);
+    if (MODE == 2) put(acc10, cm0, cn0, 1, 0);
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   using M0 = std::integral_constant<int, 0>;
   using M1 = std::integral_constant<int, 1>;
   using M2 = std::integral_constant<int, 2>;
-
-  // ---- epilogue: lane (row fr, column quad fq) of tile (mt, nt) holds 4 consecutive columns
-  auto store = [&](tg_acc& acc, int m0, int n0, int mh, int nh) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const int m = m0 + wr * 128 + mh * 64 + mt * 16 + fr;
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wc * 64 + nh * 32 + nt * 16 + fq * 4;
-        if (m < a.M && n < a.N) {
-          f32x4 v = acc[mt][nt];
-          if (a.bias) {
-            const bf16x4 bb = *reinterpret_cast<const bf16x4*>(a.bias + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] += bf2f(bb[j]);
-          }
-          bf16x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-          *reinterpret_cast<bf16x4*>(a.C + (size_t)m * a.ldc + n) = o;
-        }
-      }
-    }
-  };
 
   // ---- prologue: K tile 0 whole, B0 A0 B1 of K tile 1 (its A1 leaves in phase 1 of K tile 0)
   int id = blockIdx.x, m0, n0;
@@ -248,6 +270,8 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
     const int nid = id + gridDim.x;
     has_next = nid < ntiles;
     if (has_next) tile_origin(nid, nm0, nn0);
+    cm0 = m0;
+    cn0 = n0;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -265,10 +289,6 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
     }
     tile(B0{}, t, M1{});
     tile(B1{}, t + 1, M2{});
-    store(acc00, m0, n0, 0, 0);
-    store(acc01, m0, n0, 0, 1);
-    store(acc10, m0, n0, 1, 0);
-    store(acc11, m0, n0, 1, 1);
     if (!has_next) break;
     id = nid;
     m0 = nm0;
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
   const int pc = ((lane & 15) ^ (((lane >> 4) << 2) | (wave & 3))) * 8;  // piece column whose chunk lands here
   const bf16_t* pA = a.dY + (size_t)(tok0 + srow) * a.ldy + n0 + (pc >> 6) * 128 + (pc & 63);
   const bf16_t* pB = a.X + (size_t)(tok0 + srow) * a.ldx + k0 + (pc >> 5) * 64 + (pc & 31);
-  auto stage = [&](int buf, int piece, int kt) {
+  auto stage = [&](int buf, int piece, int kt) __attribute__((always_inline)) {
     char* dst = smem + buf * TG_BUF + piece * TG_PIECE + wave * 1024;
     const bool isA = piece < 2;
     const long ld = isA ? a.ldy : a.ldx;
@@ -357,14 +377,14 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
   // pending LDS-DMA writes and puts s_waitcnt vmcnt(0) in front of every group of reads, draining the pipeline. The
   // results are ordered by the explicit lgkmcnt waits of the phase.
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)smem;
-  auto trl = [&](uint32_t adr, int imm) {
+  auto trl = [&](uint32_t adr, int imm) __attribute__((always_inline)) {
     bf16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(adr), "i"(imm));
     return v;
   };
   bf16x8 af[2][4];    // [32-row tile][16-token slab]
   bf16x8 bf0[4], bf1[4];
-  auto read_a = [&](int buf, int h) {
+  auto read_a = [&](int buf, int h) __attribute__((always_inline)) {
     const uint32_t p = lds0 + buf * TG_BUF;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
     tg_barrier();
   };
   // TAIL 0: tiles t+1 and t+2 exist; 1: only t+1 exists; 2: last tile
-  auto tile = [&](auto buf_c, int t, auto tail_c) {
+  auto tile = [&](auto buf_c, int t, auto tail_c) __attribute__((always_inline)) {
     constexpr int buf = decltype(buf_c)::value, TAIL = decltype(tail_c)::value;
     read_b(buf, 0, bf0);
     __builtin_amdgcn_sched_barrier(0);
@@ -447,7 +467,7 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
   if (STAGGER && wr == 0) tg_barrier();
 
   // ---- epilogue: lane (k column r32, hf) holds rows n = (reg & 3) + 8 (reg >> 2) + 4 hf of each 32 x 32 tile
-  auto flush = [&](tw_acc& acc, int mh, int nh) {
+  auto flush = [&](tw_acc& acc, int mh, int nh) __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       float* op = a.dW + (size_t)(n0 + wr * 128 + mh * 64 + mi * 32 + 4 * hf) * a.ldw + k0 + wc * 64 + nh * 32 + r32;
