@@ -8,7 +8,6 @@ summed in fp32 without a rounding step and without a separate add kernel. This i
 ``fused_weight_gradient_mlp_cuda.wgrad_gemm_accum_fp32`` in the reference
 (``realhf/impl/model/parallelism/tensor_parallel/modules.py:242-402``).
 """
-import os
 from typing import Optional
 
 import torch
@@ -18,12 +17,9 @@ import torch.nn.functional as F
 from . import train_gemm
 
 
-OWN_WGRAD = os.environ.get("AREAL_OWN_WGRAD", "1") != "0"
-
-
 def _accumulate_wgrad(weight: torch.Tensor, dy2: torch.Tensor, x2: torch.Tensor) -> None:
     mg = weight.main_grad
-    if OWN_WGRAD and dy2.is_cuda and train_gemm.wgrad_supported(dy2, x2, mg):
+    if dy2.is_cuda and train_gemm.wgrad_supported(dy2, x2, mg):
         # token-major operands reduced over tokens: the hand-written kernel (transposed LDS reads, split over tokens
         # when the gradient has few tiles) is 1.2-1.6x the library's kernel for this layout
         train_gemm.tgemm_wgrad_(mg, dy2, x2)

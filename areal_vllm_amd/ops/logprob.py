@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import train_gemm
 
 
 def _stats_ref(logits, labels, inv_temp, vocab_start=0):
@@ -245,6 +246,12 @@ class _LMHeadLogprobFn(torch.autograd.Function):
         dent = dent.contiguous().float() if dent is not None else None
         dh = torch.empty_like(hidden)
         dw = torch.zeros_like(weight) if ctx.needs_input_grad[1] else None
+        # With an fp32 gradient buffer behind the weight, every chunk's d(logits)^T . hidden is summed straight into it
+        # (fp32 across chunks, no [V, H] bf16 temporary, no separate accumulation pass).
+        mg = getattr(weight, "main_grad", None) if dw is not None else None
+        direct = mg is not None and hidden.is_cuda and mg.dtype == torch.float32 and mg.shape == weight.shape
+        if direct:
+            dw = None
         for i, s in enumerate(range(0, T, chunk)):
             e = min(T, s + chunk)
             lg = kept[i] if keep_logits else _chunk_logits(hidden[s:e], weight)
@@ -252,8 +259,17 @@ class _LMHeadLogprobFn(torch.autograd.Function):
                          dlogp[s:e] if dlogp is not None else None, dent[s:e] if dent is not None else None,
                          vocab_start)
             torch.matmul(lg, weight, out=dh[s:e])
-            if dw is not None:
+            if direct:
+                if train_gemm.wgrad_supported(lg, hidden[s:e], mg):
+                    train_gemm.tgemm_wgrad_(mg, lg, hidden[s:e])
+                else:
+                    torch.addmm(mg, lg.t(), hidden[s:e], out_dtype=torch.float32, out=mg)
+            elif dw is not None:
                 dw.addmm_(lg.t(), hidden[s:e])
+        if direct:
+            done = getattr(weight, "_after_fold", None)
+            if done is not None:  # this gradient never passes the accumulation hook
+                done(weight)
         if reduce_dh and _group_size(group) > 1:
             dist.all_reduce(dh, group=group)
         return dh, dw, None, None, None, None, None, None, None

@@ -4,11 +4,15 @@
 x transposed weight copy). The kernel covers the shapes transformer layers produce (K a multiple of 128, N of 4,
 16-byte aligned rows); `supported()` tells the caller when to keep the library GEMM instead - it is a statement
 about shapes, not a fallback for a missing extension (on a GPU the extension is mandatory)."""
+import os
 from typing import Optional
 
 import torch
 
 from . import _lib as L
+
+# AREAL_OWN_WGRAD=0 sends weight gradients back to the library GEMM (A/B runs on one box)
+OWN_WGRAD = os.environ.get("AREAL_OWN_WGRAD", "1") != "0"
 
 
 def supported(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None) -> bool:
@@ -43,13 +47,15 @@ def tgemm_tn(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = No
 
 
 def wgrad_supported(dy: torch.Tensor, x: torch.Tensor, acc: torch.Tensor) -> bool:
+    if not OWN_WGRAD:
+        return False
     if not (dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and acc.dtype == torch.float32):
         return False
     if dy.dim() != 2 or x.dim() != 2 or dy.shape[0] != x.shape[0] or acc.shape != (dy.shape[1], x.shape[1]):
         return False
     M, N = dy.shape
     K = x.shape[1]
-    if N % 256 or K % 256 or M < 256:
+    if N % 128 or K % 256 or M < 256:
         return False
     if dy.stride(1) != 1 or x.stride(1) != 1 or acc.stride(1) != 1 or dy.stride(0) % 8 or x.stride(0) % 8:
         return False

@@ -352,7 +352,10 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
   // ---- staging: thread -> token row (wave * 4 + lane / 16) of a 32-row issue, physical 16-byte chunk lane & 15
   const int srow = wave * 4 + (lane >> 4);
   const int pc = ((lane & 15) ^ (((lane >> 4) << 2) | (wave & 3))) * 8;  // piece column whose chunk lands here
-  const bf16_t* pA = a.dY + (size_t)(tok0 + srow) * a.ldy + n0 + (pc >> 6) * 128 + (pc & 63);
+  // N may end half way through the last tile row (N % 256 == 128): the second wave row then re-reads the first one's
+  // columns and does not write
+  const bool half_n = n0 + 128 >= a.N;
+  const bf16_t* pA = a.dY + (size_t)(tok0 + srow) * a.ldy + n0 + (half_n ? 0 : (pc >> 6) * 128) + (pc & 63);
   const bf16_t* pB = a.X + (size_t)(tok0 + srow) * a.ldx + k0 + (pc >> 5) * 64 + (pc & 31);
   auto stage = [&](int buf, int piece, int kt) __attribute__((always_inline)) {
     char* dst = smem + buf * TG_BUF + piece * TG_PIECE + wave * 1024;
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
       }
     }
   };
+  if (half_n && wr == 1) return;
   flush(acc00, 0, 0);
   flush(acc01, 0, 1);
   flush(acc10, 1, 0);
@@ -519,14 +523,14 @@ extern "C" int areal_tgemm_tn(const void* A, long lda, const void* B, long ldb, 
   return (int)hipGetLastError();
 }
 
-// dW[N, K] (fp32, leading dimension ldw) += dY[M, N]^T . X[M, K]. N and K multiples of 256, M a multiple of 128 (the
+// dW[N, K] (fp32, leading dimension ldw) += dY[M, N]^T . X[M, K]. N a multiple of 128, K of 256, M a multiple of 128 (the
 // caller adds the last M % 128 tokens with a library GEMM), rows 16-byte aligned. splits: 0 = choose.
 extern "C" int areal_tgemm_wgrad(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, int M, int N,
                                  int K, int splits, int stagger, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (M % 128 != 0 || N % 256 != 0 || K % 256 != 0 || ldy % 8 != 0 || ldx % 8 != 0) return -1;
+  if (M % 128 != 0 || N % 128 != 0 || K % 256 != 0 || ldy % 8 != 0 || ldx % 8 != 0) return -1;
   if (((uintptr_t)dY | (uintptr_t)X) % 16 != 0 || (uintptr_t)dW % 4 != 0) return -1;
-  const int tiles = (N / 256) * (K / 256), pairs = M / 128;
+  const int tiles = ((N + 255) / 256) * (K / 256), pairs = M / 128;
   if (splits <= 0) {
     // Blocks run in rounds of 256 (one per CU); a block costs its share of the 128-token pairs plus a fixed prologue
     // and flush. Pick the split count with the least rounds x block time (measured: ~3.1 us per pair, ~8 us fixed;
@@ -544,7 +548,7 @@ extern "C" int areal_tgemm_wgrad(const void* dY, long ldy, const void* X, long l
   splits = std::max(1, std::min(splits, pairs));
   const int chunk = ((pairs + splits - 1) / splits) * 128;
   splits = (M + chunk - 1) / chunk;
-  TWArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, dW, ldw, M, N, K, N / 256, K / 256, splits, chunk};
+  TWArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, dW, ldw, M, N, K, (N + 255) / 256, K / 256, splits, chunk};
   static bool attr_set = false;
   if (!attr_set) {
     HIP_RET(hipFuncSetAttribute((const void*)tgemm_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));

@@ -1130,7 +1130,7 @@ def test_training_gemm_matches_fp32(M, N, K, bias, max_blocks):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1000, 512, 256), (4096 + 77, 2048, 1536), (8192, 1536, 1536),
-                                   (2048, 1792, 1536)])
+                                   (2048, 1792, 1536), (1024, 1920, 512), (640, 128, 256)])
 @pytest.mark.parametrize("splits", [0, 1, 3])
 def test_weight_gradient_gemm_matches_fp64(M, N, K, splits):
     """acc += dY^T . X with both operands token-major (transposed LDS reads), plain and split over tokens (atomic
