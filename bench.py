@@ -25,9 +25,14 @@ ranks reach them through the remote client, and after every step each server pul
 trainer rank's exported flat buffer (peer memory, device-to-device over xGMI) while it keeps decoding.
 ``--seq-len S`` sets max_new_tokens = S - prompt_len_max (the 4k / 24k configurations).
 
-Launch: ``python bench.py`` (1 GPU) or
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W``.
-Rank 0 prints ONE JSON line. `value` = RL samples (trajectories) per second over the whole job.
+Launch: ``python bench.py`` (1 GPU), ``python bench.py --gpus N --steps K --warmup W`` (the parent starts one
+rank per GPU itself, picks a free rendezvous port on 127.0.0.1, relays rank 0's result line and fails if any rank
+fails), or the same command line under ``python -m torch.distributed.run --nproc-per-node N ...`` (the ranks then read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher).
+Rank 0 prints ONE JSON line. `value` = RL samples (trajectories) per second over the whole job; `rccl_ranks_seen` /
+`collective_backend` / `devices` say how many ranks took part in the trainer's collectives, over which backend and on
+which PCI devices (asserted distinct), and with an even N >= 2 a short ``--mode decoupled`` pass in fresh child
+processes is reported under `decoupled` (``--no-decoupled-pass`` skips it).
 """
 import argparse
 import json
