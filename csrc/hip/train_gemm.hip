@@ -308,8 +308,10 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
 // a lane ends up with ONE k column per register, so a register is stored (or added) as 128 contiguous bytes per row.
 //   A0 / A1 = dY columns [0, 64) / [64, 128) of both wave rows; B0 / B1 = X columns [0, 32) / [32, 64) of all four
 //   wave columns - as for the forward kernel, pieces are what one phase reads.
-// grid = tiles x splits: a block reduces tokens [split * chunk, (split + 1) * chunk). One split: plain read-add-write
-// of the fp32 tile; several: fp32 atomic adds (they execute at the memory side, ~1.3 TB/s chip-wide).
+// grid = tiles x splits: a workgroup reduces `chunk` 128-token pairs of one output tile. A tile whose whole reduction
+// falls to one workgroup is added with a plain read-add-write; partial reductions are added with fp32 atomics (they
+// execute at the memory side, ~1.3 TB/s chip-wide), which is how a gradient of 48 tiles is reduced by four or five
+// workgroups per tile.
 // =====================================================================================
 struct TWArgs {
   const bf16_t* dY;
@@ -319,7 +321,9 @@ struct TWArgs {
   float* dW;
   long ldw;
   int M, N, K;
-  int tiles_n, tiles_k, splits, chunk;  // chunk: tokens per split (a multiple of 128)
+  int tiles_n, tiles_k;
+  int pairs;          // 128-token pairs of K tiles in M
+  int splits, chunk;  // workgroups per tile, pairs per workgroup (the last one of a tile may get fewer)
 };
 
 typedef f32x16 tw_acc[2];  // [32-row n tile] of one quadrant (64 n x 32 k)
@@ -331,32 +335,27 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  // ---- block id -> (output tile, split); the splits of a tile are consecutive tile-sequence numbers apart by
-  // `ntiles`, so one round of blocks covers every tile once
-  const int ntiles = a.tiles_n * a.tiles_k;
-  const int split = blockIdx.x / ntiles, tid_ = blockIdx.x - split * ntiles;
-  int n0, k0;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, x = tid_ & 7;
-    const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (tid_ >> 3);
+  // ---- this workgroup's range of work units (tile, pair): `chunk` pairs of one tile. Ids are dealt round-robin to
+  // the 8 XCDs: the workgroups of one XCD take neighbouring tiles, which share dY / X panels in its L2.
+  const int nb = gridDim.x;
+  const int xq = nb >> 3, xr = nb & 7, xx = blockIdx.x & 7;
+  const int b = (xx < xr ? xx * (xq + 1) : xr * (xq + 1) + (xx - xr) * xq) + (blockIdx.x >> 3);
+  const int b_tile = b / a.splits, b_split = b - b_tile * a.splits;
+  int w = b_tile * a.pairs + b_split * a.chunk;
+  const int w_end = min(w + a.chunk, (b_tile + 1) * a.pairs);
+  auto tile_origin = [&](int wg, int& n0, int& k0) __attribute__((always_inline)) {
     const int per_band = TG_GROUP_M * a.tiles_k;
     const int band = wg / per_band, first = band * TG_GROUP_M;
     const int rows = min(a.tiles_n - first, TG_GROUP_M);
     const int in_band = wg - band * per_band;
     n0 = (first + in_band % rows) * 256;
     k0 = (in_band / rows) * 256;
-  }
-  const int tok0 = split * a.chunk;
-  const int KT = (min(a.M, tok0 + a.chunk) - tok0) >> 6;  // 64-token tiles of this block (even, >= 2)
+  };
 
   // ---- staging: thread -> token row (wave * 4 + lane / 16) of a 32-row issue, physical 16-byte chunk lane & 15
   const int srow = wave * 4 + (lane >> 4);
   const int pc = ((lane & 15) ^ (((lane >> 4) << 2) | (wave & 3))) * 8;  // piece column whose chunk lands here
-  // N may end half way through the last tile row (N % 256 == 128): the second wave row then re-reads the first one's
-  // columns and does not write
-  const bool half_n = n0 + 128 >= a.N;
-  const bf16_t* pA = a.dY + (size_t)(tok0 + srow) * a.ldy + n0 + (half_n ? 0 : (pc >> 6) * 128) + (pc & 63);
-  const bf16_t* pB = a.X + (size_t)(tok0 + srow) * a.ldx + k0 + (pc >> 5) * 64 + (pc & 31);
+  const bf16_t *pA = nullptr, *pB = nullptr;  // set per segment
   auto stage = [&](int buf, int piece, int kt) __attribute__((always_inline)) {
     char* dst = smem + buf * TG_BUF + piece * TG_PIECE + wave * 1024;
     const bool isA = piece < 2;
@@ -402,15 +401,6 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
       bf[s] = cat4(trl(p + b_adr[0], (2 + h) * TG_PIECE + s * 4096), trl(p + b_adr[1], (2 + h) * TG_PIECE + s * 4096));
   };
   tw_acc acc00, acc01, acc10, acc11;  // [n half][k half]
-#pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      acc00[mi][j] = 0.f;
-      acc01[mi][j] = 0.f;
-      acc10[mi][j] = 0.f;
-      acc11[mi][j] = 0.f;
-    }
   auto mma = [&](tw_acc& acc, bf16x8 (&bf)[4]) {
     tg_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -450,31 +440,14 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
   using T1 = std::integral_constant<int, 1>;
   using T2 = std::integral_constant<int, 2>;
 
-  stage(0, PB0, 0);
-  stage(0, PA0, 0);
-  stage(0, PB1, 0);
-  stage(0, PA1, 0);
-  stage(1, PB0, 1);
-  stage(1, PA0, 1);
-  stage(1, PB1, 1);
-  tg_vmcnt<6>();
-  tg_barrier();
-  if (STAGGER && wr == 1) tg_barrier();
-  int t = 0;
-  for (; t + 2 < KT; t += 2) {
-    tile(B0{}, t, T0{});
-    tile(B1{}, t + 1, T0{});
-  }
-  tile(B0{}, t, T1{});
-  tile(B1{}, t + 1, T2{});
-  if (STAGGER && wr == 0) tg_barrier();
-
   // ---- epilogue: lane (k column r32, hf) holds rows n = (reg & 3) + 8 (reg >> 2) + 4 hf of each 32 x 32 tile
+  int n0 = 0, k0 = 0;
+  bool whole = false;
   auto flush = [&](tw_acc& acc, int mh, int nh) __attribute__((always_inline)) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       float* op = a.dW + (size_t)(n0 + wr * 128 + mh * 64 + mi * 32 + 4 * hf) * a.ldw + k0 + wc * 64 + nh * 32 + r32;
-      if (a.splits == 1) {
+      if (whole) {
         float old[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) old[reg] = op[(size_t)((reg & 3) + 8 * (reg >> 2)) * a.ldw];
@@ -486,11 +459,54 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
       }
     }
   };
-  if (half_n && wr == 1) return;
-  flush(acc00, 0, 0);
-  flush(acc01, 0, 1);
-  flush(acc10, 1, 0);
-  flush(acc11, 1, 1);
+
+  while (w < w_end) {
+    // ---- one segment: pairs [p0, p1) of one output tile
+    const int tile_id = w / a.pairs, p0 = w - tile_id * a.pairs;
+    const int p1 = min(a.pairs, p0 + (w_end - w));
+    w += p1 - p0;
+    tile_origin(tile_id, n0, k0);
+    whole = p0 == 0 && p1 == a.pairs;
+    const int tok0 = p0 * 128, KT = (p1 - p0) * 2;
+    // N may end half way through the last tile row (N % 256 == 128): the second wave row then re-reads the first
+    // one's columns and does not write
+    const bool half_n = n0 + 128 >= a.N;
+    pA = a.dY + (size_t)(tok0 + srow) * a.ldy + n0 + (half_n ? 0 : (pc >> 6) * 128) + (pc & 63);
+    pB = a.X + (size_t)(tok0 + srow) * a.ldx + k0 + (pc >> 5) * 64 + (pc & 31);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        acc00[mi][j] = 0.f;
+        acc01[mi][j] = 0.f;
+        acc10[mi][j] = 0.f;
+        acc11[mi][j] = 0.f;
+      }
+    stage(0, PB0, 0);
+    stage(0, PA0, 0);
+    stage(0, PB1, 0);
+    stage(0, PA1, 0);
+    stage(1, PB0, 1);
+    stage(1, PA0, 1);
+    stage(1, PB1, 1);
+    tg_vmcnt<6>();
+    tg_barrier();
+    if (STAGGER && wr == 1) tg_barrier();
+    int t = 0;
+    for (; t + 2 < KT; t += 2) {
+      tile(B0{}, t, T0{});
+      tile(B1{}, t + 1, T0{});
+    }
+    tile(B0{}, t, T1{});
+    tile(B1{}, t + 1, T2{});
+    if (STAGGER && wr == 0) tg_barrier();
+    if (!(half_n && wr == 1)) {
+      flush(acc00, 0, 0);
+      flush(acc01, 0, 1);
+      flush(acc10, 1, 0);
+      flush(acc11, 1, 1);
+    }
+  }
 }
 
 }  // namespace
@@ -524,21 +540,26 @@ extern "C" int areal_tgemm_tn(const void* A, long lda, const void* B, long ldb, 
 }
 
 // dW[N, K] (fp32, leading dimension ldw) += dY[M, N]^T . X[M, K]. N a multiple of 128, K of 256, M a multiple of 128 (the
-// caller adds the last M % 128 tokens with a library GEMM), rows 16-byte aligned. splits: 0 = choose.
+// caller adds the last M % 128 tokens with a library GEMM), rows 16-byte aligned. splits: 0 = stream-K.
 extern "C" int areal_tgemm_wgrad(const void* dY, long ldy, const void* X, long ldx, float* dW, long ldw, int M, int N,
                                  int K, int splits, int stagger, hipStream_t st) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (M % 128 != 0 || N % 128 != 0 || K % 256 != 0 || ldy % 8 != 0 || ldx % 8 != 0) return -1;
   if (((uintptr_t)dY | (uintptr_t)X) % 16 != 0 || (uintptr_t)dW % 4 != 0) return -1;
   const int tiles = ((N + 255) / 256) * (K / 256), pairs = M / 128;
+  // splits >= 1: that many workgroups per tile (1 = every tile added without atomics). splits <= 0: choose. Blocks run
+  // in rounds of 256 (one per CU); a block costs its share of the pairs (~3.1 us each) plus ~8 us of prologue and
+  // flush, ~25 us more when the tile is flushed with atomic adds (a CU retires one 256-byte atomic instruction per
+  // ~50 ns) - so splitting pays for gradients of few tiles (qkv: 48 tiles x 4) and not for 210 or 420 tiles. An even
+  // deal of ALL work over 256 workgroups (stream-K, nearly every tile partial) was measured 20-25 % slower than whole
+  // tiles for those.
   if (splits <= 0) {
-    // Blocks run in rounds of 256 (one per CU); a block costs its share of the 128-token pairs plus a fixed prologue
-    // and flush. Pick the split count with the least rounds x block time (measured: ~3.1 us per pair, ~8 us fixed;
-    // the atomic adds of split tiles ride under the other blocks' MFMA work). At least 4 pairs per block.
     double best = 1e30;
     for (int s = 1; s <= 16 && pairs / s >= 4; ++s) {
+      const int chunk = (pairs + s - 1) / s;
+      if ((pairs + chunk - 1) / chunk != s) continue;  // this count leaves a workgroup without work
       const int rounds = (tiles * s + 255) / 256;
-      const double t = rounds * (((pairs + s - 1) / s) * 3.1 + 8.0 + (s > 1 ? 1.0 : 0.0));
+      const double t = rounds * (chunk * 3.1 + 8.0 + (s > 1 ? 25.0 : 0.0));
       if (t < best - 1e-9) {
         best = t;
         splits = s;
@@ -546,16 +567,17 @@ extern "C" int areal_tgemm_wgrad(const void* dY, long ldy, const void* X, long l
     }
   }
   splits = std::max(1, std::min(splits, pairs));
-  const int chunk = ((pairs + splits - 1) / splits) * 128;
-  splits = (M + chunk - 1) / chunk;
-  TWArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, dW, ldw, M, N, K, (N + 255) / 256, K / 256, splits, chunk};
+  const int chunk = (pairs + splits - 1) / splits;
+  splits = (pairs + chunk - 1) / chunk;
+  const int nblocks = tiles * splits;
+  TWArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, dW, ldw, M, N, K, (N + 255) / 256, K / 256, pairs, splits, chunk};
   static bool attr_set = false;
   if (!attr_set) {
     HIP_RET(hipFuncSetAttribute((const void*)tgemm_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));
     HIP_RET(hipFuncSetAttribute((const void*)tgemm_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));
     attr_set = true;
   }
-  const dim3 grid(tiles * splits), block(512);
+  const dim3 grid(nblocks), block(512);
   if (stagger)
     hipLaunchKernelGGL(tgemm_wgrad_kernel<true>, grid, block, TG_LDS, st, a);
   else
