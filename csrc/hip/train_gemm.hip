@@ -323,7 +323,8 @@ struct TWArgs {
   int M, N, K;
   int tiles_n, tiles_k;
   int pairs;          // 128-token pairs of K tiles in M
-  int splits, chunk;  // workgroups per tile, pairs per workgroup (the last one of a tile may get fewer)
+  int whole;          // the first `whole` tiles are reduced by one workgroup each
+  int splits, chunk;  // the others: workgroups per tile, pairs per workgroup (the last one of a tile may get fewer)
 };
 
 typedef f32x16 tw_acc[2];  // [32-row n tile] of one quadrant (64 n x 32 k)
@@ -337,12 +338,21 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
 
   // ---- this workgroup's range of work units (tile, pair): `chunk` pairs of one tile. Ids are dealt round-robin to
   // the 8 XCDs: the workgroups of one XCD take neighbouring tiles, which share dY / X panels in its L2.
-  const int nb = gridDim.x;
-  const int xq = nb >> 3, xr = nb & 7, xx = blockIdx.x & 7;
-  const int b = (xx < xr ? xx * (xq + 1) : xr * (xq + 1) + (xx - xr) * xq) + (blockIdx.x >> 3);
-  const int b_tile = b / a.splits, b_split = b - b_tile * a.splits;
-  int w = b_tile * a.pairs + b_split * a.chunk;
-  const int w_end = min(w + a.chunk, (b_tile + 1) * a.pairs);
+  // (whole tiles and split tiles are renumbered separately: the hardware starts workgroups in id order, and the long
+  // whole-tile workgroups have to start first; `whole` is 0, a multiple of 256, or the whole grid)
+  const bool in_whole = (int)blockIdx.x < a.whole;
+  const int base = in_whole ? 0 : a.whole, nb = in_whole ? a.whole : (int)gridDim.x - a.whole;
+  const int id = blockIdx.x - base;
+  const int xq = nb >> 3, xr = nb & 7, xx = id & 7;
+  const int b = base + (xx < xr ? xx * (xq + 1) : xr * (xq + 1) + (xx - xr) * xq) + (id >> 3);
+  int b_tile = b, b_split = 0, b_chunk = a.pairs;
+  if (b >= a.whole) {
+    b_tile = a.whole + (b - a.whole) / a.splits;
+    b_split = (b - a.whole) - (b_tile - a.whole) * a.splits;
+    b_chunk = a.chunk;
+  }
+  int w = b_tile * a.pairs + b_split * b_chunk;
+  const int w_end = min(w + b_chunk, (b_tile + 1) * a.pairs);
   auto tile_origin = [&](int wg, int& n0, int& k0) __attribute__((always_inline)) {
     const int per_band = TG_GROUP_M * a.tiles_k;
     const int band = wg / per_band, first = band * TG_GROUP_M;
@@ -553,24 +563,41 @@ extern "C" int areal_tgemm_wgrad(const void* dY, long ldy, const void* X, long l
   // ~50 ns) - so splitting pays for gradients of few tiles (qkv: 48 tiles x 4) and not for 210 or 420 tiles. An even
   // deal of ALL work over 256 workgroups (stream-K, nearly every tile partial) was measured 20-25 % slower than whole
   // tiles for those.
+  // With more than 256 tiles the full rounds run whole tiles and only the tiles of the last, partly filled round are
+  // split (420 tiles: 256 whole + 164 x 3).
+  int whole = 0;
   if (splits <= 0) {
+    auto block_us = [&](int s) { return ((pairs + s - 1) / s) * 3.1 + 8.0 + (s > 1 ? 25.0 : 0.0); };
+    const int full = tiles / 256 * 256, rest = tiles - full;
     double best = 1e30;
     for (int s = 1; s <= 16 && pairs / s >= 4; ++s) {
       const int chunk = (pairs + s - 1) / s;
       if ((pairs + chunk - 1) / chunk != s) continue;  // this count leaves a workgroup without work
-      const int rounds = (tiles * s + 255) / 256;
-      const double t = rounds * (chunk * 3.1 + 8.0 + (s > 1 ? 25.0 : 0.0));
+      // every tile split s ways
+      double t = ((tiles * s + 255) / 256) * block_us(s);
       if (t < best - 1e-9) {
         best = t;
         splits = s;
+        whole = s == 1 ? tiles : 0;
+      }
+      // full rounds whole, the rest split s ways
+      if (full > 0 && rest > 0 && s > 1) {
+        t = (full / 256) * block_us(1) + ((rest * s + 255) / 256) * block_us(s);
+        if (t < best - 1e-9) {
+          best = t;
+          splits = s;
+          whole = full;
+        }
       }
     }
+  } else if (splits == 1) {
+    whole = tiles;
   }
   splits = std::max(1, std::min(splits, pairs));
   const int chunk = (pairs + splits - 1) / splits;
   splits = (pairs + chunk - 1) / chunk;
-  const int nblocks = tiles * splits;
-  TWArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, dW, ldw, M, N, K, (N + 255) / 256, K / 256, pairs, splits, chunk};
+  const int nblocks = whole + (tiles - whole) * splits;
+  TWArgs a{(const bf16_t*)dY, ldy, (const bf16_t*)X, ldx, dW, ldw, M, N, K, (N + 255) / 256, K / 256, pairs, whole, splits, chunk};
   static bool attr_set = false;
   if (!attr_set) {
     HIP_RET(hipFuncSetAttribute((const void*)tgemm_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));
