@@ -161,7 +161,12 @@ class InferenceServer:
                 return web.json_response({"error": f"cannot process image_data: {e!r}"}, status=400)
         if body.get("stream"):
             return await self._generate_stream(req, rid, ids, multimodal, kw)
-        res = await self.engine.agenerate_once(f"{rid}-{uuid.uuid4().hex[:8]}", ids, multimodal=multimodal, **kw)
+        stops = (body.get("sampling_params") or {}).get("stop") or []
+        stops = [stops] if isinstance(stops, str) else [x for x in stops if x]
+        if stops and self._tokenizer:
+            res = await self._generate_until_text(f"{rid}-{uuid.uuid4().hex[:8]}", ids, multimodal, kw, stops)
+        else:
+            res = await self.engine.agenerate_once(f"{rid}-{uuid.uuid4().hex[:8]}", ids, multimodal=multimodal, **kw)
         meta = {
             "id": rid, "finish_reason": _finish(res.finish_reason), "prompt_tokens": res.prompt_len,
             "completion_tokens": len(res.output_tokens),
@@ -170,6 +175,51 @@ class InferenceServer:
             "e2e_latency": res.latency, "ttft": res.ttft,
         }
         return web.json_response({"text": "", "output_ids": res.output_tokens, "meta_info": meta})
+
+    async def _generate_until_text(self, engine_rid, ids, multimodal, kw, stops: List[str]):
+        """Generation that also ends where the DECODED output first contains one of the stop strings. The engine
+        matches stop strings as the token-id sequences the tokenizer gives them in isolation; a model can spell the
+        same characters with other tokens (merged with a neighbour, split differently), which only the text shows.
+        The tokens are watched as they arrive (one batch per decode plan); on a match the request is aborted and the
+        result cut after the token that completes the stop string, finish reason `stop`."""
+        import dataclasses
+
+        tok = self._tokenizer
+        loop = asyncio.get_running_loop()
+        q: "asyncio.Queue" = asyncio.Queue()
+        self.engine.submit(
+            engine_rid, ids, multimodal=multimodal,
+            on_tokens=lambda t, l, v: loop.call_soon_threadsafe(q.put_nowait, ("tokens", (t, l, v))),
+            callback=lambda res: loop.call_soon_threadsafe(q.put_nowait, ("done", res)), **kw)
+        toks: List[int] = []
+        lps: List[float] = []
+        vers: List[int] = []
+        longest = max(len(tok.encode(x, add_special_tokens=False)) for x in stops) + 8
+        cut = None
+        while True:
+            kind, item = await q.get()
+            if kind == "done":
+                res = item
+                break
+            if cut is not None:
+                continue  # tokens decoded between the match and the abort
+            t, l, v = item
+            first_new = len(toks)
+            toks += t
+            lps += l
+            vers += v
+            lo = max(0, first_new - longest)
+            if any(x in tok.decode(toks[lo:]) for x in stops):
+                # the first token count whose text holds a stop string
+                for n in range(first_new + 1, len(toks) + 1):
+                    if any(x in tok.decode(toks[lo:n]) for x in stops):
+                        cut = n
+                        break
+                await self._offload(self.engine.abort, engine_rid)
+        if cut is None:
+            return res
+        return dataclasses.replace(res, output_tokens=toks[:cut], output_logprobs=lps[:cut], output_versions=vers[:cut],
+                                   finish_reason="stop")
 
     async def _generate_stream(self, req, rid, ids, multimodal, kw):
         """Server-sent events: one `data: {...}` event per batch of new tokens (`output_ids` = the tokens of this

@@ -303,3 +303,59 @@ def test_generate_streams_tokens_as_server_sent_events(server, eng):
     assert done.wait(60)
     res = got.pop()
     assert got == res.output_tokens == want["output_ids"][:want["output_ids"].index(stop_at) + 1]
+
+
+class _LetterTokenizer:
+    """26 letters, every letter spelled by many token ids (id % 26): what a real vocabulary does with merged and
+    split pieces, in the small."""
+
+    def encode(self, text, add_special_tokens=False):
+        return [ord(c) - 97 for c in text]
+
+    def decode(self, ids, **kw):
+        return "".join(chr(97 + int(i) % 26) for i in ids)
+
+
+def test_stop_strings_end_generation_where_the_decoded_text_contains_them(eng):
+    """The engine matches a stop string as the token ids its tokenizer gives it in isolation; the server also watches
+    the decoded text, so a stop string the model spells with other tokens still ends the request there."""
+    from aiohttp import web
+
+    from areal_vllm_amd.inference.server import InferenceServer
+
+    srv = InferenceServer(eng)
+    srv._tokenizer = _LetterTokenizer()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    loop = asyncio.new_event_loop()
+    started = threading.Event()
+
+    def run():
+        asyncio.set_event_loop(loop)
+        runner = web.AppRunner(srv.app)
+        loop.run_until_complete(runner.setup())
+        loop.run_until_complete(web.TCPSite(runner, "127.0.0.1", port).start())
+        started.set()
+        loop.run_forever()
+
+    threading.Thread(target=run, daemon=True).start()
+    assert started.wait(30)
+    url = f"http://127.0.0.1:{port}"
+    try:
+        base = _greedy(eng, n=24).output_tokens
+        text = srv._tokenizer.decode(base)
+        # a two-letter stop string whose first occurrence is spelled with non-canonical ids
+        j = next(i for i in range(4, 22) if (base[i] >= 26 or base[i + 1] >= 26) and text.find(text[i:i + 2]) == i)
+        stop = text[j:j + 2]
+        assert srv._tokenizer.encode(stop) != base[j:j + 2]
+        r = _gen(url, {"max_new_tokens": 24, "temperature": 0.0, "stop": [stop]}).json()
+        assert r["output_ids"] == base[:j + 2] and r["meta_info"]["finish_reason"]["type"] == "stop"
+        assert len(r["meta_info"]["output_token_logprobs"]) == j + 2 and len(r["meta_info"]["output_versions"]) == j + 2
+        # a stop string that never shows up leaves the request alone
+        absent = next(a + b for a in "abcdefghijklmnopqrstuvwxyz" for b in "abcdefghijklmnopqrstuvwxyz"
+                      if a + b not in text)
+        r = _gen(url, {"max_new_tokens": 24, "temperature": 0.0, "stop": [absent]}).json()
+        assert r["output_ids"] == base and r["meta_info"]["finish_reason"]["type"] == "length"
+    finally:
+        loop.call_soon_threadsafe(loop.stop)
