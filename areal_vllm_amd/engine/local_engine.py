@@ -17,7 +17,7 @@ from ..api.engine_api import InferenceEngine
 from ..api.io_struct import ModelRequest, ModelResponse, WeightUpdateMeta
 from ..api.workflow_api import RolloutWorkflow, WorkflowExecutor
 from ..inference.engine import NativeInferenceEngine
-from ..utils import logging
+from ..utils import logging, stop_strings
 
 logger = logging.getLogger("local-engine")
 
@@ -48,6 +48,15 @@ async def interruptible_generate(req: ModelRequest, gen_once: Callable, is_pause
         acc_logprobs += res["output_logprobs"]
         acc_versions += res["output_versions"]
         itl += res.get("itl", [])
+        if g.stop and req.tokenizer is not None:
+            # the servers match stop strings as token-id sequences; the text decides (a stop string spelled with
+            # other tokens): cut after the token that completes it
+            first_new = len(acc_tokens) - len(res["output_tokens"])
+            cut = stop_strings.first_cut(req.tokenizer, acc_tokens, g.stop, first_new)
+            if cut is not None:
+                del acc_tokens[cut:], acc_logprobs[cut:], acc_versions[cut:]
+                stop_reason = "stop"
+                break
         fr = res["finish_reason"]
         if fr == "abort":
             stop_reason = "interrupt"

@@ -38,7 +38,7 @@ import torch
 from aiohttp import web
 
 from ..api.cli_args import InferenceServerConfig
-from ..utils import logging
+from ..utils import logging, stop_strings
 from .engine import NativeInferenceEngine
 
 logger = logging.getLogger("inference-server")
@@ -194,7 +194,7 @@ class InferenceServer:
         toks: List[int] = []
         lps: List[float] = []
         vers: List[int] = []
-        longest = max(len(tok.encode(x, add_special_tokens=False)) for x in stops) + 8
+        lookback = stop_strings.window(tok, stops)
         cut = None
         while True:
             kind, item = await q.get()
@@ -208,13 +208,8 @@ class InferenceServer:
             toks += t
             lps += l
             vers += v
-            lo = max(0, first_new - longest)
-            if any(x in tok.decode(toks[lo:]) for x in stops):
-                # the first token count whose text holds a stop string
-                for n in range(first_new + 1, len(toks) + 1):
-                    if any(x in tok.decode(toks[lo:n]) for x in stops):
-                        cut = n
-                        break
+            cut = stop_strings.first_cut(tok, toks, stops, first_new, lookback)
+            if cut is not None:
                 await self._offload(self.engine.abort, engine_rid)
         if cut is None:
             return res

@@ -359,3 +359,25 @@ def test_stop_strings_end_generation_where_the_decoded_text_contains_them(eng):
         assert r["output_ids"] == base and r["meta_info"]["finish_reason"]["type"] == "length"
     finally:
         loop.call_soon_threadsafe(loop.stop)
+
+
+def test_client_loop_cuts_at_a_stop_string_the_server_did_not_see(eng):
+    """`agenerate` of the in-process engine (the same loop serves the HTTP client): the stop string's canonical token
+    ids never occur, its text does."""
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters, InferenceEngineConfig
+    from areal_vllm_amd.api.io_struct import ModelRequest
+    from areal_vllm_amd.engine.local_engine import LocalInferenceEngine
+
+    tok = _LetterTokenizer()
+    base = _greedy(eng, n=24).output_tokens
+    text = tok.decode(base)
+    j = next(i for i in range(4, 22) if (base[i] >= 26 or base[i + 1] >= 26) and text.find(text[i:i + 2]) == i)
+    le = LocalInferenceEngine(InferenceEngineConfig(max_concurrent_rollouts=4, consumer_batch_size=1), eng)
+    le.initialize(train_data_parallel_size=1)
+    try:
+        g = GenerationHyperparameters(n_samples=1, max_new_tokens=24, greedy=True, stop=[text[j:j + 2]])
+        resp = asyncio.run(le.agenerate(ModelRequest(rid="s", input_ids=PROMPT, gconfig=g, tokenizer=tok)))
+        assert resp.output_tokens == base[:j + 2] and resp.stop_reason == "stop"
+        assert len(resp.output_logprobs) == j + 2 and len(resp.output_versions) == j + 2
+    finally:
+        le.destroy()
