@@ -185,7 +185,10 @@ class ModelRunner:
         if cfg.n_experts > 0:
             h = blk.mlp(x, None, self.model.ep_group)
         else:
-            h = F.linear(ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act), blk.mlp.down)
+            a = ops.train_gemm.gate_up_act(x, blk.mlp.gate_up, blk.mlp.act)  # prefill of many rows: one kernel
+            if a is None:
+                a = ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)
+            h = F.linear(a, blk.mlp.down)
         if self.tp_comm:
             self._tp_all_reduce(h)
         return h, residual

@@ -193,7 +193,9 @@ class MLP(nn.Module):
 
             h = ops.swiglu(ops.linear(GatherFromSP.apply(x, tp_group), self.gate_up), self.act)
             return ReduceScatterToSP.apply(ops.linear(h, self.down), tp_group)
-        h = ops.swiglu(ops.linear(x, self.gate_up, reduce_dx_group=tp_group), self.act)
+        h = ops.train_gemm.gate_up_act(x, self.gate_up, self.act)  # one kernel in no-grad forwards of many rows
+        if h is None:
+            h = ops.swiglu(ops.linear(x, self.gate_up, reduce_dx_group=tp_group), self.act)
         return _AllReduceFwd.apply(ops.linear(h, self.down), tp_group)
 
 

@@ -26,6 +26,7 @@ from .norm_act import RotaryTable, apply_rope, rmsnorm, rope_inplace_, swiglu  #
 from .optim import adam_prepare_, adamw_, scale_, sumsq_  # noqa: F401
 from .rl import gae_1d_packed, gae_2d, gae_padded, merge_intervals, set_intervals, slice_intervals  # noqa: F401
 from .sampling import TokenCounts, advance_step_, decode_advance_, decode_begin_, sample  # noqa: F401
+from . import train_gemm  # noqa: F401
 from .linear import embedding, linear  # noqa: F401
 from .decode_gemm import dgemm, splitk_residual_rmsnorm, splitk_rope_cache_write  # noqa: F401
 from .grouped_gemm import grouped_gemm, grouped_gemm_ref  # noqa: F401

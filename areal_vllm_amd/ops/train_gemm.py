@@ -75,3 +75,47 @@ def tgemm_wgrad_(acc: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, splits: i
     if main < M:
         torch.addmm(acc, dy[main:].t(), x[main:], out_dtype=torch.float32, out=acc)
     return acc
+
+
+# rows from which the fused gate|up + SwiGLU kernel replaces library GEMM + activation kernel in no-grad forwards
+GATED_MIN_ROWS = int(os.environ.get("AREAL_FUSED_MLP_MIN_ROWS", "4096"))
+
+
+def gated_supported(x: torch.Tensor, w_gate_up: torch.Tensor) -> bool:
+    if not (x.is_cuda and x.dim() == 2 and w_gate_up.dim() == 2 and x.dtype == torch.bfloat16
+            and w_gate_up.dtype == torch.bfloat16):
+        return False
+    M, K = x.shape
+    if w_gate_up.shape[1] != K or w_gate_up.shape[0] % 2 or K % 128 or (w_gate_up.shape[0] // 2) % 4:
+        return False
+    if x.stride(1) != 1 or x.stride(0) % 8 or not w_gate_up.is_contiguous():
+        return False
+    return x.data_ptr() % 16 == 0 and w_gate_up.data_ptr() % 16 == 0 and M > 0
+
+
+def tgemm_swiglu(x: torch.Tensor, w_gate_up: torch.Tensor, out: Optional[torch.Tensor] = None,
+                 max_blocks: int = 256) -> torch.Tensor:
+    """out[M, F] = silu(x @ Wg^T) * (x @ Wu^T) for W = [Wg; Wu] of shape [2 F, K]: the gate|up projection of a gated
+    MLP and its activation in one kernel (gate and up are rounded to bf16 before the activation, as the unfused path
+    holds them); the [M, 2 F] intermediate is never written. For forward passes that keep no activations."""
+    assert gated_supported(x, w_gate_up)
+    M, K = x.shape
+    Fo = w_gate_up.shape[0] // 2
+    if out is None:
+        out = torch.empty(M, Fo, dtype=torch.bfloat16, device=x.device)
+    assert out.dtype == torch.bfloat16 and out.stride(1) == 1 and out.stride(0) % 4 == 0
+    L.check(L.lib().areal_tgemm_swiglu(L.ptr(x), L.c_int64(x.stride(0)), L.ptr(w_gate_up), L.c_int64(w_gate_up.stride(0)),
+                                       L.ptr(out), L.c_int64(out.stride(0)), L.c_int(M), L.c_int(Fo), L.c_int(K),
+                                       L.c_int(int(max_blocks)), L.stream_ptr()), "tgemm_swiglu")
+    return out
+
+
+def gate_up_act(x: torch.Tensor, w_gate_up: torch.Tensor, act: str = "silu") -> Optional[torch.Tensor]:
+    """The fused kernel's result when it applies (no gradient wanted, SiLU gate, enough rows, supported shapes),
+    else None: the caller then runs projection and activation separately."""
+    if act != "silu" or torch.is_grad_enabled() and (x.requires_grad or w_gate_up.requires_grad):
+        return None
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.shape[0] < GATED_MIN_ROWS or not gated_supported(x2, w_gate_up):
+        return None
+    return tgemm_swiglu(x2, w_gate_up).view(*x.shape[:-1], w_gate_up.shape[0] // 2)

@@ -73,8 +73,13 @@ DEVINL void tg_barrier() {
 typedef bf16x8 tg_bfrag[2][2];  // [n tile][k step]
 typedef f32x4 tg_acc[4][2];     // [m tile][n tile] of one quadrant
 
-template <bool STAGGER>
+// EPI 0: C = A.B^T (+ bias), output tiles of 256 x 256. EPI 1 (gated MLP, no-grad forward): B = [gate rows; up rows]
+// of width N each, C[M, N] = silu(A.gate^T) * (A.up^T); an output tile is 256 rows x 128 columns, its B pieces hold
+// the 128 gate rows (read in the phases of the first column half) and the 128 matching up rows (second half), so a
+// lane finds gate and up of the same output element in the same registers of the two accumulator quadrants.
+template <bool STAGGER, int EPI>
 __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
+  constexpr int TN = EPI == 1 ? 128 : 256;  // output columns per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
     const int rows = min(a.tiles_m - first, TG_GROUP_M);
     const int in_band = wg - band * per_band;
     m0 = (first + in_band % rows) * 256;
-    n0 = (in_band / rows) * 256;
+    n0 = (in_band / rows) * TN;
   };
   const int KT = a.K >> 6;
 
@@ -107,8 +112,14 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
         int row = m0 + i * 128 + h * 64 + srow;
         row = row < a.M ? row : a.M - 1;
         srcA[h][i] = a.A + (size_t)row * a.lda + schunk * 8;
-        int col = n0 + (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
-        col = col < a.N ? col : a.N - 1;
+        int col;
+        if (EPI == 1) {  // piece h: gate (0) or up (1) rows of the tile's 128 columns, 32 per wave column
+          col = n0 + (i * 2 + (wave >> 2)) * 32 + (wave & 3) * 8 + (lane >> 3);
+          col = (col < a.N ? col : a.N - 1) + h * a.N;
+        } else {
+          col = n0 + (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
+          col = col < a.N ? col : a.N - 1;
+        }
         srcB[h][i] = a.B + (size_t)col * a.ldb + schunk * 8;
       }
   };
@@ -197,6 +208,38 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
       }
     }
   };
+  // gated form: `g` and `u` are the two column quadrants of one row half
+  auto put_gated = [&](tg_acc& g, tg_acc& u, int m0, int n0, int mh) __attribute__((always_inline)) {
+    const int n = n0 + wc * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int m = m0 + wr * 128 + mh * 64 + mt * 16 + fr;
+      unsigned pk[2][2];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // the unfused path carries gate|up as a bf16 tensor
+          const float gg = bf2f(f2bf(g[mt][nt][j])), uu = bf2f(f2bf(u[mt][nt][j]));
+          v[j] = gg / (1.f + __expf(-gg)) * uu;
+        }
+        bf16x2 lo = {f2bf(v[0]), f2bf(v[1])}, hi = {f2bf(v[2]), f2bf(v[3])};
+        pk[nt][0] = __builtin_bit_cast(unsigned, lo);
+        pk[nt][1] = __builtin_bit_cast(unsigned, hi);
+      }
+      const auto r0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+      const u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+      if (m < a.M && n < a.N) {
+        if (n + 8 <= a.N) {
+          *reinterpret_cast<u32x4*>(a.C + (size_t)m * a.ldc + n) = o;
+        } else {
+          *reinterpret_cast<u32x2*>(a.C + (size_t)m * a.ldc + n) = (u32x2){o[0], o[1]};
+        }
+      }
+    }
+  };
   int cm0 = 0, cn0 = 0;  // origin of the output tile being computed
 
   // One K tile = four phases. The K tiles of the block's successive output tiles form ONE stream: the pieces staged
@@ -223,18 +266,19 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
     mma(acc00, bf0);
     // last K tile: a quadrant is final once its phase is over; its stores are issued while the other wave group
     // computes
-    if (MODE == 2) put(acc00, cm0, cn0, 0, 0);
+    if (MODE == 2 && EPI == 0) put(acc00, cm0, cn0, 0, 0);
     if (MODE == 1 && go) set_sources(nm0, nn0);
     // phase 2: quadrant (0, 1)
     read_b(buf, 1, bf1);
     if (go) stage(buf, PB0, t2);
     mma(acc01, bf1);
-    if (MODE == 2) put(acc01, cm0, cn0, 0, 1);
+    if (MODE == 2 && EPI == 0) put(acc01, cm0, cn0, 0, 1);
+    if (MODE == 2 && EPI == 1) put_gated(acc00, acc01, cm0, cn0, 0);
     // phase 3: quadrant (1, 1)
     read_a(buf, 1);
     if (go) stage(buf, PA0, t2);
     mma(acc11, bf1);
-    if (MODE == 2) put(acc11, cm0, cn0, 1, 1);
+    if (MODE == 2 && EPI == 0) put(acc11, cm0, cn0, 1, 1);
     // phase 4: quadrant (1, 0); the next K tile of the stream becomes readable
     if (go) {
       stage(buf, PB1, t2);
@@ -243,7 +287,8 @@ __global__ __launch_bounds__(512) void tgemm_tn_kernel(const TGArgs a) {
       tg_vmcnt<0>();
     }
     mma(acc10, bf0);
-    if (MODE == 2) put(acc10, cm0, cn0, 1, 0);
+    if (MODE == 2 && EPI == 0) put(acc10, cm0, cn0, 1, 0);
+    if (MODE == 2 && EPI == 1) put_gated(acc10, acc11, cm0, cn0, 1);
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
@@ -524,17 +569,20 @@ __global__ __launch_bounds__(512) void tgemm_wgrad_kernel(const TWArgs a) {
 // C[M, N] = A[M, K] . B[N, K]^T (+ bias). Leading dimensions in elements (multiples of 8: 16-byte rows), K a multiple
 // of 128, N a multiple of 4. Returns -1 for shapes outside that (the caller keeps its library path).
 // One launch = min(tiles, max_blocks) persistent workgroups (256 = one per CU).
-extern "C" int areal_tgemm_tn(const void* A, long lda, const void* B, long ldb, void* C, long ldc, const void* bias,
-                              int M, int N, int K, int stagger, int max_blocks, hipStream_t st) {
+// gated = 1: B holds 2 N rows (gate rows, then up rows), C[M, N] = silu(A.gate^T) * (A.up^T), no bias.
+static int tgemm_tn_launch(const void* A, long lda, const void* B, long ldb, void* C, long ldc, const void* bias, int M,
+                           int N, int K, int stagger, int max_blocks, int gated, hipStream_t st) {
   if (M <= 0 || N <= 0) return 0;
   if (K % 128 != 0 || N % 4 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 4 != 0) return -1;
   if (((uintptr_t)A | (uintptr_t)B) % 16 != 0 || (uintptr_t)C % 8 != 0 || (bias && (uintptr_t)bias % 8 != 0)) return -1;
+  if (gated && bias) return -1;
   TGArgs a{(const bf16_t*)A, lda, (const bf16_t*)B, ldb, (bf16_t*)C, ldc, (const bf16_t*)bias, M, N, K,
-           (M + 255) / 256, (N + 255) / 256};
+           (M + 255) / 256, gated ? (N + 127) / 128 : (N + 255) / 256};
   static bool attr_set = false;  // 128 KiB of dynamic LDS: above the default limit
   if (!attr_set) {
-    HIP_RET(hipFuncSetAttribute((const void*)tgemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));
-    HIP_RET(hipFuncSetAttribute((const void*)tgemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));
+    HIP_RET(hipFuncSetAttribute((const void*)tgemm_tn_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));
+    HIP_RET(hipFuncSetAttribute((const void*)tgemm_tn_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));
+    HIP_RET(hipFuncSetAttribute((const void*)tgemm_tn_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS));
     attr_set = true;
   }
   // max_blocks workgroups (a multiple of 8: block id mod 8 is the XCD for every tile of a block's sequence) walk the
@@ -542,11 +590,26 @@ extern "C" int areal_tgemm_tn(const void* A, long lda, const void* B, long ldb, 
   const int ntiles = a.tiles_m * a.tiles_n;
   if (max_blocks > 0 && max_blocks % 8 != 0) return -1;
   const dim3 grid(max_blocks > 0 ? std::min(ntiles, max_blocks) : ntiles), block(512);
-  if (stagger)
-    hipLaunchKernelGGL(tgemm_tn_kernel<true>, grid, block, TG_LDS, st, a);
+  if (gated)
+    hipLaunchKernelGGL((tgemm_tn_kernel<true, 1>), grid, block, TG_LDS, st, a);
+  else if (stagger)
+    hipLaunchKernelGGL((tgemm_tn_kernel<true, 0>), grid, block, TG_LDS, st, a);
   else
-    hipLaunchKernelGGL(tgemm_tn_kernel<false>, grid, block, TG_LDS, st, a);
+    hipLaunchKernelGGL((tgemm_tn_kernel<false, 0>), grid, block, TG_LDS, st, a);
   return (int)hipGetLastError();
+}
+
+extern "C" int areal_tgemm_tn(const void* A, long lda, const void* B, long ldb, void* C, long ldc, const void* bias,
+                              int M, int N, int K, int stagger, int max_blocks, hipStream_t st) {
+  return tgemm_tn_launch(A, lda, B, ldb, C, ldc, bias, M, N, K, stagger, max_blocks, 0, st);
+}
+
+// C[M, F] = silu(A . Wg^T) * (A . Wu^T) with W = [Wg; Wu] of shape [2 F, K] (the gate|up projection of a gated MLP and
+// its activation in one kernel: the [M, 2 F] intermediate is never written). For forward passes that keep no
+// activations (scoring, prefill).
+extern "C" int areal_tgemm_swiglu(const void* A, long lda, const void* W, long ldw, void* C, long ldc, int M, int F,
+                                  int K, int max_blocks, hipStream_t st) {
+  return tgemm_tn_launch(A, lda, W, ldw, C, ldc, nullptr, M, F, K, 1, max_blocks, 1, st);
 }
 
 // dW[N, K] (fp32, leading dimension ldw) += dY[M, N]^T . X[M, K]. N a multiple of 128, K of 256, M a multiple of 128 (the

@@ -1155,3 +1155,27 @@ def test_weight_gradient_gemm_matches_fp64(M, N, K, splits):
     ops.linear(xin, w).backward(dy)
     torch.testing.assert_close(w.main_grad.double(), dy.double().t() @ x.double(), atol=2e-5, rtol=1e-5)
     torch.testing.assert_close(xin.grad.float(), dy.float() @ w.float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Fo,K", [(256, 128, 128), (4096 + 77, 8960, 1536), (1000, 1284, 256), (2048, 4480, 1536)])
+def test_fused_gate_up_swiglu_forward_matches_unfused(M, Fo, K):
+    """gate|up projection + SwiGLU in one kernel (no-grad forwards) against projection, bf16 round, activation."""
+    from areal_vllm_amd.ops import train_gemm as tg
+
+    torch.manual_seed(M + Fo)
+    dev = torch.device("cuda")
+    x = (torch.rand(M, K, device=dev) * 2 - 1).bfloat16()
+    w = ((torch.rand(2 * Fo, K, device=dev) * 2 - 1) * (3.0 / K ** 0.5)).bfloat16()
+    got = tg.tgemm_swiglu(x, w)
+    gu = (x.float() @ w.float().t()).bfloat16().float()
+    ref = torch.nn.functional.silu(gu[:, :Fo]) * gu[:, Fo:]
+    torch.testing.assert_close(got.float(), ref, atol=0.03, rtol=0.03)
+    if Fo % 8 == 0:  # the stand-alone activation kernel takes multiples of 8
+        unfused = ops.swiglu(torch.nn.functional.linear(x, w), "silu")
+        assert float((got.float() - ref).abs().max()) <= 2.0 * float((unfused.float() - ref).abs().max()) + 2e-2
+    # the dispatcher: fused without gradients from GATED_MIN_ROWS rows on, otherwise left to the caller
+    with torch.no_grad():
+        r = tg.gate_up_act(x, w, "silu")
+    assert (r is not None) == (M >= tg.GATED_MIN_ROWS) and (r is None or torch.equal(r, got))
+    assert tg.gate_up_act(x.requires_grad_(True), w, "silu") is None and tg.gate_up_act(x.detach(), w, "gelu_tanh") is None

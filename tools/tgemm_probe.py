@@ -54,6 +54,18 @@ def main():
              ("down", s["H"], s["F"]), ("dgrad gate_up", s["H"], 2 * s["F"]), ("dgrad down", s["F"], s["H"])]
     if args.lm_head:
         cases.append(("lm_head (8192 rows)", s["V"], s["H"]))
+    # gate|up + SwiGLU in one kernel against library GEMM + activation kernel
+    import areal_vllm_amd.ops as ops
+    import torch.nn.functional as Fn
+
+    torch.manual_seed(0)
+    a = (torch.rand(M, s["H"], device=dev) * 2 - 1).bfloat16()
+    w = ((torch.rand(2 * s["F"], s["H"], device=dev) * 2 - 1) / s["H"] ** 0.5).bfloat16()
+    out = torch.empty(M, s["F"], device=dev, dtype=torch.bfloat16)
+    res = time_rounds({"lib+act": lambda: ops.swiglu(Fn.linear(a, w), "silu"),
+                       "fused": lambda: tg.tgemm_swiglu(a, w, out=out)}, args.iters, args.rounds)
+    print(f"M={M:6d} gate|up + SwiGLU  F={s['F']:6d} K={s['H']:6d} | "
+          + " | ".join(f"{k} {med:8.1f} us (best {mn:8.1f})" for k, (med, mn) in res.items()), flush=True)
     for name, N, K in cases:
         m = 8192 if name.startswith("lm_head") else M
         torch.manual_seed(0)
