@@ -158,35 +158,49 @@ __global__ __launch_bounds__(1024) void sample_kernel(
   ArgMax best;
   best.v = -INFINITY;
   best.i = 0x7fffffff;
-  for (int i8 = threadIdx.x * 8; i8 < V8; i8 += blockDim.x * 8) {
-    float z[8];
-    R.z8(i8, z);
-    float m8 = -INFINITY;
+  // The row is walked in groups of PF chunks per thread whose loads are all issued before the first one is used: a
+  // thread sees ~19 chunks of a 152k-entry row, and with one load in flight at a time the pass is a chain of that
+  // many memory round trips (the per-entry noise and exponentials are cheap next to them).
+  constexpr int PF = 4;
+  for (int base = threadIdx.x * 8; base < V8; base += blockDim.x * 8 * PF) {
+    float zz[PF][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      m8 = fmaxf(m8, z[j]);
-      mn = fminf(mn, z[j]);
+    for (int u = 0; u < PF; ++u) {
+      const int i8 = base + u * (int)blockDim.x * 8;
+      if (i8 < V8) R.z8(i8, zz[u]);
     }
-    if (m8 > mx) {
-      se *= __expf(mx - m8);
-      mx = m8;
-    }
-    if (mx > -INFINITY) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) se += __expf(z[j] - mx);
-    }
-    if (pick_now) {
-      u32x4 r0, r1;
-      if (noise) {
-        r0 = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i8 >> 2));
-        r1 = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i8 >> 2) + 1);
-      }
+    for (int u = 0; u < PF; ++u) {
+      const int i8 = base + u * (int)blockDim.x * 8;
+      if (i8 >= V8) break;
+      float* z = zz[u];
+      float m8 = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        ArgMax c;
-        c.v = noise ? z[j] + gumbel(j < 4 ? r0[j] : r1[j - 4]) : z[j];
-        c.i = i8 + j;
-        best = amax(best, c);
+        m8 = fmaxf(m8, z[j]);
+        mn = fminf(mn, z[j]);
+      }
+      if (m8 > mx) {
+        se *= __expf(mx - m8);
+        mx = m8;
+      }
+      if (mx > -INFINITY) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) se += __expf(z[j] - mx);
+      }
+      if (pick_now) {
+        u32x4 r0, r1;
+        if (noise) {
+          r0 = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i8 >> 2));
+          r1 = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i8 >> 2) + 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ArgMax c;
+          c.v = noise ? z[j] + gumbel(j < 4 ? r0[j] : r1[j - 4]) : z[j];
+          c.i = i8 + j;
+          best = amax(best, c);
+        }
       }
     }
   }
