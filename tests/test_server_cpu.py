@@ -121,9 +121,15 @@ def test_interrupted_generation_spans_versions(server):
     client.set_version(base)
 
     async def go():
-        req = ModelRequest(input_ids=[4, 5, 6], gconfig=GenerationHyperparameters(max_new_tokens=120, min_new_tokens=120))
+        req = ModelRequest(input_ids=[4, 5, 6], gconfig=GenerationHyperparameters(max_new_tokens=240, min_new_tokens=240))
+        done_before = eng.stats["decode_steps"]  # counts decode plans as they complete
         task = asyncio.create_task(client.agenerate(req))
-        await asyncio.sleep(0.3)
+        # interrupt once the request is under way - by progress, not by wall time (a fast host finishes 100 tokens of
+        # this model in a fraction of a second)
+        for _ in range(4000):
+            if eng.stats["decode_steps"] - done_before >= 4:
+                break
+            await asyncio.sleep(0.002)
         loop = asyncio.get_running_loop()
         await loop.run_in_executor(None, lambda: requests.post(f"http://{addr}/pause_generation", timeout=30))
         await loop.run_in_executor(None, lambda: requests.post(
@@ -134,7 +140,7 @@ def test_interrupted_generation_spans_versions(server):
         return await task
 
     resp = asyncio.run(go())
-    assert resp.output_len == 120
+    assert resp.output_len == 240
     vs = set(resp.output_versions)
     assert vs <= {base, base + 1} and (base + 1) in vs
     assert resp.output_versions == sorted(resp.output_versions)
