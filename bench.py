@@ -181,16 +181,23 @@ def _port_block_free(base, offsets=(0, 1, 2, 16, 17, 18)):
 
 
 def _pick_master_port():
+    """Base of a free block of rendezvous ports BELOW the range the kernel hands out for `bind(port 0)`: the job's own
+    servers and gloo pairs take ports from that range while it runs, and a base taken from there was seen to lose
+    its +1 neighbour (the decoupled mode's trainer group) to one of them."""
     import random
-    import socket
 
-    for _ in range(64):
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            base = sk.getsockname()[1]
-        if base + 18 < 65536 and _port_block_free(base):
+    lo = 32768
+    try:
+        lo = int(open("/proc/sys/net/ipv4/ip_local_port_range").read().split()[0])
+    except (OSError, ValueError, IndexError):
+        pass
+    top = max(12000, min(lo, 65000) - 64)
+    rnd = random.SystemRandom()
+    for _ in range(256):
+        base = rnd.randrange(10000, top)
+        if _port_block_free(base):
             return base
-    return random.randint(20000, 40000)
+    return rnd.randrange(10000, top)
 
 
 def launch_ranks(args):

@@ -17,19 +17,17 @@ ARGS = ["--device", "cpu", "--model", "tiny", "--steps", "2", "--warmup", "1", "
 
 
 def _free_port():
-    """A port whose neighbours (+1, +2: trainer group and host store of the decoupled mode) are free as well."""
-    for _ in range(64):
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            base = s.getsockname()[1]
-        try:
-            for off in (1, 2):
-                with socket.socket() as t:
-                    t.bind(("127.0.0.1", base + off))
-            return base
-        except OSError:
-            continue
-    raise RuntimeError("no free port block")
+    """A rendezvous port whose neighbours (+1, +2: trainer group and host store of the decoupled mode; +16..18: the
+    decoupled second pass) are free as well - chosen the way `bench.py` chooses it for the ranks it spawns itself."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return bench._pick_master_port()
+
+
+def _err(p):
+    """The children's stderr without the C++ frames of torch's error reports (they push the Python traceback out)."""
+    return "\n".join(l for l in p.stderr.splitlines() if "frame #" not in l)[-6000:]
 
 
 @pytest.mark.parametrize("n,mode", [(1, "colocated"), (4, "colocated"), (2, "decoupled"), (8, "decoupled")])
@@ -43,7 +41,7 @@ def test_bench_prints_one_json_line(n, mode):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), "--mode", mode, "--no-decoupled-pass", *ARGS]
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, _err(p)
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
@@ -71,7 +69,7 @@ def test_plain_invocation_spawns_its_own_ranks(n):
         env.pop(k, None)
     p = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), *ARGS], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, _err(p)
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout
     out = json.loads(lines[0])
