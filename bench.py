@@ -688,7 +688,13 @@ def run_rank(args):
         engine.destroy()
     if getattr(actor, "_ipc_export", None) is not None:
         actor._ipc_export.close()
+    second_port = None
     if world > 1:
+        if not decoupled and not args.no_decoupled_pass:
+            # the second pass rendezvouses on a port block of its own, picked by rank 0 below the ephemeral range
+            box = [_pick_master_port() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            second_port = box[0]
         dist.barrier()
         dist.destroy_process_group()
     if (not decoupled and args.gpus >= 2 and args.gpus % 2 == 0 and not args.no_decoupled_pass
@@ -702,7 +708,7 @@ def run_rank(args):
         if on_gpu:
             torch.cuda.empty_cache()
         mark("decoupled pass")
-        second = decoupled_second_pass(args, rank)
+        second = decoupled_second_pass(args, rank, second_port)
         if out is not None:
             out["decoupled"] = second
     if out is not None:
@@ -712,14 +718,14 @@ def run_rank(args):
         os.dup2(2, 1)
 
 
-def decoupled_second_pass(args, rank):
+def decoupled_second_pass(args, rank, port=None):
     """Run ``--mode decoupled`` on the same ranks in one fresh child process per rank and return rank 0's
     summary of its result line ({"error": ...} if the pass failed or overran its budget: the headline result
     must not depend on it)."""
     import subprocess
 
     steps = max(1, min(args.steps, args.decoupled_steps))
-    env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 16),
+    env = dict(os.environ, MASTER_PORT=str(port or int(os.environ.get("MASTER_PORT", "29533")) + 16),
                TORCHELASTIC_USE_AGENT_STORE="False")
     cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--mode", "decoupled", "--steps", str(steps),
            "--warmup", "1", "--no-decoupled-pass", "--stall-timeout", str(args.decoupled_budget)]
