@@ -137,6 +137,10 @@ class NativeEngineConfig:
         "help": "ZeRO-3: drop a block's gathered weights after its forward and gather them again for the backward"})
     offload_optimizer: bool = field(default=False, metadata={
         "help": "ZeRO-3: keep fp32 master weights and Adam moments in pinned host memory"})
+    peer_collectives: bool = field(default=False, metadata={
+        "help": "groups of 2..8 ranks on one node run the Ulysses exchange, the sequence-parallel all-gather / "
+                "reduce-scatter and the ZeRO-1 bucket collectives as kernels over peer-mapped memory instead of RCCL "
+                "(also AREAL_PEER_COLLECTIVES=1); a group that fails the start-up check stays on RCCL"})
     context_parallel_mode: str = field(default="ulysses", metadata={
         "help": "what the `c` dimension of the allocation mode does: 'ulysses' (all-to-all between token and "
                 "head partitions, the reference's FSDP engine) or 'zigzag' (load-balanced token placement with "

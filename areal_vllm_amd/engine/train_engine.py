@@ -30,6 +30,7 @@ from ..api.io_struct import FinetuneSpec, ParamSpec, SaveLoadMeta, WeightUpdateM
 from ..models import hf_io
 from ..models.config import PRESETS, ModelConfig, preset
 from ..models.transformer import ALIGN, FlatParams, Transformer
+from ..ops import peer_collectives
 from ..parallel import comm
 from ..parallel.grid import ProcessGrid, init_distributed
 from ..parallel.zero import ShardedAdamW, lr_lambda
@@ -244,6 +245,12 @@ class NativeTrainEngine(TrainEngine):
                 from ..parallel.ulysses import UlyssesContext
 
                 self.model.sp = UlyssesContext(g.group("cp"), g.cp, g.coord.cp)
+        use_peer = self.device.type == "cuda" and (cfg.native.peer_collectives or peer_collectives.ENABLED)
+        if use_peer:
+            # activation collectives of the compute stream: Ulysses exchange (cp), sequence parallelism (tp)
+            for name in (("cp",) if g.cp > 1 else ()) + (("tp",) if self.model.seq_par else ()):
+                if comm.peer(g.group(name)) is None:
+                    comm.attach_peer(g.group(name), peer_collectives.open_for(g.group(name), self.device))
         edp = max(1, len(g.group_ranks["edp"]))  # replicas of every expert shard
         flat = self.model.flatten(pad_to=g.dp * g.cp, expert_pad_to=edp if g.ep > 1 else None)
         if cfg.init_from_scratch or not (cfg.path and os.path.isdir(cfg.path)):
@@ -279,8 +286,10 @@ class NativeTrainEngine(TrainEngine):
         elif with_optim:
             flat.alloc_main_grad()
             mp_groups = tuple(x for x in (g.group("tp"), g.group("pp")) if x is not None)
+            zpeer = (peer_collectives.open_for(g.group("dp_cp"), self.device)
+                     if use_peer and g.dp * g.cp > 1 else None)
             self.optimizer = ShardedAdamW(flat, self.optimizer_config, dp_group=g.group("dp_cp"), mp_groups=mp_groups,
-                                          replicated_ranges=self._norm_ranges())
+                                          replicated_ranges=self._norm_ranges(), peer=zpeer)
             fe = self.model.flat_experts
             if fe is not None:
                 fe.alloc_main_grad()

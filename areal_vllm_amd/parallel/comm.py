@@ -17,6 +17,22 @@ import torch.distributed as dist
 FORCE_COLLECTIVES = os.environ.get("AREAL_FORCE_COLLECTIVES", "0") == "1"
 
 
+# peer-memory collectives (ops/peer_collectives.py) attached to a group for the ACTIVATION collectives the model
+# issues on the compute stream; the sharded optimizer holds an object of its own (it works on a side stream)
+_PEERS = {}
+
+
+def attach_peer(group, pc) -> None:
+    if pc is None:
+        _PEERS.pop(group, None)
+    else:
+        _PEERS[group] = pc
+
+
+def peer(group):
+    return _PEERS.get(group) if _PEERS else None
+
+
 def group_size(group) -> int:
     if not dist.is_initialized():
         return 1
@@ -90,6 +106,9 @@ def all_gather_cat(x: torch.Tensor, group) -> torch.Tensor:
     if n == 1:
         return x
     x = x.contiguous()
+    pc = peer(group)
+    if pc is not None and pc.serves_rows(x) and x.numel() * x.element_size() % 16 == 0:
+        return pc.all_gather_rows(x)
     out = x.new_empty((n * x.shape[0],) + tuple(x.shape[1:]))
     if _is_nccl(x):
         dist.all_gather_into_tensor(out, x, group=group)
@@ -105,6 +124,9 @@ def reduce_scatter_rows(x: torch.Tensor, group) -> torch.Tensor:
         return x
     x = x.contiguous()
     c = x.shape[0] // n
+    pc = peer(group)
+    if pc is not None and x.shape[0] % n == 0 and pc.serves_rows(x):
+        return pc.reduce_scatter_rows(x)
     if _is_nccl(x):
         out = x.new_empty((c,) + tuple(x.shape[1:]))
         dist.reduce_scatter_tensor(out, x, group=group)

@@ -26,11 +26,7 @@ class _SeqToHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         ctx.group = group
-        tl, cp, h, D = x.shape
-        send = x.permute(1, 0, 2, 3).contiguous()
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=group)
-        return recv.view(cp * tl, h, D)
+        return _seq_to_head(x, group)
 
     @staticmethod
     def backward(ctx, g):
@@ -47,16 +43,34 @@ class _HeadToSeq(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        tl, cp, h, D = g.shape
-        send = g.permute(1, 0, 2, 3).contiguous()
-        recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=ctx.group)
-        return recv.view(cp * tl, h, D), None
+        return _seq_to_head(g, ctx.group), None
+
+
+def _peer_for(x, group):
+    """The group's peer-memory exchange when it can carry `x` (rows of whole 16-byte vectors), else None."""
+    pc = comm.peer(group)
+    if pc is None or not x.is_cuda or (x.shape[-1] * x.shape[-2] * x.element_size()) % 16 != 0:
+        return None
+    return pc
+
+
+def _seq_to_head(x, group):
+    tl, cp, h, D = x.shape
+    pc = _peer_for(x, group)
+    if pc is not None:  # the transpose is the kernel's addressing
+        return pc.seq_to_head(x.contiguous())
+    send = x.permute(1, 0, 2, 3).contiguous()
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv.view(cp * tl, h, D)
 
 
 def _head_to_seq(x, group):
     cp = dist.get_world_size(group)
     T, h, D = x.shape
+    pc = _peer_for(x, group)
+    if pc is not None:
+        return pc.head_to_seq(x.contiguous())
     send = x.contiguous().view(cp, T // cp, h, D)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)

@@ -37,14 +37,28 @@ from . import comm
 N_BUCKETS = int(os.environ.get("AREAL_ZERO_BUCKETS", "8"))
 
 
+class _StreamWork:
+    """Stand-in for a communicator's work handle: `wait()` orders the current stream after what a side stream holds."""
+
+    def __init__(self, stream):
+        self.event = stream.record_event()
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 class ShardedAdamW:
     def __init__(self, flat: FlatParams, cfg: OptimizerConfig, dp_group=None, mp_groups: Tuple = (),
-                 replicated_ranges: Optional[List[Tuple[int, int, int]]] = None, n_buckets: Optional[int] = None):
+                 replicated_ranges: Optional[List[Tuple[int, int, int]]] = None, n_buckets: Optional[int] = None,
+                 peer=None):
         """`dp_group`: group over which parameters are replicated (gradients are summed over it).
         `mp_groups`: model-parallel groups (tp, pp) over which the squared gradient norm is summed.
         `replicated_ranges`: (lo, hi, rep) flat ranges of parameters held by `rep` ranks of the tp group
         (norm weights, embeddings, KV projections when tp exceeds the KV heads); their norm contribution
-        is counted once."""
+        is counted once.
+        `peer`: an `ops.peer_collectives.PeerCollectives` over `dp_group` used by nobody else: bucket
+        reduce-scatters and parameter all-gathers then run as peer-memory kernels on a side stream of this
+        object instead of the communicator's."""
         self.flat = flat
         self.cfg = cfg
         self.group = dp_group
@@ -52,6 +66,8 @@ class ShardedAdamW:
         self.n = comm.group_size(dp_group)
         self.rank = comm.group_rank(dp_group)
         self.solo = comm.trivial(dp_group)  # nothing to reduce or gather: the fp32 gradient buffer is the shard
+        self.peer = peer if (peer is not None and flat.flat.is_cuda and not self.solo) else None
+        self._side = torch.cuda.Stream(device=flat.flat.device) if self.peer is not None else None
         assert flat.numel % self.n == 0, "flat buffer must be padded to a multiple of the dp size"
         self.shard_numel = flat.numel // self.n
         # ---- block-cyclic layout: bucket g = flat[n * cut[g] : n * cut[g + 1]], this rank's piece of it starts
@@ -124,7 +140,19 @@ class ShardedAdamW:
     def _launch(self, g: int, async_op: bool):
         lo, hi = self.buckets[g]
         src, out = self.flat.main_grad[lo:hi], self._shard_piece(self.grad_shard, g)
-        if comm._is_nccl(src):
+        if self.peer is not None and (hi - lo) // self.n % 4 == 0:
+            # everything folded into the bucket so far is queued on the compute stream: the side stream starts there
+            from ..ops.peer_collectives import OVERLAP_BLOCKS
+
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self.peer.reduce_scatter_into(out, src, max_blocks=OVERLAP_BLOCKS if async_op else 0)
+            if async_op:
+                self._works.append((_StreamWork(self._side), None))
+            else:
+                cur.wait_stream(self._side)
+        elif comm._is_nccl(src):
             w = dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             if async_op:
                 self._works.append((w, None))
@@ -238,7 +266,14 @@ class ShardedAdamW:
                 shadow.copy_(master)
             # the new parameters of bucket g travel while the next piece is still being updated
             lo, hi = self.buckets[g]
-            comm.all_gather_flat(self.flat.flat[lo:hi], shadow, self.group)
+            if self.peer is not None and (b - a) * shadow.element_size() % 16 == 0:
+                self._side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._side):
+                    self.peer.all_gather_into(self.flat.flat[lo:hi], shadow)
+            else:
+                comm.all_gather_flat(self.flat.flat[lo:hi], shadow, self.group)
+        if self.peer is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def step_stats(self) -> Tuple[float, bool]:
         """(gradient norm, was the update applied) of the last step: ONE read-back of the device-side state."""

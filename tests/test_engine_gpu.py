@@ -901,6 +901,9 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
         assert world == 1
         os.environ.pop("AREAL_HOST_STAGED_COLLECTIVES")
         os.environ.update(AREAL_FORCE_COLLECTIVES="1", AREAL_ZERO_BUCKETS="6")
+    use_peer = dict(layout).get("_peer", False)
+    if use_peer:  # activation and optimizer collectives as kernels over peer-mapped memory
+        os.environ.update(AREAL_PEER_COLLECTIVES="1", AREAL_ZERO_BUCKETS="4", AREAL_PEER_SLOT_MB="1")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from areal_vllm_amd.api.alloc_mode import ParallelStrategy
     from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
@@ -910,6 +913,7 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
 
     layout = dict(layout)
     layout.pop("_rccl1", None)
+    layout.pop("_peer", None)
     preset_name = layout.pop("_model", "small")
     cfg = TrainEngineConfig(experiment_name="t", trial_name="lay", path=ckpt_in or preset_name, init_from_scratch=ckpt_in is None,
                             dtype="bfloat16", gradient_checkpointing=False,
@@ -948,6 +952,16 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
     if (dp > 1 or rccl1) and eng.grid.pp == 1 and eng.zero3 is None and eng.expert_optimizer is None:
         assert len(eng.optimizer.buckets) > 1
         assert eng.optimizer.overlapped_buckets >= 2 * (len(eng.optimizer.buckets) - 1)  # bucketed reduce during backward
+    if use_peer:
+        from areal_vllm_amd.parallel import comm
+
+        g = eng.grid
+        if g.dp * g.cp > 1:  # bucket reduce-scatters and parameter all-gathers
+            pc = eng.optimizer.peer
+            assert pc is not None and pc.calls >= 2 * len(eng.optimizer.buckets) and not pc.error()
+        for name in (("cp",) if g.cp > 1 else ()) + (("tp",) if seq_par else ()):
+            pc = comm.peer(g.group(name))
+            assert pc is not None and pc.calls > 8 * eng.model_config.n_layers and not pc.error(), name
     torch.save(dict(norms=norms, ev=ev, fw=fw, dpr=dpr), f"{out_path}.r{rank}")
     eng.destroy()
 
@@ -1000,6 +1014,35 @@ def test_two_rank_layouts_on_one_gpu_follow_the_single_process(tmp_path):
             fw = torch.cat([p["fw"] for p in sorted(parts, key=lambda p: p["dpr"])])
         S = min(fw.shape[1], ref["fw"].shape[1])
         # position t scores token t + 1: the last position of a sequence scores whatever follows it in the pack
+        valid = torch.zeros(len(_LAYOUT_LENS), S, dtype=torch.bool)
+        for i, n in enumerate(_LAYOUT_LENS):
+            valid[i, :n - 1] = True
+        diff = (fw[:, :S] - ref["fw"][:, :S]).abs()[valid]
+        assert float(diff.mean()) < 0.03 and float(diff.max()) < 0.5, (name, float(diff.mean()), float(diff.max()))
+
+
+def test_layouts_on_peer_memory_collectives_follow_the_single_process(tmp_path):
+    """The same comparison with the trainer's collectives as kernels over peer-mapped memory: ZeRO-1 bucket
+    reduce-scatters (during the backward, on a side stream) and parameter all-gathers, the Ulysses sequence<->head
+    exchange, and the sequence-parallel all-gather / reduce-scatter around tensor-parallel linears; staging slots of
+    1 MiB, so that large messages take several kernels. Every worker checks that its kernels ran and none timed out."""
+    init = str(tmp_path / "init")
+    _run_layout(1, dict(), False, None, init)
+    ref_path = str(tmp_path / "ref")
+    _run_layout(1, dict(), False, init, ref_path)
+    ref = torch.load(ref_path + ".r0", weights_only=True)
+    for name, world, layout, sp in [("dp2", 2, dict(data_parallel_size=2), False),
+                                    ("cp2", 2, dict(context_parallel_size=2), False),
+                                    ("tp2sp", 2, dict(tensor_parallel_size=2), True),
+                                    ("dp2cp2", 4, dict(data_parallel_size=2, context_parallel_size=2), False)]:
+        out = str(tmp_path / name)
+        _run_layout(world, dict(layout, _peer=True), sp, init, out)
+        parts = [torch.load(f"{out}.r{r}", weights_only=True) for r in range(world)]
+        dp = layout.get("data_parallel_size", 1)
+        assert parts[0]["norms"] == pytest.approx(ref["norms"], rel=4e-2), (name, parts[0]["norms"], ref["norms"])
+        by_dp = {p["dpr"]: p["fw"] for p in parts}
+        fw = torch.cat([by_dp[d] for d in range(dp)])
+        S = min(fw.shape[1], ref["fw"].shape[1])
         valid = torch.zeros(len(_LAYOUT_LENS), S, dtype=torch.bool)
         for i, n in enumerate(_LAYOUT_LENS):
             valid[i, :n - 1] = True
