@@ -251,6 +251,13 @@ class NativeTrainEngine(TrainEngine):
             for name in (("cp",) if g.cp > 1 else ()) + (("tp",) if self.model.seq_par else ()):
                 if comm.peer(g.group(name)) is None:
                     comm.attach_peer(g.group(name), peer_collectives.open_for(g.group(name), self.device))
+            if self.model.seq_par and os.environ.get("AREAL_SP_OVERLAP", "1") == "1" and \
+                    comm.overlap(g.group("tp")) is None:
+                # the pipelined linears own a second exchange object: its calls sit on a side stream
+                from ..parallel.sp_overlap import SPOverlap
+
+                pc2 = peer_collectives.open_for(g.group("tp"), self.device)
+                comm.attach_overlap(g.group("tp"), SPOverlap(pc2) if pc2 is not None else None)
         edp = max(1, len(g.group_ranks["edp"]))  # replicas of every expert shard
         flat = self.model.flatten(pad_to=g.dp * g.cp, expert_pad_to=edp if g.ep > 1 else None)
         if cfg.init_from_scratch or not (cfg.path and os.path.isdir(cfg.path)):

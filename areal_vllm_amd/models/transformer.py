@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..parallel import comm
 from ..utils import rng
 from .config import ModelConfig
 
@@ -150,7 +151,14 @@ class Attention(nn.Module):
 
     def forward(self, x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None, seq_par=False):
         D = self.cfg.head_dim
-        if seq_par:  # token-sharded input: all-gather (backward: reduce-scatter)
+        ov = comm.overlap(tp_group) if seq_par else None
+        if ov is not None and not (ov.usable(x) and not self.cfg.qk_norm):
+            ov = None
+        if ov is not None:  # the all-gather travels chunk by chunk under the projection's GEMMs
+            from ..parallel import sp_overlap
+
+            qkv = sp_overlap.gather_linear(x, self.qkv, ov, self.qkv_bias)
+        elif seq_par:  # token-sharded input: all-gather (backward: reduce-scatter)
             from ..parallel.tensor_parallel import GatherFromSP, ReduceScatterToSP
 
             qkv = self.project_qkv(GatherFromSP.apply(x, tp_group))
@@ -171,6 +179,8 @@ class Attention(nn.Module):
                                              dropout_p=self.cfg.attn_pdrop)
         else:
             attn = ops.flash_attn_varlen_qkv(qkv, cu_seqlens, max_seqlen, self.hq, self.hkv)
+        if ov is not None:
+            return sp_overlap.linear_scatter(attn.reshape(T, -1), self.o, ov)
         out = ops.linear(attn.reshape(T, -1), self.o)
         if seq_par:
             return ReduceScatterToSP.apply(out, tp_group)
@@ -188,6 +198,12 @@ class MLP(nn.Module):
         self.down = nn.Parameter(torch.empty(hidden, f, dtype=dtype, device=device))
 
     def forward(self, x, tp_group, seq_par=False):
+        ov = comm.overlap(tp_group) if seq_par else None
+        if ov is not None and ov.usable(x):
+            from ..parallel import sp_overlap
+
+            h = ops.swiglu(sp_overlap.gather_linear(x, self.gate_up, ov), self.act)
+            return sp_overlap.linear_scatter(h, self.down, ov)
         if seq_par:
             from ..parallel.tensor_parallel import GatherFromSP, ReduceScatterToSP
 

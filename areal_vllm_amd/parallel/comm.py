@@ -33,6 +33,21 @@ def peer(group):
     return _PEERS.get(group) if _PEERS else None
 
 
+# parallel/sp_overlap.SPOverlap of a tensor-parallel group: sequence-parallel linears pipelined with their collective
+_OVERLAPS = {}
+
+
+def attach_overlap(group, ov) -> None:
+    if ov is None:
+        _OVERLAPS.pop(group, None)
+    else:
+        _OVERLAPS[group] = ov
+
+
+def overlap(group):
+    return _OVERLAPS.get(group) if _OVERLAPS else None
+
+
 def group_size(group) -> int:
     if not dist.is_initialized():
         return 1

@@ -903,7 +903,8 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
         os.environ.update(AREAL_FORCE_COLLECTIVES="1", AREAL_ZERO_BUCKETS="6")
     use_peer = dict(layout).get("_peer", False)
     if use_peer:  # activation and optimizer collectives as kernels over peer-mapped memory
-        os.environ.update(AREAL_PEER_COLLECTIVES="1", AREAL_ZERO_BUCKETS="4", AREAL_PEER_SLOT_MB="1")
+        os.environ.update(AREAL_PEER_COLLECTIVES="1", AREAL_ZERO_BUCKETS="4", AREAL_PEER_SLOT_MB="1",
+                          AREAL_SP_OVERLAP="0" if use_peer == "plain" else "1", AREAL_SP_OVERLAP_MIN_ROWS="64")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from areal_vllm_amd.api.alloc_mode import ParallelStrategy
     from areal_vllm_amd.api.cli_args import MicroBatchSpec, OptimizerConfig, TrainEngineConfig
@@ -961,7 +962,14 @@ def _layout_worker(rank, world, port, layout, seq_par, ckpt_in, out_path):
             assert pc is not None and pc.calls >= 2 * len(eng.optimizer.buckets) and not pc.error()
         for name in (("cp",) if g.cp > 1 else ()) + (("tp",) if seq_par else ()):
             pc = comm.peer(g.group(name))
-            assert pc is not None and pc.calls > 8 * eng.model_config.n_layers and not pc.error(), name
+            assert pc is not None and pc.calls > 0 and not pc.error(), name
+            if name == "cp":
+                assert pc.calls > 8 * eng.model_config.n_layers
+        if seq_par and os.environ.get("AREAL_SP_OVERLAP", "1") == "1":  # pipelined linears: all four per layer
+            ov = comm.overlap(g.group("tp"))
+            assert ov is not None and ov.pc.calls > 8 * eng.model_config.n_layers and not ov.pc.error()
+        elif seq_par:
+            assert comm.overlap(g.group("tp")) is None and comm.peer(g.group("tp")).calls > 8 * eng.model_config.n_layers
     torch.save(dict(norms=norms, ev=ev, fw=fw, dpr=dpr), f"{out_path}.r{rank}")
     eng.destroy()
 
@@ -1024,8 +1032,9 @@ def test_two_rank_layouts_on_one_gpu_follow_the_single_process(tmp_path):
 def test_layouts_on_peer_memory_collectives_follow_the_single_process(tmp_path):
     """The same comparison with the trainer's collectives as kernels over peer-mapped memory: ZeRO-1 bucket
     reduce-scatters (during the backward, on a side stream) and parameter all-gathers, the Ulysses sequence<->head
-    exchange, and the sequence-parallel all-gather / reduce-scatter around tensor-parallel linears; staging slots of
-    1 MiB, so that large messages take several kernels. Every worker checks that its kernels ran and none timed out."""
+    exchange, and the sequence-parallel all-gather / reduce-scatter around tensor-parallel linears - pipelined chunk
+    by chunk with the GEMMs on a side stream, and as plain collectives; staging slots of 1 MiB, so that large
+    messages take several kernels. Every worker checks that its kernels ran and none timed out."""
     init = str(tmp_path / "init")
     _run_layout(1, dict(), False, None, init)
     ref_path = str(tmp_path / "ref")
@@ -1034,9 +1043,10 @@ def test_layouts_on_peer_memory_collectives_follow_the_single_process(tmp_path):
     for name, world, layout, sp in [("dp2", 2, dict(data_parallel_size=2), False),
                                     ("cp2", 2, dict(context_parallel_size=2), False),
                                     ("tp2sp", 2, dict(tensor_parallel_size=2), True),
+                                    ("tp2sp-unpipelined", 2, dict(tensor_parallel_size=2, _peer="plain"), True),
                                     ("dp2cp2", 4, dict(data_parallel_size=2, context_parallel_size=2), False)]:
         out = str(tmp_path / name)
-        _run_layout(world, dict(layout, _peer=True), sp, init, out)
+        _run_layout(world, dict(dict(_peer=True), **layout), sp, init, out)
         parts = [torch.load(f"{out}.r{r}", weights_only=True) for r in range(world)]
         dp = layout.get("data_parallel_size", 1)
         assert parts[0]["norms"] == pytest.approx(ref["norms"], rel=4e-2), (name, parts[0]["norms"], ref["norms"])

@@ -94,9 +94,45 @@ def _worker(rank, world, port, out_dir):
         want = torch.arange(1, n + 1).float().add(rep).repeat_interleave(16)
         assert torch.equal(y[:, 0, 0].float().cpu(), want), (rank, rep)
     assert not pc.error()
+    # sequence-parallel linears pipelined with their collective (an exchange object of their own, side stream)
+    from areal_vllm_amd.parallel.sp_overlap import SPOverlap, gather_linear, linear_scatter
+
+    pc2 = open_for(dist.group.WORLD, dev, 192 << 10)
+    ov = SPOverlap(pc2, chunks=3, min_rows=32)
+    before = pc2.calls  # the start-up self-check
+    t, H, Fc = 300, 64, 96
+    assert len(ov.plan(t, H * 2)) == 3
+    xs = _inputs(n, (t, H), 901, torch.bfloat16)
+    w1s = [w * 0.2 for w in _inputs(n, (Fc, H), 902, torch.bfloat16)]
+    w2s = [w * 0.2 for w in _inputs(n, (H, Fc), 903, torch.bfloat16)]
+    gs = _inputs(n, (t, H), 904, torch.float32)
+    x = xs[rank].to(dev).requires_grad_(True)
+    w1 = w1s[rank].to(dev).requires_grad_(True)
+    w2 = w2s[rank].to(dev).requires_grad_(True)
+    z = linear_scatter(gather_linear(x, w1, ov), w2, ov)
+    (z.float() * gs[rank].to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    X = torch.cat(xs).float().requires_grad_(True)
+    W1 = [w.float().requires_grad_(True) for w in w1s]
+    W2 = [w.float().requires_grad_(True) for w in w2s]
+    Z = sum((X @ a.t()).bfloat16().float() @ b.t() for a, b in zip(W1, W2))
+    (Z * torch.cat(gs)).sum().backward()
+    rows = slice(rank * t, (rank + 1) * t)
+
+    def close(got, want, what):
+        err = (got.float().cpu() - want).abs().max().item()
+        assert err <= 3e-2 * want.abs().max().item() + 1e-3, (what, rank, err, want.abs().max().item())
+
+    close(z, Z.detach()[rows], "forward")
+    close(x.grad, X.grad[rows], "dx")
+    close(w1.grad, W1[rank].grad, "dw1")
+    close(w2.grad, W2[rank].grad, "dw2")
+    assert not pc2.error()
+    assert pc2.calls - before == 4 * 3 + 3, pc2.calls  # four pipelined collectives + the re-gather for dW1
     torch.save(kept, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     pc.close()
+    pc2.close()
     dist.destroy_process_group()
 
 
