@@ -92,9 +92,10 @@ class ModelRunner:
         # Decode batches of FUSED_MIN_BATCH rows and more run the layer as seven launches (ops/decode_gemm.py);
         # smaller ones, and model variants its epilogues do not cover, take the library GEMMs.
         # (tensor-parallel shards included: the row-parallel projections then hand their summed slabs to the group's
-        # all-reduce ahead of the residual + norm kernel; mixture-of-experts layers keep the library path)
-        fusable = (not self.plain_family and cfg.n_experts == 0 and cfg.hidden_act == "silu"
-                   and cfg.hidden_size % 64 == 0 and (cfg.intermediate_size // model.tp_size) % 64 == 0
+        # all-reduce ahead of the residual + norm kernel; mixture-of-experts layers run their attention half this
+        # way and the routed experts through the grouped kernels)
+        fusable = (not self.plain_family and cfg.hidden_act == "silu" and cfg.hidden_size % 64 == 0
+                   and (cfg.n_experts > 0 or (cfg.intermediate_size // model.tp_size) % 64 == 0)
                    and cfg.head_dim % 16 == 0 and (self.hq * cfg.head_dim) % 64 == 0)
         if fused_decode is None:
             env = os.environ.get("AREAL_FUSED_DECODE", "1")  # "force": also on the CPU fallbacks of the kernels (tests)
@@ -425,6 +426,9 @@ class ModelRunner:
         fused either way."""
         if Bp in self._gate_up_choice:
             return self._gate_up_choice[Bp]
+        if self.cfg.n_experts > 0:  # routed experts: the grouped kernels, nothing to choose
+            self._gate_up_choice[Bp] = "experts"
+            return "experts"
         from ..ops import decode_gemm as dg
 
         has_plan = dg.swiglu_plan(Bp, self.cfg.intermediate_size // max(1, self.model.tp_size)) is not None
@@ -473,7 +477,8 @@ class ModelRunner:
         Per layer: qkv GEMM with bias + RoPE + KV-cache write in its epilogue (smaller batches: split-K slabs ->
         slab sum + bias + RoPE + KV-cache write) -> paged attention ->
         o GEMM (slabs) -> slab sum + residual + RMSNorm -> gate|up GEMM with SwiGLU epilogue -> down GEMM
-        (slabs) -> slab sum + residual + the NEXT layer's RMSNorm."""
+        (slabs) -> slab sum + residual + the NEXT layer's RMSNorm. Mixture-of-experts layers keep the attention
+        half and run router and experts through the grouped kernels, then residual + the next norm."""
         from ..ops import decode_gemm as dg
 
         cfg = self.cfg
@@ -511,6 +516,15 @@ class ModelRunner:
                                               workspace=st["ws"])
             slab = dg.dgemm(attn.view(Bp, hq * D), blk.attn.o, epilogue=dg.EPI_SLAB)
             x, residual = finish(slab, residual, blk.ln2)
+            nw = layers[li + 1].ln1 if li + 1 < len(layers) else self.model.norm
+            if gate_up_mode == "experts":
+                # router + permutation + grouped GEMMs + weighted combine; the sum joins the residual stream in the
+                # next norm's kernel
+                mixed = blk.mlp(x, None, self.model.ep_group)
+                if tp:
+                    self._tp_all_reduce(mixed)
+                x, residual = ops.rmsnorm(mixed, nw, eps, residual, gemma)
+                continue
             if gate_up_mode == "balanced":
                 act = dg.dgemm_swiglu_balanced(x, blk.mlp.gate_up)
             elif gate_up_mode == "tiled":
@@ -518,7 +532,6 @@ class ModelRunner:
             else:
                 act = ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)
             slab = dg.dgemm(act, blk.mlp.down, epilogue=dg.EPI_SLAB)
-            nw = layers[li + 1].ln1 if li + 1 < len(layers) else self.model.norm
             x, residual = finish(slab, residual, nw)
         return x
 

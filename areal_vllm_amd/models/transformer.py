@@ -367,6 +367,15 @@ class MoE(nn.Module):
         inv = torch.empty_like(order)
         inv[order] = torch.arange(order.numel(), device=order.device)
         xs = ops.moe_permute(x, order, inv, k)
+        if (cfg.moe_capacity_factor is None and not torch.is_grad_enabled() and not (ep_group is not None and self.ep_size > 1)
+                and ops.grouped_gemm_offsets_ok(xs, self.gate_up) and ops.grouped_gemm_offsets_ok(xs, self.down)):
+            # inference: the experts' row ranges stay on the device (the grouped kernels read them there), so the
+            # layer has no host synchronisation and can sit inside a captured decode graph
+            per_e = torch.zeros(E, dtype=torch.int32, device=x.device).scatter_add_(
+                0, flat_e, torch.ones_like(flat_e, dtype=torch.int32))
+            offsets = F.pad(torch.cumsum(per_e, 0, dtype=torch.int32), (1, 0))
+            h = ops.swiglu(ops.grouped_gemm_offsets(xs, self.gate_up, offsets))
+            return ops.moe_combine(ops.grouped_gemm_offsets(h, self.down, offsets), topv, order, inv)
         counts = torch.bincount(flat_e, minlength=E + 1)
         if cfg.moe_capacity_factor is not None:
             n_drop = int(counts[E])

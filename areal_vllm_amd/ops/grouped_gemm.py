@@ -168,6 +168,19 @@ def _prefer_library(n_rows: int, n_experts: int) -> bool:
     return n_experts <= LIBRARY_MAX_EXPERTS and n_rows >= LIBRARY_MIN_ROWS_PER_EXPERT * n_experts
 
 
+def grouped_gemm_offsets_ok(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """Whether `grouped_gemm_offsets` serves these operands."""
+    return _hip_ok(x, w) and x.shape[0] > 0
+
+
+def grouped_gemm_offsets(x: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor) -> torch.Tensor:
+    """Forward-only grouped GEMM whose expert row ranges live on the device: x [T, K] rows sorted by expert,
+    w [E, N, K], offsets int32 [E + 1] (offsets[e]..offsets[e + 1] = rows of expert e). The launch depends on shapes
+    only, so no host synchronisation is needed and the call can be captured into a graph."""
+    assert not torch.is_grad_enabled() or not (x.requires_grad or w.requires_grad)
+    return _launch(x.contiguous(), w, offsets)
+
+
 def grouped_gemm(x: torch.Tensor, w: torch.Tensor, counts: List[int]) -> torch.Tensor:
     """x [T, K] rows sorted by expert, w [E, N, K], counts[e] rows per expert (host ints, sum = T)."""
     if _hip_ok(x, w) and x.shape[0] > 0 and _prefer_library(x.shape[0], w.shape[0]):

@@ -658,7 +658,7 @@ def test_decoupled_server_process_with_disk_weight_updates(tmp_path, transport):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,name", [(64, "small"), (200, "small"), (330, "small"), (64, "tiny-qknorm"),
-                                    (200, "tiny-qknorm")])
+                                    (200, "tiny-qknorm"), (64, "tiny-moe"), (200, "tiny-moe")])
 def test_fused_decode_path_matches_library_path(B, name):
     """Decode steps through the fused layer path (decode GEMMs + slab row kernels, inside a captured graph)
     against the library-GEMM path on the same weights and KV cache: same greedy tokens except where the two
@@ -671,7 +671,9 @@ def test_fused_decode_path_matches_library_path(B, name):
     from areal_vllm_amd.ops.attention import PAGE_SIZE
 
     dev = torch.device("cuda", 0)
-    cfg = preset(name)  # tiny-qknorm: per-head q / k RMSNorm (Qwen3) inside the RoPE + cache-write row kernel
+    # tiny-qknorm: per-head q / k RMSNorm (Qwen3) inside the RoPE + cache-write row kernel; tiny-moe: routed experts
+    # behind the fused attention half
+    cfg = preset(name)
     model = Transformer(cfg, dtype=torch.bfloat16, device=dev)
     model.requires_grad_(False)
     model.eval()
