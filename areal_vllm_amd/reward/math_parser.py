@@ -250,6 +250,18 @@ def _to_sympy(text: str):
     )
 
     tf = standard_transformations + (implicit_multiplication_application, convert_xor)
+    if "\\" in text or "^" in text or "_" in text:
+        # anything with LaTeX markup goes through the LaTeX grammar first (sums, integrals, matrices, \log_b,
+        # \sin^2 x ... have no reading as plain expression text); calculus objects are evaluated so that
+        # "\int_0^1 x dx" and "1/2" compare equal
+        from ..evaluation.latex2sympy import try_latex2sympy
+
+        e = try_latex2sympy(text)
+        if e is not None and not isinstance(e, tuple):
+            try:
+                return e.doit() if hasattr(e, "doit") else e
+            except Exception:
+                return e
     try:
         return parse_expr(latex_to_expr_text(text), transformations=tf, evaluate=True)
     except Exception:
