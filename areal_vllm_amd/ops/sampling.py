@@ -5,11 +5,16 @@ step counter so captured graphs draw fresh noise on replay). CPU: PyTorch refere
 Counterparts: ``realhf/impl/model/utils/logits_warper.py:52-125,207-225`` and ``genstep`` in
 ``realhf/impl/model/nn/real_llm_generate.py:30-146``.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
 
 from . import _lib as L
+
+# unfiltered batches (no top-k / top-p) split every row over several workgroups; 0 keeps the one-workgroup-per-row
+# kernel for A/B timing
+SPLIT_UNFILTERED = os.environ.get("AREAL_SAMPLE_SPLIT", "1") != "0"
 
 
 class TokenCounts:
@@ -96,6 +101,22 @@ def sample(logits: torch.Tensor, temperature: Optional[torch.Tensor], top_k: Opt
         out_tokens = torch.empty(B, dtype=torch.int64, device=logits.device)
     if out_logprobs is None:
         out_logprobs = torch.empty(B, dtype=torch.float32, device=logits.device)
+    if top_k is None and top_p is None and SPLIT_UNFILTERED:
+        # no filtering anywhere in the batch: every row is reduced by several workgroups (same tokens as below)
+        lib = L.lib()
+        S = int(lib.areal_sample_splits(L.c_int(B)))
+        ws = torch.empty(B * S * 4, dtype=torch.float32, device=logits.device)
+        L.check(
+            lib.areal_sample_unfiltered(L.ptr(logits), L.c_int(L.dtype_flag(logits)), L.c_int(B), L.c_int(V),
+                                        L.c_int64(logits.stride(0)), L.ptr(temperature),
+                                        L.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), L.ptr(step),
+                                        L.c_int(int(bump_step)), L.ptr(out_tokens), L.ptr(out_logprobs), L.ptr(active),
+                                        L.ptr(counts.table if counts is not None else None),
+                                        L.c_int64(counts.ld if counts is not None else 0), L.ptr(count_slot),
+                                        L.ptr(freq_pen), L.ptr(pres_pen), L.ptr(ws), L.c_int(S), L.stream_ptr()),
+            "sample_unfiltered",
+        )
+        return out_tokens, out_logprobs
     L.check(
         L.lib().areal_sample(L.ptr(logits), L.c_int(L.dtype_flag(logits)), L.c_int(B), L.c_int(V),
                              L.c_int64(logits.stride(0)), L.ptr(temperature), L.ptr(top_k), L.ptr(top_p),

@@ -286,6 +286,190 @@ __global__ __launch_bounds__(1024) void sample_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Unfiltered sampling (no top-k / top-p anywhere in the batch) with every row split over `S` workgroups: one
+// 1024-thread workgroup per row leaves a 384-row decode batch with 1.5 workgroups per CU, each walking 152k entries
+// as a chain of dependent passes. Here S x B workgroups of 256 threads each reduce a slice of a row to
+// (max, sum-exp relative to it, best perturbed value, its index); a one-thread-per-row kernel merges the slices,
+// writes token and log-prob, bumps the token count and the step. The noise of entry i is the same Philox word as
+// in the one-workgroup kernel, so both draw the SAME token; the log-prob differs by summation order only.
+template <typename T>
+__global__ __launch_bounds__(256) void sample_partial_kernel(
+    const T* __restrict__ logits, int64_t ld, int V, const float* __restrict__ temperature, uint64_t seed,
+    const int64_t* __restrict__ step_ptr, const int* __restrict__ active, const int16_t* __restrict__ counts,
+    int64_t count_ld, const int* __restrict__ count_slot, const float* __restrict__ freq_pen,
+    const float* __restrict__ pres_pen, float* __restrict__ ws, int S) {
+  __shared__ float red[16];
+  __shared__ float redv[16];
+  __shared__ int redi[16];
+  const int row = blockIdx.y, s = blockIdx.x;
+  if (active && !active[row]) return;
+  const T* p = logits + (size_t)row * ld;
+  const float temp = temperature ? temperature[row] : 1.f;
+  const bool greedy = temp <= 0.f;
+  const uint64_t step = step_ptr ? (uint64_t)step_ptr[0] : 0;
+  const uint64_t ctr0 = step * (uint64_t)((V + 3) / 4);
+  const int V8 = (reinterpret_cast<uintptr_t>(p) & 15) == 0 ? (V & ~7) : 0;
+  const int slot = (counts && count_slot) ? count_slot[row] : -1;
+  Row<T> R;
+  R.p = p;
+  R.cnt = slot >= 0 ? counts + (size_t)slot * count_ld : nullptr;
+  R.freq = R.cnt && freq_pen ? freq_pen[row] : 0.f;
+  R.pres = R.cnt && pres_pen ? pres_pen[row] : 0.f;
+  R.inv_t = greedy ? 1.f : 1.f / temp;
+  const bool noise = !greedy;
+  const int chunks = V8 >> 3;
+  const int per = (chunks + S - 1) / S;
+  const int lo = min(chunks, s * per) * 8, hi = min(chunks, (s + 1) * per) * 8;
+  float mx = -INFINITY, se = 0.f;
+  ArgMax best;
+  best.v = -INFINITY;
+  best.i = 0x7fffffff;
+  constexpr int PF = 4;
+  for (int base = lo + threadIdx.x * 8; base < hi; base += 256 * 8 * PF) {
+    float zz[PF][8];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i8 = base + u * 256 * 8;
+      if (i8 < hi) R.z8(i8, zz[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i8 = base + u * 256 * 8;
+      if (i8 >= hi) break;
+      float* z = zz[u];
+      float m8 = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m8 = fmaxf(m8, z[j]);
+      if (m8 > mx) {
+        se *= __expf(mx - m8);
+        mx = m8;
+      }
+      if (mx > -INFINITY) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) se += __expf(z[j] - mx);
+      }
+      u32x4 r0, r1;
+      if (noise) {
+        r0 = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i8 >> 2));
+        r1 = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i8 >> 2) + 1);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ArgMax c;
+        c.v = noise ? z[j] + gumbel(j < 4 ? r0[j] : r1[j - 4]) : z[j];
+        c.i = i8 + j;
+        best = amax(best, c);
+      }
+    }
+  }
+  if (s == S - 1) {  // the entries behind the last whole group of 8 (or the whole row when it is not 16-byte aligned)
+    for (int i = V8 + threadIdx.x; i < V; i += 256) {
+      const float z = R.z1(i);
+      if (z > mx) {
+        se *= __expf(mx - z);
+        mx = z;
+      }
+      if (mx > -INFINITY) se += __expf(z - mx);
+      ArgMax c;
+      c.v = z;
+      c.i = i;
+      if (noise) c.v += gumbel(Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i >> 2))[i & 3]);
+      best = amax(best, c);
+    }
+  }
+  const float mx_all = block_max(mx, red);
+  se = block_sum(mx > -INFINITY ? se * __expf(mx - mx_all) : 0.f, red);
+  best = block_argmax(best, redv, redi);
+  if (threadIdx.x == 0) {
+    float* o = ws + ((size_t)row * S + s) * 4;
+    o[0] = mx_all;
+    o[1] = se;
+    o[2] = best.v;
+    o[3] = __int_as_float(best.i);
+  }
+}
+
+template <typename T>
+__global__ void sample_combine_kernel(const T* __restrict__ logits, int64_t ld, int V, int B,
+                                      const float* __restrict__ temperature, int64_t* __restrict__ step_ptr,
+                                      int bump_step, int64_t* __restrict__ out_tok, float* __restrict__ out_logp,
+                                      const int* __restrict__ active, int16_t* __restrict__ counts, int64_t count_ld,
+                                      const int* __restrict__ count_slot, const float* __restrict__ freq_pen,
+                                      const float* __restrict__ pres_pen, const float* __restrict__ ws, int S) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row == 0 && bump_step && step_ptr) step_ptr[0] += 1;  // every reader of the step ran in the previous kernel
+  if (row >= B) return;
+  if (active && !active[row]) {
+    out_tok[row] = 0;
+    if (out_logp) out_logp[row] = 0.f;
+    return;
+  }
+  float mx = -INFINITY;
+  for (int s = 0; s < S; ++s) mx = fmaxf(mx, ws[((size_t)row * S + s) * 4]);
+  float se = 0.f;
+  ArgMax best;
+  best.v = -INFINITY;
+  best.i = 0x7fffffff;
+  for (int s = 0; s < S; ++s) {
+    const float* o = ws + ((size_t)row * S + s) * 4;
+    if (o[0] > -INFINITY) se += o[1] * __expf(o[0] - mx);
+    ArgMax c;
+    c.v = o[2];
+    c.i = __float_as_int(o[3]);
+    best = amax(best, c);
+  }
+  const float temp = temperature ? temperature[row] : 1.f;
+  const int slot = (counts && count_slot) ? count_slot[row] : -1;
+  Row<T> R;
+  R.p = logits + (size_t)row * ld;
+  R.cnt = slot >= 0 ? counts + (size_t)slot * count_ld : nullptr;
+  R.freq = R.cnt && freq_pen ? freq_pen[row] : 0.f;
+  R.pres = R.cnt && pres_pen ? pres_pen[row] : 0.f;
+  R.inv_t = temp <= 0.f ? 1.f : 1.f / temp;
+  int tok = best.i;
+  if (tok < 0 || tok >= V) tok = 0;
+  out_tok[row] = tok;
+  if (out_logp) out_logp[row] = R.z1(tok) - (mx + __logf(se));
+  if (slot >= 0) {
+    int16_t* cnt = counts + (size_t)slot * count_ld;
+    if (cnt[tok] < 32767) cnt[tok] += 1;
+  }
+}
+
+// Workspace floats the split path needs for B rows, and the number of slices per row it will use.
+extern "C" int areal_sample_splits(int B) {
+  if (B >= 1024) return 1;
+  const int s = (1024 + B - 1) / B;
+  return s > 16 ? 16 : s;
+}
+
+extern "C" int areal_sample_unfiltered(const void* logits, int dtype, int B, int V, int64_t ld,
+                                       const float* temperature, uint64_t seed, int64_t* step_ptr, int bump_step,
+                                       int64_t* out_tok, float* out_logp, const int* active, int16_t* counts,
+                                       int64_t count_ld, const int* count_slot, const float* freq_pen,
+                                       const float* pres_pen, float* ws, int S, hipStream_t st) {
+  if (B == 0) return 0;
+  if (S < 1 || S > 64 || !ws) return (int)hipErrorInvalidValue;
+  if (counts && (count_ld % 8 != 0 || count_ld < V)) return (int)hipErrorInvalidValue;
+  const dim3 grid(S, B);
+  const int cb = (B + 63) / 64;
+  if (dtype == 0) {
+    hipLaunchKernelGGL(sample_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)logits, ld, V,
+                       temperature, seed, step_ptr, active, counts, count_ld, count_slot, freq_pen, pres_pen, ws, S);
+    hipLaunchKernelGGL(sample_combine_kernel<bf16_t>, dim3(cb), dim3(64), 0, st, (const bf16_t*)logits, ld, V, B,
+                       temperature, step_ptr, bump_step, out_tok, out_logp, active, counts, count_ld, count_slot,
+                       freq_pen, pres_pen, ws, S);
+  } else {
+    hipLaunchKernelGGL(sample_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, ld, V,
+                       temperature, seed, step_ptr, active, counts, count_ld, count_slot, freq_pen, pres_pen, ws, S);
+    hipLaunchKernelGGL(sample_combine_kernel<float>, dim3(cb), dim3(64), 0, st, (const float*)logits, ld, V, B,
+                       temperature, step_ptr, bump_step, out_tok, out_logp, active, counts, count_ld, count_slot,
+                       freq_pen, pres_pen, ws, S);
+  }
+  return (int)hipGetLastError();
+}
+
 __global__ void bump_step_kernel(int64_t* step_ptr) {
   if (threadIdx.x == 0 && blockIdx.x == 0) step_ptr[0] += 1;
 }

@@ -168,3 +168,47 @@ def test_tool_integrated_transcripts():
     text = out[0] if isinstance(out, tuple) else out
     assert str(text).strip() == "3"  # earlier successful cell re-run silently, failed cell skipped
     assert voting.last_output_of(t).startswith("Traceback") and not voting.execution_succeeded(voting.last_output_of(t))
+
+
+def test_prompt_styles_render_the_reference_templates():
+    """Expected strings: the reference's literal templates (evaluation/utils.py:78-245) filled in by hand."""
+    from areal_vllm_amd.evaluation.prompts import STYLES, build_prompt, style
+
+    q = "What is 1+1?"
+    boxed = "Please reason step by step, and put your final answer within \\boxed{}."
+    assert style("qwen25-math-cot").render(q) == (
+        f"<|im_start|>system\n{boxed}<|im_end|>\n<|im_start|>user\n{q}<|im_end|>\n<|im_start|>assistant\n")
+    assert style("qwen-boxed").render(q) == (
+        "<|im_start|>system\nYou are a helpful assistant.<|im_end|>\n"
+        f"<|im_start|>user\n{q}\n{boxed}<|im_end|>\n<|im_start|>assistant\n")
+    assert style("deepseek-math").render(q) == f"User: {q}\n{boxed}\n\nAssistant:"
+    assert style("r1-distilled-qwen").render(q) == f"<｜User｜>{q}\n{boxed}<｜Assistant｜><think>\n"
+    assert style("deepscaler-fix") is style("r1-distilled-qwen")
+    assert style("qwen3").render(q) == (
+        f"<|im_start|>user\n{q}\n{boxed}/no_think<|im_end|>\n<|im_start|>assistant\n<think></think>")
+    assert style("mistral").render(q) == f"[INST] {q}[/INST]"
+    assert style("kpmath").render(q) == (
+        'User: Please reason step by step and put your final answer at the end with "The answer is: ".\n\n'
+        f"{q}\n\nAssistant:")
+    assert style("mmiqc").render(q).startswith(
+        'Please solve the following problem and put your answer at the end with "The answer is: ".\n\n')
+    shots = [("2+2?", "4"), ("3+3?", "6")]
+    assert style("cot").render(q, shots) == (
+        "Question: 2+2?\nAnswer: 4\n\n\nQuestion: 3+3?\nAnswer: 6\n\n\nQuestion: What is 1+1?\nAnswer:")
+    # chat models take the examples inside ONE user turn
+    one_turn = style("qwen25-math-cot").render(q, shots)
+    assert one_turn.count("<|im_start|>user") == 1 and "2+2?\n4\n\n3+3?\n6\n\n" + q in one_turn
+    assert style("numina").render(q, shots[:1]) == "### Problem: 2+2?\n### Solution: 4\n\n### Problem: What is 1+1?\n### Solution:"
+    assert style("platypus_fs").render(q).startswith("Below is an instruction that describes a task.")
+    assert style("tora").render(q).startswith("Integrate step-by-step reasoning and Python code")
+    assert len(STYLES) >= 35
+    with pytest.raises(KeyError):
+        style("no-such-style")
+    ex = {"gsm8k": shots, "gaokao": [("q%d" % i, "A") for i in range(6)]}
+    row = {"question": q, "gt_ans": "2"}
+    assert build_prompt(row, "svamp", "cot", num_shots=1, examples=ex).startswith("Question: 2+2?\nAnswer: 4")
+    assert build_prompt(row, "svamp", "cot", num_shots=0, examples=ex) == "Question: What is 1+1?\nAnswer:"
+    # adapt_few_shot: five examples for the Chinese exam sets, but only for multiple-choice rows
+    assert build_prompt(row, "gaokao2024_I", "cot", 0, ex, adapt_few_shot=True) == "Question: What is 1+1?\nAnswer:"
+    mc = build_prompt({"question": q, "gt_ans": "B"}, "gaokao2024_I", "cot", 0, ex, adapt_few_shot=True)
+    assert mc.count("Question:") == 6

@@ -623,6 +623,39 @@ def test_sampler_penalties_and_inactive_rows(V):
         assert (tok != hot).all()
 
 
+@pytest.mark.parametrize("B,V", [(384, 151936), (7, 517), (1500, 1000), (33, 32003)])
+def test_split_row_sampler_draws_the_tokens_of_the_one_workgroup_kernel(B, V):
+    """Unfiltered batches are reduced by several workgroups per row: same noise per entry, so the same tokens; the
+    log-prob may differ by summation order only. Rows on an odd stride take the scalar-load path in both."""
+    from areal_vllm_amd.ops import sampling
+
+    torch.manual_seed(15)
+    for ld in (V, V + 3):
+        buf = (2 * torch.randn(B, ld, device=DEV)).bfloat16()
+        logits = buf[:, :V]
+        temp = torch.ones(B, device=DEV)
+        temp[::5] = 0.0  # some greedy rows
+        temp[1::7] = 0.7
+        active = torch.ones(B, dtype=torch.int32, device=DEV)
+        active[2::9] = 0
+        out = {}
+        for split in (True, False):
+            sampling.SPLIT_UNFILTERED = split
+            step = torch.full((1,), 5, dtype=torch.int64, device=DEV)
+            try:
+                out[split] = ops.sample(logits, temp, None, None, seed=77, step=step, active=active)
+            finally:
+                sampling.SPLIT_UNFILTERED = True
+            assert step.item() == 6
+        assert torch.equal(out[True][0], out[False][0])
+        assert torch.allclose(out[True][1], out[False][1], atol=1e-4)
+        live = active.bool()
+        ref = torch.log_softmax(logits.float() / temp.clamp(min=1e-9).unsqueeze(1).where(temp.unsqueeze(1) > 0, torch.ones_like(temp).unsqueeze(1)), -1)
+        got = ref.gather(1, out[True][0].unsqueeze(1)).squeeze(1)
+        assert torch.allclose(out[True][1][live], got[live], atol=2e-3)
+        assert (out[True][0][~live] == 0).all()
+
+
 def test_decode_advance_and_begin_kernels_match_their_cpu_twins():
     """Device bookkeeping of a multi-step decode plan (early exit on stop ids / budget, kill mask of a
     continuation plan) against the PyTorch twins the CPU engine runs."""
