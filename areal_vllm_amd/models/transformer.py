@@ -319,8 +319,12 @@ class MoE(nn.Module):
         aux = None
         if cfg.moe_z_loss_coef > 0 and self.training and n_valid > 0:
             aux = aux_scale * cfg.moe_z_loss_coef * torch.logsumexp(logits[:n_valid], -1).square().mean()
-        probs = torch.softmax(logits, -1)
-        if cfg.moe_routing_type == "sinkhorn":
+        plain = cfg.moe_routing_type in ("aux_loss", "none")
+        fused_route = plain and not torch.is_grad_enabled() and not self.training
+        probs = None if fused_route else torch.softmax(logits, -1)
+        if fused_route:  # scoring / serving pass: softmax, top-k and re-normalisation in one launch
+            topv, topi = ops.moe_topk(logits, k, cfg.norm_topk_prob)
+        elif cfg.moe_routing_type == "sinkhorn":
             act = torch.sigmoid(logits) if k == 1 else probs
             if self.training:
                 with torch.no_grad():
@@ -363,20 +367,18 @@ class MoE(nn.Module):
                 dropped[n_valid * k:] = True
             topv = topv.masked_fill(dropped.view(T, k), 0.0)
             flat_e = flat_e.masked_fill(dropped, E)
-        order = torch.argsort(flat_e, stable=True)  # expert-sorted position -> (token, choice) pair t*k + j
-        inv = torch.empty_like(order)
-        inv[order] = torch.arange(order.numel(), device=order.device)
-        xs = ops.moe_permute(x, order, inv, k)
+        # expert-sorted position -> (token, choice) pair t*k + j (stable), its inverse, the source row of every
+        # position and the experts' row ranges: one counting sort (``ops/moe.py::moe_sort``)
+        order, inv, src_row, offsets = ops.moe_sort(flat_e, E, k)
+        xs = ops.moe_permute(x, order, inv, k, src_row)
         if (cfg.moe_capacity_factor is None and not torch.is_grad_enabled() and not (ep_group is not None and self.ep_size > 1)
                 and ops.grouped_gemm_offsets_ok(xs, self.gate_up) and ops.grouped_gemm_offsets_ok(xs, self.down)):
             # inference: the experts' row ranges stay on the device (the grouped kernels read them there), so the
             # layer has no host synchronisation and can sit inside a captured decode graph
-            per_e = torch.zeros(E, dtype=torch.int32, device=x.device).scatter_add_(
-                0, flat_e, torch.ones_like(flat_e, dtype=torch.int32))
-            offsets = F.pad(torch.cumsum(per_e, 0, dtype=torch.int32), (1, 0))
+            offsets = offsets[:E + 1]
             h = ops.swiglu(ops.grouped_gemm_offsets(xs, self.gate_up, offsets))
             return ops.moe_combine(ops.grouped_gemm_offsets(h, self.down, offsets), topv, order, inv)
-        counts = torch.bincount(flat_e, minlength=E + 1)
+        counts = offsets[1:] - offsets[:-1]  # E experts + the bin of dropped pairs
         if cfg.moe_capacity_factor is not None:
             n_drop = int(counts[E])
         counts = counts[:E]

@@ -30,4 +30,4 @@ from . import train_gemm  # noqa: F401
 from .linear import embedding, linear  # noqa: F401
 from .decode_gemm import dgemm, splitk_residual_rmsnorm, splitk_rope_cache_write  # noqa: F401
 from .grouped_gemm import grouped_gemm, grouped_gemm_offsets, grouped_gemm_offsets_ok, grouped_gemm_ref  # noqa: F401
-from .moe import moe_combine, moe_permute  # noqa: F401
+from .moe import moe_combine, moe_permute, moe_sort, moe_topk  # noqa: F401

@@ -45,16 +45,16 @@ def _combine_rows(src: torch.Tensor, inv: torch.Tensor, w, T: int, k: int) -> to
 
 class _PermuteFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, order, inv, k):
+    def forward(ctx, x, order, inv, k, src_row=None):
         ctx.save_for_backward(inv)
         ctx.k = k
-        return _gather_rows(x, order // k)
+        return _gather_rows(x, order // k if src_row is None else src_row)
 
     @staticmethod
     def backward(ctx, dxs):
         (inv,) = ctx.saved_tensors
         k = ctx.k
-        return _combine_rows(dxs.contiguous(), inv, None, inv.numel() // k, k), None, None, None
+        return _combine_rows(dxs.contiguous(), inv, None, inv.numel() // k, k), None, None, None, None
 
 
 class _CombineFn(torch.autograd.Function):
@@ -85,9 +85,61 @@ class _CombineFn(torch.autograd.Function):
         return dys, (dw.to(ctx.w_dtype) if dw is not None else None), None, None
 
 
-def moe_permute(x: torch.Tensor, order: torch.Tensor, inv: torch.Tensor, k: int) -> torch.Tensor:
-    """x [T, H] -> rows in expert order [T*k, H] (row p = token order[p] // k)."""
-    return _PermuteFn.apply(x, order, inv, k)
+def moe_permute(x: torch.Tensor, order: torch.Tensor, inv: torch.Tensor, k: int, src_row=None) -> torch.Tensor:
+    """x [T, H] -> rows in expert order [T*k, H] (row p = token order[p] // k = src_row[p] when the sort handed
+    it out)."""
+    return _PermuteFn.apply(x, order, inv, k, src_row)
+
+
+def moe_topk(logits: torch.Tensor, k: int, norm: bool):
+    """Softmax over the experts and its k largest entries per token, without autograd (serving, scoring passes):
+    logits fp32 [T, E] -> (weights fp32 [T, k] - softmax probabilities, re-normalised over the k choices when
+    `norm` -, expert ids int64 [T, k]), choices in descending order of probability. One launch on the GPU."""
+    T, E = logits.shape
+    if not (L.use_hip(logits) and logits.dtype == torch.float32 and E <= 512 and k <= min(64, E)):
+        topv, topi = torch.topk(torch.softmax(logits.float(), -1), k, -1)
+        if norm:
+            topv = topv / topv.sum(-1, keepdim=True)
+        return topv, topi
+    logits = logits.contiguous()
+    topi = torch.empty(T, k, dtype=torch.int64, device=logits.device)
+    topv = torch.empty(T, k, dtype=torch.float32, device=logits.device)
+    L.check(L.lib().areal_moe_topk(L.ptr(logits), L.c_int64(T), L.c_int(E), L.c_int(k), L.c_int(int(bool(norm))),
+                                   L.ptr(topi), L.ptr(topv), L.stream_ptr()), "moe_topk")
+    return topv, topi
+
+
+def moe_sort(flat_e: torch.Tensor, n_experts: int, k: int):
+    """Expert-sorted order of the (token, choice) pairs: flat_e int64 [T*k] with ids 0 .. n_experts (id n_experts =
+    dropped pair, sorted last) -> (order [T*k], inv [T*k], src_row [T*k] = order // k, all int64; offsets int32
+    [n_experts + 2]: expert e owns positions offsets[e] .. offsets[e + 1], the dropped pairs sit from
+    offsets[n_experts] on). The order is the stable one (ties in pair order), what ``torch.argsort(stable=True)``
+    gives; on the GPU a counting sort in one launch (lists up to 4096 pairs) or three."""
+    n = flat_e.numel()
+    bins = n_experts + 1
+    if not (L.use_hip(flat_e) and flat_e.dtype == torch.int64 and bins <= 513):
+        order = torch.argsort(flat_e, stable=True)
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(n, device=flat_e.device)
+        counts = torch.bincount(flat_e, minlength=bins)[:bins]
+        offsets = torch.zeros(bins + 1, dtype=torch.int32, device=flat_e.device)
+        offsets[1:] = torch.cumsum(counts, 0)
+        return order, inv, order // k, offsets
+    flat_e = flat_e.contiguous()
+    lib = L.lib()
+    order = torch.empty(n, dtype=torch.int64, device=flat_e.device)
+    inv = torch.empty_like(order)
+    src_row = torch.empty_like(order)
+    offsets = torch.empty(bins + 1, dtype=torch.int32, device=flat_e.device)
+    items, ws = 1, None
+    if n > int(lib.areal_moe_sort_single_max()):
+        items = max(1, -(-n // (256 * 128)))  # at most 128 chunks
+        chunks = -(-n // (256 * items))
+        ws = torch.empty(chunks * bins, dtype=torch.int32, device=flat_e.device)
+    L.check(lib.areal_moe_sort(L.ptr(flat_e), L.c_int64(n), L.c_int(bins), L.c_int(k), L.ptr(order), L.ptr(inv),
+                               L.ptr(src_row), L.ptr(offsets), L.ptr(ws), L.c_int(items), L.stream_ptr()),
+            "moe_sort")
+    return order, inv, src_row, offsets
 
 
 def moe_combine(ys: torch.Tensor, w: torch.Tensor, order: torch.Tensor, inv: torch.Tensor) -> torch.Tensor:

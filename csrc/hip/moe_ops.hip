@@ -125,3 +125,223 @@ extern "C" int areal_moe_combine_dots(const void* g, const void* src, const int6
                      (const bf16_t*)src, inv, (bf16_t*)dw, T, k, H);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Routing: softmax + top-k of the router logits, and the expert-sorted order of the (token, choice) pairs, as a few
+// fixed launches. Done with library primitives the same work is a dozen dependent small kernels per layer (softmax,
+// top-k, sort, index-put, bincount, cumsum, floor-divide ...), about a third of a decode step of a 128-expert model.
+//
+//   topk : one wave per token. Lane l holds logits l, l + 64, ...; the wave takes max and sum-exp, then extracts the
+//          k largest logits one by one (value descending, index ascending on ties); weight = softmax probability of
+//          the choice, divided by the sum over the k choices when `norm`.
+//   sort : counting sort by expert, STABLE in the pair index (the order torch.argsort(stable=True) gives). The pairs
+//          are cut in chunks; `count` builds per-chunk histograms, `scan` turns them into chunk bases and the experts'
+//          row ranges, `place` ranks every pair among the same-expert pairs before it in its chunk. A list that fits
+//          one chunk takes one launch (histogram, scan and placement by one workgroup).
+// Expert ids may be 0 .. E: id E is the bin of dropped pairs, sorted behind every expert.
+constexpr int RT_MAX_PER_LANE = 8;  // experts <= 512
+
+__global__ __launch_bounds__(256) void moe_topk_kernel(const float* __restrict__ logits, int64_t T, int E, int k,
+                                                       int norm, int64_t* __restrict__ topi,
+                                                       float* __restrict__ topv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const float* row = logits + t * (int64_t)E;
+  float v[RT_MAX_PER_LANE];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < RT_MAX_PER_LANE; ++i) {
+    const int e = lane + 64 * i;
+    v[i] = e < E ? row[e] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+  mx = wave_max(mx);
+  float se = 0.f;
+#pragma unroll
+  for (int i = 0; i < RT_MAX_PER_LANE; ++i) se += v[i] > -INFINITY ? __expf(v[i] - mx) : 0.f;
+  se = wave_sum(se);
+  float mine_v = 0.f;  // lane j keeps choice j
+  int mine_i = 0;
+  float picked = 0.f;
+  for (int j = 0; j < k; ++j) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < RT_MAX_PER_LANE; ++i) {  // ascending expert index within the lane: first maximum wins
+      if (v[i] > bv) {
+        bv = v[i];
+        bi = lane + 64 * i;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    if (bi >= E) bi = 0;  // fewer finite logits than k: cannot happen for finite router outputs
+    const float p = __expf(bv - mx) / se;
+    picked += p;
+    if (lane == j) {
+      mine_v = p;
+      mine_i = bi;
+    }
+    if ((bi & 63) == lane) {
+#pragma unroll
+      for (int i = 0; i < RT_MAX_PER_LANE; ++i)
+        if (i == (bi >> 6)) v[i] = -INFINITY;
+    }
+  }
+  if (lane < k) {
+    topi[t * k + lane] = mine_i;
+    topv[t * k + lane] = norm ? mine_v / picked : mine_v;
+  }
+}
+
+constexpr int SORT_BINS_MAX = 513;
+
+// ranks of one 256-pair tile and their placement; `run[e]` = next free position of expert e, advanced per tile
+DEVINL void sort_place_tile(const int64_t* __restrict__ flat_e, int64_t n, int64_t base, int k, int* run, int* tile,
+                            int64_t* __restrict__ order, int64_t* __restrict__ inv, int64_t* __restrict__ src_row) {
+  const int i = threadIdx.x;
+  const int64_t p = base + i;
+  const int e = p < n ? (int)flat_e[p] : -1;
+  tile[i] = e;
+  __syncthreads();
+  int pos = -1;
+  if (e >= 0) {
+    int r = 0;
+    for (int j = 0; j < i; ++j) r += tile[j] == e ? 1 : 0;
+    pos = run[e] + r;
+  }
+  __syncthreads();
+  if (e >= 0) {
+    atomicAdd(&run[e], 1);  // counts only: the positions above were taken from the value before this tile
+    order[pos] = p;
+    inv[p] = pos;
+    src_row[pos] = p / k;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void moe_sort_count_kernel(const int64_t* __restrict__ flat_e, int64_t n, int bins,
+                                                             int items, int* __restrict__ counts) {
+  __shared__ int hist[SORT_BINS_MAX];
+  for (int e = threadIdx.x; e < bins; e += 256) hist[e] = 0;
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * items * 256;
+  for (int s = 0; s < items; ++s) {
+    const int64_t p = lo + (int64_t)s * 256 + threadIdx.x;
+    if (p < n) atomicAdd(&hist[(int)flat_e[p]], 1);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < bins; e += 256) counts[(size_t)blockIdx.x * bins + e] = hist[e];
+}
+
+// counts [C, bins] -> exclusive chunk bases in place, offsets [bins + 1]
+__global__ __launch_bounds__(1024) void moe_sort_scan_kernel(int* __restrict__ counts, int C, int bins,
+                                                             int* __restrict__ offsets) {
+  __shared__ int total[SORT_BINS_MAX];
+  for (int e = threadIdx.x; e < bins; e += 1024) {
+    int acc = 0;
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {  // four independent loads per round
+      const int a0 = counts[(size_t)c * bins + e], a1 = counts[(size_t)(c + 1) * bins + e];
+      const int a2 = counts[(size_t)(c + 2) * bins + e], a3 = counts[(size_t)(c + 3) * bins + e];
+      counts[(size_t)c * bins + e] = acc;
+      counts[(size_t)(c + 1) * bins + e] = acc + a0;
+      counts[(size_t)(c + 2) * bins + e] = acc + a0 + a1;
+      counts[(size_t)(c + 3) * bins + e] = acc + a0 + a1 + a2;
+      acc += a0 + a1 + a2 + a3;
+    }
+    for (; c < C; ++c) {
+      const int a = counts[(size_t)c * bins + e];
+      counts[(size_t)c * bins + e] = acc;
+      acc += a;
+    }
+    total[e] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int e = 0; e < bins; ++e) {
+      offsets[e] = acc;
+      acc += total[e];
+    }
+    offsets[bins] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void moe_sort_place_kernel(const int64_t* __restrict__ flat_e, int64_t n, int bins,
+                                                             int items, int k, const int* __restrict__ bases,
+                                                             const int* __restrict__ offsets,
+                                                             int64_t* __restrict__ order, int64_t* __restrict__ inv,
+                                                             int64_t* __restrict__ src_row) {
+  __shared__ int run[SORT_BINS_MAX];
+  __shared__ int tile[256];
+  for (int e = threadIdx.x; e < bins; e += 256) run[e] = offsets[e] + bases[(size_t)blockIdx.x * bins + e];
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * items * 256;
+  for (int s = 0; s < items; ++s) sort_place_tile(flat_e, n, lo + (int64_t)s * 256, k, run, tile, order, inv, src_row);
+}
+
+// the whole list in one workgroup
+__global__ __launch_bounds__(256) void moe_sort_single_kernel(const int64_t* __restrict__ flat_e, int64_t n, int bins,
+                                                              int k, int* __restrict__ offsets,
+                                                              int64_t* __restrict__ order, int64_t* __restrict__ inv,
+                                                              int64_t* __restrict__ src_row) {
+  __shared__ int run[SORT_BINS_MAX];
+  __shared__ int tile[256];
+  for (int e = threadIdx.x; e < bins; e += 256) run[e] = 0;
+  __syncthreads();
+  for (int64_t p = threadIdx.x; p < n; p += 256) atomicAdd(&run[(int)flat_e[p]], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int e = 0; e < bins; ++e) {
+      const int c = run[e];
+      run[e] = acc;
+      offsets[e] = acc;
+      acc += c;
+    }
+    offsets[bins] = acc;
+  }
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 256) sort_place_tile(flat_e, n, base, k, run, tile, order, inv, src_row);
+}
+
+extern "C" int areal_moe_topk(const float* logits, int64_t T, int E, int k, int norm, int64_t* topi, float* topv,
+                              hipStream_t st) {
+  if (T == 0) return 0;
+  if (E < 1 || E > 64 * RT_MAX_PER_LANE || k < 1 || k > 64 || k > E) return -1;
+  hipLaunchKernelGGL(moe_topk_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, logits, T, E, k, norm, topi,
+                     topv);
+  return (int)hipGetLastError();
+}
+
+// Largest list the one-workgroup sort takes; chunks of the three-launch form hold `items` tiles of 256 pairs.
+extern "C" int areal_moe_sort_single_max() { return 4096; }
+
+// flat_e [n] expert id per pair (0 .. E; E = dropped), bins = E + 1. offsets [bins + 1]. ws: C * bins ints with
+// C = ceil(n / (256 * items)) (unused when n <= areal_moe_sort_single_max()).
+extern "C" int areal_moe_sort(const int64_t* flat_e, int64_t n, int bins, int k, int64_t* order, int64_t* inv,
+                              int64_t* src_row, int* offsets, int* ws, int items, hipStream_t st) {
+  if (bins < 1 || bins > SORT_BINS_MAX || k < 1) return -1;
+  if (n <= areal_moe_sort_single_max()) {
+    hipLaunchKernelGGL(moe_sort_single_kernel, dim3(1), dim3(256), 0, st, flat_e, n, bins, k, offsets, order, inv,
+                       src_row);
+    return (int)hipGetLastError();
+  }
+  if (items < 1 || !ws) return -2;
+  const int64_t per = (int64_t)items * 256;
+  const int C = (int)((n + per - 1) / per);
+  hipLaunchKernelGGL(moe_sort_count_kernel, dim3(C), dim3(256), 0, st, flat_e, n, bins, items, ws);
+  hipLaunchKernelGGL(moe_sort_scan_kernel, dim3(1), dim3(1024), 0, st, ws, C, bins, offsets);
+  hipLaunchKernelGGL(moe_sort_place_kernel, dim3(C), dim3(256), 0, st, flat_e, n, bins, items, k, ws, offsets, order,
+                     inv, src_row);
+  return (int)hipGetLastError();
+}

@@ -656,6 +656,32 @@ def test_split_row_sampler_draws_the_tokens_of_the_one_workgroup_kernel(B, V):
         assert (out[True][0][~live] == 0).all()
 
 
+@pytest.mark.parametrize("T,E,k", [(1, 4, 2), (7, 60, 4), (256, 128, 8), (300, 8, 2), (5000, 128, 8), (33, 512, 1),
+                                   (40000, 64, 6)])
+def test_moe_routing_kernels_match_the_library_formulation(T, E, k):
+    """Fused softmax + top-k and the counting sort by expert against softmax / topk / stable argsort / bincount:
+    same experts, same (stable) order, same row ranges; weights to rounding."""
+    torch.manual_seed(16)
+    logits = 3 * torch.randn(T, E, device=DEV)
+    for norm in (True, False):
+        topv, topi = ops.moe_topk(logits, k, norm)
+        rv, ri = torch.topk(torch.softmax(logits, -1), k, -1)
+        if norm:
+            rv = rv / rv.sum(-1, keepdim=True)
+        assert torch.equal(topi, ri)
+        assert torch.allclose(topv, rv, rtol=2e-5, atol=1e-7)
+    flat_e = topi.reshape(-1).clone()
+    flat_e[::11] = E  # some pairs dropped: the bin behind every expert
+    order, inv, src_row, offsets = ops.moe_sort(flat_e, E, k)
+    want = torch.argsort(flat_e, stable=True)
+    assert torch.equal(order, want)
+    assert torch.equal(inv[order], torch.arange(T * k, device=DEV))
+    assert torch.equal(src_row, want // k)
+    counts = torch.bincount(flat_e, minlength=E + 1)
+    assert offsets.dtype == torch.int32 and offsets.numel() == E + 2
+    assert torch.equal(offsets[1:].long(), torch.cumsum(counts, 0)) and int(offsets[0]) == 0
+
+
 def test_decode_advance_and_begin_kernels_match_their_cpu_twins():
     """Device bookkeeping of a multi-step decode plan (early exit on stop ids / budget, kill mask of a
     continuation plan) against the PyTorch twins the CPU engine runs."""
