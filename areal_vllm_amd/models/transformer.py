@@ -315,15 +315,18 @@ class MoE(nn.Module):
         if cfg.moe_input_jitter_eps and self.training:  # the router alone sees the jittered input
             eps = float(cfg.moe_input_jitter_eps)
             xr = x * torch.empty_like(x).uniform_(1.0 - eps, 1.0 + eps)
-        logits = F.linear(xr, router).float()
+        raw = F.linear(xr, router)
+        plain = cfg.moe_routing_type in ("aux_loss", "none")
+        fused_route = plain and not torch.is_grad_enabled() and not self.training
+        logits = None if fused_route else raw.float()
         aux = None
         if cfg.moe_z_loss_coef > 0 and self.training and n_valid > 0:
             aux = aux_scale * cfg.moe_z_loss_coef * torch.logsumexp(logits[:n_valid], -1).square().mean()
-        plain = cfg.moe_routing_type in ("aux_loss", "none")
-        fused_route = plain and not torch.is_grad_enabled() and not self.training
         probs = None if fused_route else torch.softmax(logits, -1)
-        if fused_route:  # scoring / serving pass: softmax, top-k and re-normalisation in one launch
-            topv, topi = ops.moe_topk(logits, k, cfg.norm_topk_prob)
+        if fused_route:
+            # scoring / serving pass: softmax (fp32 arithmetic on the projection's output), top-k and
+            # re-normalisation in one launch; weights in the dtype the combine multiplies in
+            topv, topi = ops.moe_topk(raw, k, cfg.norm_topk_prob, out_dtype=x.dtype)
         elif cfg.moe_routing_type == "sinkhorn":
             act = torch.sigmoid(logits) if k == 1 else probs
             if self.training:

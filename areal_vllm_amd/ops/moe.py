@@ -91,21 +91,25 @@ def moe_permute(x: torch.Tensor, order: torch.Tensor, inv: torch.Tensor, k: int,
     return _PermuteFn.apply(x, order, inv, k, src_row)
 
 
-def moe_topk(logits: torch.Tensor, k: int, norm: bool):
+def moe_topk(logits: torch.Tensor, k: int, norm: bool, out_dtype=torch.float32):
     """Softmax over the experts and its k largest entries per token, without autograd (serving, scoring passes):
-    logits fp32 [T, E] -> (weights fp32 [T, k] - softmax probabilities, re-normalised over the k choices when
-    `norm` -, expert ids int64 [T, k]), choices in descending order of probability. One launch on the GPU."""
+    logits [T, E] fp32 or bf16 (the arithmetic is fp32 either way) -> (weights [T, k] in `out_dtype` - softmax
+    probabilities, re-normalised over the k choices when `norm` -, expert ids int64 [T, k]), choices in descending
+    order of probability. One launch on the GPU."""
     T, E = logits.shape
-    if not (L.use_hip(logits) and logits.dtype == torch.float32 and E <= 512 and k <= min(64, E)):
+    if not (L.use_hip(logits) and logits.dtype in (torch.float32, torch.bfloat16) and E <= 512 and k <= min(64, E)
+            and out_dtype in (torch.float32, torch.bfloat16)):
         topv, topi = torch.topk(torch.softmax(logits.float(), -1), k, -1)
         if norm:
             topv = topv / topv.sum(-1, keepdim=True)
-        return topv, topi
+        return topv.to(out_dtype), topi
     logits = logits.contiguous()
     topi = torch.empty(T, k, dtype=torch.int64, device=logits.device)
-    topv = torch.empty(T, k, dtype=torch.float32, device=logits.device)
-    L.check(L.lib().areal_moe_topk(L.ptr(logits), L.c_int64(T), L.c_int(E), L.c_int(k), L.c_int(int(bool(norm))),
-                                   L.ptr(topi), L.ptr(topv), L.stream_ptr()), "moe_topk")
+    topv = torch.empty(T, k, dtype=out_dtype, device=logits.device)
+    f32 = out_dtype == torch.float32
+    L.check(L.lib().areal_moe_topk(L.ptr(logits), L.c_int(L.dtype_flag(logits)), L.c_int64(T), L.c_int(E), L.c_int(k),
+                                   L.c_int(int(bool(norm))), L.ptr(topi), L.ptr(topv) if f32 else None,
+                                   None if f32 else L.ptr(topv), L.stream_ptr()), "moe_topk")
     return topv, topi
 
 
@@ -114,7 +118,7 @@ def moe_sort(flat_e: torch.Tensor, n_experts: int, k: int):
     dropped pair, sorted last) -> (order [T*k], inv [T*k], src_row [T*k] = order // k, all int64; offsets int32
     [n_experts + 2]: expert e owns positions offsets[e] .. offsets[e + 1], the dropped pairs sit from
     offsets[n_experts] on). The order is the stable one (ties in pair order), what ``torch.argsort(stable=True)``
-    gives; on the GPU a counting sort in one launch (lists up to 4096 pairs) or three."""
+    gives; on the GPU a counting sort in one launch (lists of a few thousand pairs: a decode batch) or three."""
     n = flat_e.numel()
     bins = n_experts + 1
     if not (L.use_hip(flat_e) and flat_e.dtype == torch.int64 and bins <= 513):
@@ -132,7 +136,7 @@ def moe_sort(flat_e: torch.Tensor, n_experts: int, k: int):
     src_row = torch.empty_like(order)
     offsets = torch.empty(bins + 1, dtype=torch.int32, device=flat_e.device)
     items, ws = 1, None
-    if n > int(lib.areal_moe_sort_single_max()):
+    if not int(lib.areal_moe_sort_single(L.c_int64(n), L.c_int(bins))):
         items = max(1, -(-n // (256 * 128)))  # at most 128 chunks
         chunks = -(-n // (256 * items))
         ws = torch.empty(chunks * bins, dtype=torch.int32, device=flat_e.device)

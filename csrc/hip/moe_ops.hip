@@ -141,25 +141,26 @@ extern "C" int areal_moe_combine_dots(const void* g, const void* src, const int6
 // Expert ids may be 0 .. E: id E is the bin of dropped pairs, sorted behind every expert.
 constexpr int RT_MAX_PER_LANE = 8;  // experts <= 512
 
-__global__ __launch_bounds__(256) void moe_topk_kernel(const float* __restrict__ logits, int64_t T, int E, int k,
+template <typename TIN, int PER_LANE>
+__global__ __launch_bounds__(256) void moe_topk_kernel(const TIN* __restrict__ logits, int64_t T, int E, int k,
                                                        int norm, int64_t* __restrict__ topi,
-                                                       float* __restrict__ topv) {
+                                                       float* __restrict__ topv, bf16_t* __restrict__ topv_bf) {
   const int lane = threadIdx.x & 63;
   const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= T) return;
-  const float* row = logits + t * (int64_t)E;
-  float v[RT_MAX_PER_LANE];
+  const TIN* row = logits + t * (int64_t)E;
+  float v[PER_LANE];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < RT_MAX_PER_LANE; ++i) {
+  for (int i = 0; i < PER_LANE; ++i) {
     const int e = lane + 64 * i;
-    v[i] = e < E ? row[e] : -INFINITY;
+    v[i] = e < E ? (float)row[e] : -INFINITY;
     mx = fmaxf(mx, v[i]);
   }
   mx = wave_max(mx);
   float se = 0.f;
 #pragma unroll
-  for (int i = 0; i < RT_MAX_PER_LANE; ++i) se += v[i] > -INFINITY ? __expf(v[i] - mx) : 0.f;
+  for (int i = 0; i < PER_LANE; ++i) se += v[i] > -INFINITY ? __expf(v[i] - mx) : 0.f;
   se = wave_sum(se);
   float mine_v = 0.f;  // lane j keeps choice j
   int mine_i = 0;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void moe_topk_kernel(const float* __restrict__
     float bv = -INFINITY;
     int bi = 0x7fffffff;
 #pragma unroll
-    for (int i = 0; i < RT_MAX_PER_LANE; ++i) {  // ascending expert index within the lane: first maximum wins
+    for (int i = 0; i < PER_LANE; ++i) {  // ascending expert index within the lane: first maximum wins
       if (v[i] > bv) {
         bv = v[i];
         bi = lane + 64 * i;
@@ -192,13 +193,15 @@ __global__ __launch_bounds__(256) void moe_topk_kernel(const float* __restrict__
     }
     if ((bi & 63) == lane) {
 #pragma unroll
-      for (int i = 0; i < RT_MAX_PER_LANE; ++i)
+      for (int i = 0; i < PER_LANE; ++i)
         if (i == (bi >> 6)) v[i] = -INFINITY;
     }
   }
   if (lane < k) {
     topi[t * k + lane] = mine_i;
-    topv[t * k + lane] = norm ? mine_v / picked : mine_v;
+    const float w = norm ? mine_v / picked : mine_v;
+    if (topv) topv[t * k + lane] = w;
+    if (topv_bf) topv_bf[t * k + lane] = f2bf(w);
   }
 }
 
@@ -289,50 +292,119 @@ __global__ __launch_bounds__(256) void moe_sort_place_kernel(const int64_t* __re
   for (int s = 0; s < items; ++s) sort_place_tile(flat_e, n, lo + (int64_t)s * 256, k, run, tile, order, inv, src_row);
 }
 
-// the whole list in one workgroup
-__global__ __launch_bounds__(256) void moe_sort_single_kernel(const int64_t* __restrict__ flat_e, int64_t n, int bins,
-                                                              int k, int* __restrict__ offsets,
-                                                              int64_t* __restrict__ order, int64_t* __restrict__ inv,
-                                                              int64_t* __restrict__ src_row) {
-  __shared__ int run[SORT_BINS_MAX];
-  __shared__ int tile[256];
-  for (int e = threadIdx.x; e < bins; e += 256) run[e] = 0;
+// rank of every lane among the lanes BEFORE it that hold the same value (64 scalar broadcasts, no LDS)
+DEVINL int wave_rank_of_equal(int e, int lane) {
+  int r = 0;
+#pragma unroll
+  for (int j = 0; j < 64; ++j) {
+    const int ej = __builtin_amdgcn_readlane(e, j);
+    r += (ej == e && j < lane) ? 1 : 0;
+  }
+  return r;
+}
+
+// The whole list in one workgroup of 16 waves: the list is cut in 64-pair slices; every wave histograms its slices
+// into LDS (slice x bin), one thread per bin turns the slice counts into slice bases, the bins are scanned, and
+// every wave places its slices (rank inside a slice by scalar broadcasts). `table` holds slices x bins ints.
+__global__ __launch_bounds__(1024) void moe_sort_single_kernel(const int64_t* __restrict__ flat_e, int64_t n,
+                                                               int bins, int k, int* __restrict__ offsets,
+                                                               int64_t* __restrict__ order, int64_t* __restrict__ inv,
+                                                               int64_t* __restrict__ src_row) {
+  extern __shared__ int table[];  // [slices][bins], then totals [bins]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slices = (int)((n + 63) >> 6);
+  int* total = table + slices * bins;
+  for (int i = threadIdx.x; i < slices * bins + bins; i += 1024) table[i] = 0;
   __syncthreads();
-  for (int64_t p = threadIdx.x; p < n; p += 256) atomicAdd(&run[(int)flat_e[p]], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int e = 0; e < bins; ++e) {
-      const int c = run[e];
-      run[e] = acc;
-      offsets[e] = acc;
-      acc += c;
-    }
-    offsets[bins] = acc;
+  for (int s = wave; s < slices; s += 16) {
+    const int64_t p = (int64_t)s * 64 + lane;
+    if (p < n) atomicAdd(&table[s * bins + (int)flat_e[p]], 1);
   }
   __syncthreads();
-  for (int64_t base = 0; base < n; base += 256) sort_place_tile(flat_e, n, base, k, run, tile, order, inv, src_row);
+  for (int e = threadIdx.x; e < bins; e += 1024) {
+    int acc = 0;
+    for (int s = 0; s < slices; ++s) {
+      const int c = table[s * bins + e];
+      table[s * bins + e] = acc;
+      acc += c;
+    }
+    total[e] = acc;
+  }
+  __syncthreads();
+  if (wave == 0) {  // exclusive scan of the bin totals, 64 bins per round
+    int carry = 0;
+    for (int b0 = 0; b0 < bins; b0 += 64) {
+      const int e = b0 + lane;
+      const int c = e < bins ? total[e] : 0;
+      int x = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+      if (e < bins) {
+        total[e] = carry + x - c;
+        offsets[e] = carry + x - c;
+      }
+      carry += __shfl(x, 63, 64);
+    }
+    if (lane == 0) offsets[bins] = carry;
+  }
+  __syncthreads();
+  for (int s = wave; s < slices; s += 16) {
+    const int64_t p = (int64_t)s * 64 + lane;
+    const int e = p < n ? (int)flat_e[p] : -1 - lane;  // idle lanes: distinct values nobody matches
+    const int r = wave_rank_of_equal(e, lane);
+    if (p < n) {
+      const int pos = total[e] + table[s * bins + e] + r;
+      order[pos] = p;
+      inv[p] = pos;
+      src_row[pos] = p / k;
+    }
+  }
 }
 
-extern "C" int areal_moe_topk(const float* logits, int64_t T, int E, int k, int norm, int64_t* topi, float* topv,
-                              hipStream_t st) {
+template <typename TIN>
+static int topk_launch(const TIN* logits, int64_t T, int E, int k, int norm, int64_t* topi, float* topv,
+                       bf16_t* topv_bf, hipStream_t st) {
+  const dim3 grid((unsigned)((T + 3) / 4)), block(256);
+#define TOPK_CASE(P) \
+  if (E <= 64 * P) { \
+    hipLaunchKernelGGL((moe_topk_kernel<TIN, P>), grid, block, 0, st, logits, T, E, k, norm, topi, topv, topv_bf); \
+    return (int)hipGetLastError(); \
+  }
+  TOPK_CASE(1) TOPK_CASE(2) TOPK_CASE(4) TOPK_CASE(8)
+#undef TOPK_CASE
+  return -1;
+}
+
+// logits [T, E] fp32 (dtype 1) or bf16 (dtype 0); weights are written as fp32 (topv), bf16 (topv_bf) or both.
+extern "C" int areal_moe_topk(const void* logits, int dtype, int64_t T, int E, int k, int norm, int64_t* topi,
+                              float* topv, void* topv_bf, hipStream_t st) {
   if (T == 0) return 0;
   if (E < 1 || E > 64 * RT_MAX_PER_LANE || k < 1 || k > 64 || k > E) return -1;
-  hipLaunchKernelGGL(moe_topk_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, st, logits, T, E, k, norm, topi,
-                     topv);
-  return (int)hipGetLastError();
+  if (dtype == 0) return topk_launch((const bf16_t*)logits, T, E, k, norm, topi, topv, (bf16_t*)topv_bf, st);
+  return topk_launch((const float*)logits, T, E, k, norm, topi, topv, (bf16_t*)topv_bf, st);
 }
 
-// Largest list the one-workgroup sort takes; chunks of the three-launch form hold `items` tiles of 256 pairs.
-extern "C" int areal_moe_sort_single_max() { return 4096; }
+// Largest list the one-workgroup sort takes (its slice x bin table has to fit 64 KiB of LDS for every bin count up
+// to the maximum); chunks of the three-launch form hold `items` tiles of 256 pairs.
+static bool sort_single_fits(int64_t n, int bins) {
+  const int64_t slices = (n + 63) / 64;
+  return n <= 8192 && (slices * bins + bins) * 4 <= 64 * 1024;
+}
+
+// 1 when a list of n pairs over `bins` bins is sorted by the one-workgroup kernel (no workspace needed)
+extern "C" int areal_moe_sort_single(int64_t n, int bins) { return sort_single_fits(n, bins) ? 1 : 0; }
 
 // flat_e [n] expert id per pair (0 .. E; E = dropped), bins = E + 1. offsets [bins + 1]. ws: C * bins ints with
-// C = ceil(n / (256 * items)) (unused when n <= areal_moe_sort_single_max()).
+// C = ceil(n / (256 * items)) (unused when areal_moe_sort_single(n, bins)).
 extern "C" int areal_moe_sort(const int64_t* flat_e, int64_t n, int bins, int k, int64_t* order, int64_t* inv,
                               int64_t* src_row, int* offsets, int* ws, int items, hipStream_t st) {
   if (bins < 1 || bins > SORT_BINS_MAX || k < 1) return -1;
-  if (n <= areal_moe_sort_single_max()) {
-    hipLaunchKernelGGL(moe_sort_single_kernel, dim3(1), dim3(256), 0, st, flat_e, n, bins, k, offsets, order, inv,
+  if (sort_single_fits(n, bins)) {
+    const size_t lds = (size_t)(((n + 63) / 64) * bins + bins) * 4;
+    hipLaunchKernelGGL(moe_sort_single_kernel, dim3(1), dim3(1024), lds, st, flat_e, n, bins, k, offsets, order, inv,
                        src_row);
     return (int)hipGetLastError();
   }

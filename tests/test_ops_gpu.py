@@ -670,6 +670,16 @@ def test_moe_routing_kernels_match_the_library_formulation(T, E, k):
             rv = rv / rv.sum(-1, keepdim=True)
         assert torch.equal(topi, ri)
         assert torch.allclose(topv, rv, rtol=2e-5, atol=1e-7)
+        # bf16 logits in (read as fp32 inside), bf16 weights out (rounded once, at the end)
+        lb = logits.bfloat16()
+        bv, bi = ops.moe_topk(lb, k, norm, out_dtype=torch.bfloat16)
+        rv2, ri2 = torch.topk(torch.softmax(lb.float(), -1), k, -1)
+        if norm:
+            rv2 = rv2 / rv2.sum(-1, keepdim=True)
+        assert bv.dtype == torch.bfloat16
+        assert torch.allclose(bv.float(), rv2.bfloat16().float(), rtol=8e-3, atol=1e-6)
+        tie_free = (rv2[:, :-1] != rv2[:, 1:]).all(-1) if k > 1 else torch.ones(T, dtype=torch.bool, device=DEV)
+        assert torch.equal(bi[tie_free], ri2[tie_free])
     flat_e = topi.reshape(-1).clone()
     flat_e[::11] = E  # some pairs dropped: the bin behind every expert
     order, inv, src_row, offsets = ops.moe_sort(flat_e, E, k)
