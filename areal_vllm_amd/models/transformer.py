@@ -381,7 +381,7 @@ class MoE(nn.Module):
             offsets = offsets[:E + 1]
             h = ops.swiglu(ops.grouped_gemm_offsets(xs, self.gate_up, offsets))
             return ops.moe_combine(ops.grouped_gemm_offsets(h, self.down, offsets), topv, order, inv)
-        counts = offsets[1:] - offsets[:-1]  # E experts + the bin of dropped pairs
+        counts = (offsets[1:] - offsets[:-1]).long()  # E experts + the bin of dropped pairs
         if cfg.moe_capacity_factor is not None:
             n_drop = int(counts[E])
         counts = counts[:E]
