@@ -161,19 +161,48 @@ __global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void paged_decode_kernel(
   }
 }
 
-// Combine split partials: grid (B * Hq), block D threads.
+// Combine split partials: grid (B * Hq), block D threads. The (max, sum) pairs of the splits are fetched by one
+// parallel load into LDS and the partial outputs four splits at a time: a loop of one dependent load per split is a
+// chain of memory round trips (16 splits at a batch of 8 rows: 7.5 us for a few KB).
 __global__ void paged_decode_reduce_kernel(const float* __restrict__ part_o,
                                            const float* __restrict__ part_ml,
                                            bf16_t* __restrict__ out, int nsplit, int D) {
+  constexpr int MAXS = 256;
+  __shared__ float sm[MAXS], sl[MAXS];
   const int bh = blockIdx.x, d = threadIdx.x;
+  const bool staged = nsplit <= MAXS;
+  if (staged) {
+    for (int s = d; s < nsplit; s += blockDim.x) {
+      const float2 ml = *reinterpret_cast<const float2*>(part_ml + ((size_t)bh * nsplit + s) * 2);
+      sm[s] = ml.x;
+      sl[s] = ml.y;
+    }
+    __syncthreads();
+  }
+  auto M = [&](int s) { return staged ? sm[s] : part_ml[((size_t)bh * nsplit + s) * 2]; };
+  auto Lsum = [&](int s) { return staged ? sl[s] : part_ml[((size_t)bh * nsplit + s) * 2 + 1]; };
   float mm = -INFINITY;
-  for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, part_ml[((size_t)bh * nsplit + s) * 2]);
+  for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, M(s));
   float acc = 0.f, ll = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float ms = part_ml[((size_t)bh * nsplit + s) * 2];
+  const float* po = part_o + (size_t)bh * nsplit * D + d;
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    const float o0 = po[(size_t)s * D], o1 = po[(size_t)(s + 1) * D];
+    const float o2 = po[(size_t)(s + 2) * D], o3 = po[(size_t)(s + 3) * D];
+    const float os[4] = {o0, o1, o2, o3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ms = M(s + j);
+      const float f = (ms == -INFINITY) ? 0.f : fast_exp2(ms - mm);
+      acc += os[j] * f;
+      ll += Lsum(s + j) * f;
+    }
+  }
+  for (; s < nsplit; ++s) {
+    const float ms = M(s);
     const float f = (ms == -INFINITY) ? 0.f : fast_exp2(ms - mm);
-    acc += part_o[((size_t)bh * nsplit + s) * D + d] * f;
-    ll += part_ml[((size_t)bh * nsplit + s) * 2 + 1] * f;
+    acc += po[(size_t)s * D] * f;
+    ll += Lsum(s) * f;
   }
   out[(size_t)bh * D + d] = f2bf(ll > 0.f ? acc / ll : 0.f);
 }
