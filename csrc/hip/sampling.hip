@@ -9,8 +9,10 @@
 //  * unfiltered (top_k >= V and top_p >= 1): Gumbel-max over z = logit / T, in the same single pass
 //    over the row (16-byte loads) that accumulates the running max / sum-exp for the log-prob.
 //  * filtered: thresholds for top-k (k-th largest z) and top-p (smallest set whose mass
-//    reaches top_p of the top-k mass) are found by bisection on z, then Gumbel-max runs over
-//    the surviving entries. No sort, no [B, V] temporaries.
+//    reaches top_p of the top-k mass) are found by bisection on z - over the whole row only until
+//    the bracket holds a few thousand entries, then among those entries in LDS (fixed-point sums:
+//    order-independent) -, then Gumbel-max runs over the surviving entries. No sort, no [B, V]
+//    temporaries.
 //  * frequency / presence penalties: a request that asks for them owns a row of a token-count table
 //    (`counts`, int16 [slots, count_ld]); its logits become logit - freq * count - pres * (count > 0)
 //    before the temperature, in every pass, and the kernel bumps the count of the token it draws.
@@ -98,18 +100,104 @@ struct Row {
 };
 
 // f(i, z_i) over one row: vector loads over [0, V8), scalar loads over the tail [V8, V)
+// (a thread's chunks are fetched four at a time: with one load in flight a pass over a 152k-entry row is a chain of
+// ~19 memory round trips per thread, and the filtered path makes dozens of passes)
 template <typename T, typename F>
 DEVINL void for_each_z(const Row<T>& r, int V, int V8, F f) {
-  for (int i8 = threadIdx.x * 8; i8 < V8; i8 += blockDim.x * 8) {
-    float z[8];
-    r.z8(i8, z);
+  constexpr int PF = 4;
+  const int stride = blockDim.x * 8;
+  for (int base = threadIdx.x * 8; base < V8; base += stride * PF) {
+    float zz[PF][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f(i8 + j, z[j]);
+    for (int u = 0; u < PF; ++u)
+      if (base + u * stride < V8) r.z8(base + u * stride, zz[u]);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i8 = base + u * stride;
+      if (i8 >= V8) break;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f(i8 + j, zz[u][j]);
+    }
   }
   for (int i = V8 + threadIdx.x; i < V; i += blockDim.x) f(i, r.z1(i));
 }
 
 DEVINL float gumbel(uint32_t bits) { return -__logf(-__logf(u32_to_unit(bits) * 0.99999994f)); }
+
+DEVINL unsigned long long block_sum_u64(unsigned long long v, unsigned long long* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  unsigned long long t = lane < nw ? red[lane] : 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+  return t;
+}
+
+constexpr int THR_CAP = 8192;  // candidates kept in LDS once a threshold's bracket holds no more than that
+constexpr float THR_FIX = 1099511627776.f;  // 2^40: fixed-point scale of exp(z - max) in the LDS phase
+
+// Largest t in [lo, hi] with F(t) >= target, F(t) = number (MASS = false) or softmax mass relative to exp(-mx)
+// (MASS = true) of the entries z >= t, to the resolution of 32 halvings of [lo, hi] - the threshold of top-k
+// (target k) and of top-p (target p x mass of the allowed entries; lo = the top-k threshold, so that only allowed
+// entries count). The halvings run over the whole row only until the bracket [lo, hi) holds at most THR_CAP
+// entries; those are copied into LDS and the remaining halvings run there. Sums of the LDS phase are taken in fixed
+// point: they do not depend on the order in which the candidates were appended, so replays and the ranks of a
+// tensor-parallel group agree bit for bit.
+template <bool MASS, typename T>
+DEVINL float find_threshold(const Row<T>& R, int V, int V8, float lo, float hi, float target, float mx, float* red,
+                            unsigned long long* red64, float* buf, int* buf_n) {
+  float c_lo = (float)V, c_hi = 0.f, F_hi = 0.f;
+  bool hi_moved = false;
+  int it = 0;
+  for (; it < 32 && c_lo - c_hi > (float)THR_CAP; ++it) {
+    const float mid = 0.5f * (lo + hi);
+    float cm = 0.f, fm = 0.f;
+    for_each_z(R, V, V8, [&](int, float z) {
+      if (z >= mid) {
+        cm += 1.f;
+        if (MASS) fm += __expf(z - mx);
+      }
+    });
+    cm = block_sum(cm, red);
+    const float Fm = MASS ? block_sum(fm, red) : cm;
+    if (Fm >= target) {
+      lo = mid;
+      c_lo = cm;
+    } else {
+      hi = mid;
+      c_hi = cm;
+      F_hi = Fm;
+      hi_moved = true;
+    }
+  }
+  if (it == 32) return lo;
+  if (threadIdx.x == 0) *buf_n = 0;
+  __syncthreads();
+  for_each_z(R, V, V8, [&](int, float z) {
+    if (z >= lo && (!hi_moved || z < hi)) {
+      const int pos = atomicAdd(buf_n, 1);
+      if (pos < THR_CAP) buf[pos] = z;
+    }
+  });
+  __syncthreads();
+  const int n = min(*buf_n, THR_CAP);
+  for (; it < 32; ++it) {
+    const float mid = 0.5f * (lo + hi);
+    unsigned long long q = 0ull;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const float z = buf[j];
+      if (z >= mid) q += MASS ? (unsigned long long)(__expf(z - mx) * THR_FIX) : 1ull;
+    }
+    q = block_sum_u64(q, red64);
+    const float Fm = F_hi + (MASS ? (float)q * (1.f / THR_FIX) : (float)q);
+    if (Fm >= target) lo = mid; else hi = mid;
+  }
+  return lo;
+}
 
 template <typename T>
 __global__ __launch_bounds__(1024) void sample_kernel(
@@ -122,6 +210,9 @@ __global__ __launch_bounds__(1024) void sample_kernel(
   __shared__ float red[16];
   __shared__ float redv[16];
   __shared__ int redi[16];
+  __shared__ unsigned long long red64[16];
+  __shared__ float cand[THR_CAP];
+  __shared__ int cand_n;
   const int row = blockIdx.x;
   if (active && !active[row]) {  // uniform over the block
     if (threadIdx.x == 0) {
@@ -228,53 +319,29 @@ __global__ __launch_bounds__(1024) void sample_kernel(
 
   if (filtered) {
     float thr = -INFINITY;
-    float lo, hi;
     float mass_k = se;  // mass (relative to exp(-mx)) of the top-k set
     if (k < V && k >= 1) {
       // largest t with count(z >= t) >= k
-      lo = mn; hi = mx;
-      for (int it = 0; it < 32; ++it) {
-        const float mid = 0.5f * (lo + hi);
-        float cnt = 0.f;
-        for_each_z(R, V, V8, [&](int, float z) { cnt += z >= mid ? 1.f : 0.f; });
-        cnt = block_sum(cnt, red);
-        if (cnt >= (float)k) lo = mid; else hi = mid;
-      }
-      thr = lo;
+      thr = find_threshold<false>(R, V, V8, mn, mx, (float)k, mx, red, red64, cand, &cand_n);
       float mk = 0.f;
       for_each_z(R, V, V8, [&](int, float z) { mk += z >= thr ? __expf(z - mx) : 0.f; });
       mass_k = block_sum(mk, red);
     }
     if (tp < 1.f) {
       // largest t >= thr with mass(z >= t) >= tp * mass_k
-      lo = fmaxf(thr, mn); hi = mx;
-      const float target = tp * mass_k;
-      for (int it = 0; it < 32; ++it) {
-        const float mid = 0.5f * (lo + hi);
-        float ms = 0.f;
-        for_each_z(R, V, V8, [&](int, float z) { ms += z >= mid ? __expf(z - mx) : 0.f; });
-        ms = block_sum(ms, red);
-        if (ms >= target) lo = mid; else hi = mid;
-      }
-      thr = fmaxf(thr, lo);
+      const float t2 = find_threshold<true>(R, V, V8, fmaxf(thr, mn), mx, tp * mass_k, mx, red, red64, cand, &cand_n);
+      thr = fmaxf(thr, t2);
     }
     // arg-max of z + Gumbel noise over the entries that survive the threshold
-    for (int i4 = threadIdx.x * 4; i4 < V; i4 += blockDim.x * 4) {
-      const u32x4 r = Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i4 >> 2));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int i = i4 + j;
-        if (i < V) {
-          const float z = R.z1(i);
-          if (z >= thr) {
-            ArgMax c;
-            c.v = z + gumbel(r[j]);
-            c.i = i;
-            best = amax(best, c);
-          }
-        }
+    // (few entries survive: the noise block of four entries is generated only where one of them does)
+    for_each_z(R, V, V8, [&](int i, float z) {
+      if (z >= thr) {
+        ArgMax c;
+        c.v = z + gumbel(Philox::gen(seed, (uint64_t)row, ctr0 + (uint64_t)(i >> 2))[i & 3]);
+        c.i = i;
+        best = amax(best, c);
       }
-    }
+    });
   }
   best = block_argmax(best, redv, redi);
   if (threadIdx.x == 0) {

@@ -570,6 +570,43 @@ def test_sampling_distribution_and_filters():
     assert set(tok.tolist()) <= nucleus
 
 
+@pytest.mark.parametrize("V,scale", [(151936, 2.0), (50000, 6.0), (9000, 1.0)])
+def test_filtered_sampling_on_large_vocabularies(V, scale):
+    """top-k / top-p thresholds found by halving over the whole row until the bracket fits LDS, then among the
+    candidates: every drawn token lies in the reference's top-k set / nucleus (computed by sorting), the reported
+    log-prob is the unfiltered one, and a replay of the same step draws the same tokens."""
+    torch.manual_seed(17)
+    B = 48
+    logits = (scale * torch.randn(B, V, device=DEV)).bfloat16()
+    lf = logits.float()
+    probs = torch.softmax(lf, -1)
+    sp, si = torch.sort(probs, -1, descending=True)
+    t1 = torch.ones(B, device=DEV)
+    for k, p in ((50, 1.0), (V, 0.9), (200, 0.5), (1, 1.0), (V, 0.999)):
+        tk = torch.full((B,), k, dtype=torch.int32, device=DEV)
+        tp = torch.full((B,), p, device=DEV)
+        # reference with the kernel's treatment of ties (bf16 logits tie often): the top-k set holds every entry that
+        # is >= the k-th largest value, the nucleus every entry >= the value at which the descending cumulative mass
+        # first reaches p x (mass of the top-k set); one entry of slack at that boundary (summation order)
+        in_k = probs >= sp[:, k - 1:k] if k < V else torch.ones_like(probs, dtype=torch.bool)
+        mass_k = (probs * in_k).sum(-1, keepdim=True)
+        cum = torch.cumsum(sp, -1)
+        first = (cum < p * mass_k).sum(-1)  # index of the entry that crosses the target
+        last = (first + (1 if p < 1.0 else 0)).clamp(max=V - 1)
+        kept = in_k & (probs >= sp.gather(1, last.unsqueeze(1))) if p < 1.0 else in_k
+        draws = []
+        for rep in range(2):
+            step = torch.full((1,), 3, dtype=torch.int64, device=DEV)
+            tok, lp = ops.sample(logits, t1, tk, tp, seed=21, step=step)
+            draws.append(tok.clone())
+            assert kept[torch.arange(B, device=DEV), tok].all(), (k, p)
+            ref = torch.log_softmax(lf, -1)[torch.arange(B, device=DEV), tok]
+            assert torch.allclose(lp, ref, atol=2e-3)
+        assert torch.equal(draws[0], draws[1])
+        if k == 1:
+            assert torch.equal(lf.gather(1, draws[0].unsqueeze(1)).squeeze(1), lf.max(-1).values)
+
+
 @pytest.mark.parametrize("V", [1000, 151936, 517])
 def test_sampler_penalties_and_inactive_rows(V):
     """Rows with a slot of the token-count table sample from logit - f * count - p * (count > 0) and bump the

@@ -41,11 +41,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vocab", type=int, default=151936)
     ap.add_argument("--batch", default="64,128,256,320,384,512")
+    ap.add_argument("--top-p", type=float, default=1.0, help="< 1: time the filtered path (nucleus sampling) instead")
+    ap.add_argument("--top-k", type=int, default=0, help="> 0: time the filtered path (top-k) instead")
+    ap.add_argument("--scale", type=float, default=2.0, help="standard deviation of the random logits")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     for B in [int(x) for x in a.batch.split(",")]:
         # two sets of logits (2 x B x V x 2 bytes): more than the 256 MB Infinity Cache from B = 512 on
-        logits = [(2 * torch.randn(B, a.vocab, device=dev)).bfloat16() for _ in range(2)]
+        logits = [(a.scale * torch.randn(B, a.vocab, device=dev)).bfloat16() for _ in range(2)]
         temp = torch.ones(B, device=dev)
         step = torch.zeros(1, dtype=torch.int64, device=dev)
         tok = torch.empty(B, dtype=torch.int64, device=dev)
@@ -56,6 +59,17 @@ def main():
             i[0] ^= 1
             ops.sample(logits[i[0]], temp, None, None, seed=1, step=step, out_tokens=tok, out_logprobs=lp)
 
+        if a.top_p < 1.0 or a.top_k > 0:
+            tp = torch.full((B,), a.top_p, device=dev)
+            tk = torch.full((B,), a.top_k if a.top_k > 0 else a.vocab, dtype=torch.int32, device=dev)
+
+            def run_f():
+                i[0] ^= 1
+                ops.sample(logits[i[0]], temp, tk, tp, seed=1, step=step, out_tokens=tok, out_logprobs=lp)
+
+            t = timeit(run_f)
+            print(f"B={B:4d} V={a.vocab}: filtered (top_p={a.top_p}, top_k={a.top_k or 'off'}) {t:8.1f} us", flush=True)
+            continue
         res = {}
         for split in (False, True):
             sampling.SPLIT_UNFILTERED = split
