@@ -275,7 +275,7 @@ class _Parser:
                     if exp == -1:
                         base = base.inv()
                         continue
-                base = sp.Pow(base, exp)
+                base = _power(base, exp)
             elif self.at("op", "'") and isinstance(base, sp.MatrixBase):
                 self.next()
                 base = base.T
@@ -325,7 +325,9 @@ class _Parser:
         while True:
             if self.at("op", "!"):
                 self.next()
-                e = sp.factorial(e)
+                # 10^9 ! would be computed digit by digit: numbers beyond a few thousand stay symbolic
+                big = isinstance(e, sp.Integer) and abs(int(e)) > 5000
+                e = sp.factorial(e, evaluate=False) if big else sp.factorial(e)
             elif self.at("op", "%"):
                 self.next()
                 e = e / 100
@@ -893,6 +895,16 @@ class _Parser:
         return m.det() if base in ("vmatrix",) else m
 
 
+def _power(base, exp):
+    """base ** exp; an integer tower such as 9^{9^{9}} stays unevaluated instead of being expanded digit by digit."""
+    if isinstance(exp, tuple) or isinstance(base, tuple):
+        raise LatexError("a list cannot be an operand of ^")
+    if (isinstance(base, (sp.Integer, sp.Rational)) and isinstance(exp, (sp.Integer, sp.Rational))
+            and abs(exp) > 4096 and base not in (0, 1, -1)):
+        return sp.Pow(base, exp, evaluate=False)
+    return sp.Pow(base, exp)
+
+
 _LOG_BASE10 = [True]
 _EMPTY = object()
 
@@ -922,11 +934,20 @@ def latex2sympy(text: str, variable_values: Optional[dict] = None, complex_i: bo
     """Parse a LaTeX math string -> a SymPy object (an expression, a relation, a Matrix, an Interval / FiniteSet, or a
     tuple for comma-separated lists). Raises ``LatexError`` on text outside the supported subset. Nothing is
     simplified: sums, integrals, limits and derivatives stay unevaluated (``.doit()`` evaluates them)."""
+    import warnings
+
     _LOG_BASE10[0] = log_base_10
+    if len(text) > 4000:
+        raise LatexError("expression too long")
     tokens = tokenize(_preprocess(text))
     if not tokens:
         raise LatexError("empty expression")
-    return _Parser(tokens, complex_i=complex_i, variable_values=variable_values).parse()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # SymPy's deprecation notes on lists inside matrices / powers
+        try:
+            return _Parser(tokens, complex_i=complex_i, variable_values=variable_values).parse()
+        except RecursionError:
+            raise LatexError("expression nested too deeply") from None
 
 
 def latex2latex(text: str, **kw) -> str:

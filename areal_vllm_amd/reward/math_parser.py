@@ -258,8 +258,12 @@ def _to_sympy(text: str):
 
         e = try_latex2sympy(text)
         if e is not None and not isinstance(e, tuple):
+            import sympy
+
             try:
-                return e.doit() if hasattr(e, "doit") else e
+                calculus = isinstance(e, sympy.Basic) and e.has(sympy.Integral, sympy.Sum, sympy.Product,
+                                                                sympy.Limit, sympy.Derivative)
+                return e.doit() if calculus else e
             except Exception:
                 return e
     try:
