@@ -323,9 +323,11 @@ __global__ __launch_bounds__(1024) void sample_kernel(
     if (k < V && k >= 1) {
       // largest t with count(z >= t) >= k
       thr = find_threshold<false>(R, V, V8, mn, mx, (float)k, mx, red, red64, cand, &cand_n);
-      float mk = 0.f;
-      for_each_z(R, V, V8, [&](int, float z) { mk += z >= thr ? __expf(z - mx) : 0.f; });
-      mass_k = block_sum(mk, red);
+      if (tp < 1.f) {  // the nucleus is taken inside the top-k set: its mass is the reference
+        float mk = 0.f;
+        for_each_z(R, V, V8, [&](int, float z) { mk += z >= thr ? __expf(z - mx) : 0.f; });
+        mass_k = block_sum(mk, red);
+      }
     }
     if (tp < 1.f) {
       // largest t >= thr with mass(z >= t) >= tp * mass_k
