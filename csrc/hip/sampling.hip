@@ -149,8 +149,9 @@ constexpr float THR_FIX = 1099511627776.f;  // 2^40: fixed-point scale of exp(z 
 // tensor-parallel group agree bit for bit.
 template <bool MASS, typename T>
 DEVINL float find_threshold(const Row<T>& R, int V, int V8, float lo, float hi, float target, float mx, float* red,
-                            unsigned long long* red64, float* buf, int* buf_n) {
-  float c_lo = (float)V, c_hi = 0.f, F_hi = 0.f;
+                            unsigned long long* red64, float* buf, int* buf_n, float n_ge_lo) {
+  // n_ge_lo: number of entries >= lo, or any upper bound of it (V when unknown)
+  float c_lo = n_ge_lo, c_hi = 0.f, F_hi = 0.f;
   bool hi_moved = false;
   int it = 0;
   for (; it < 32 && c_lo - c_hi > (float)THR_CAP; ++it) {
@@ -320,18 +321,26 @@ __global__ __launch_bounds__(1024) void sample_kernel(
   if (filtered) {
     float thr = -INFINITY;
     float mass_k = se;  // mass (relative to exp(-mx)) of the top-k set
+    float n_allowed = (float)V;  // entries in it (ties at the k-th value included)
     if (k < V && k >= 1) {
       // largest t with count(z >= t) >= k
-      thr = find_threshold<false>(R, V, V8, mn, mx, (float)k, mx, red, red64, cand, &cand_n);
+      thr = find_threshold<false>(R, V, V8, mn, mx, (float)k, mx, red, red64, cand, &cand_n, (float)V);
       if (tp < 1.f) {  // the nucleus is taken inside the top-k set: its mass is the reference
-        float mk = 0.f;
-        for_each_z(R, V, V8, [&](int, float z) { mk += z >= thr ? __expf(z - mx) : 0.f; });
+        float mk = 0.f, nk = 0.f;
+        for_each_z(R, V, V8, [&](int, float z) {
+          if (z >= thr) {
+            mk += __expf(z - mx);
+            nk += 1.f;
+          }
+        });
         mass_k = block_sum(mk, red);
+        n_allowed = block_sum(nk, red);
       }
     }
     if (tp < 1.f) {
       // largest t >= thr with mass(z >= t) >= tp * mass_k
-      const float t2 = find_threshold<true>(R, V, V8, fmaxf(thr, mn), mx, tp * mass_k, mx, red, red64, cand, &cand_n);
+      const float t2 = find_threshold<true>(R, V, V8, fmaxf(thr, mn), mx, tp * mass_k, mx, red, red64, cand, &cand_n,
+                                            n_allowed);
       thr = fmaxf(thr, t2);
     }
     // arg-max of z + Gumbel noise over the entries that survive the threshold
