@@ -142,11 +142,8 @@ class Attention(nn.Module):
         T = x.shape[0]
         D = self.cfg.head_dim
         qkv = ops.linear(x, self.qkv, self.qkv_bias, reduce_dx_group=reduce_dx_group)
-        if self.cfg.qk_norm:
-            q3 = qkv.view(T, self.hq + 2 * self.hkv, D)
-            q, _ = ops.rmsnorm(q3[:, :self.hq], self.q_norm, self.cfg.rms_norm_eps)
-            k, _ = ops.rmsnorm(q3[:, self.hq:self.hq + self.hkv], self.k_norm, self.cfg.rms_norm_eps)
-            qkv = torch.cat([q, k, q3[:, self.hq + self.hkv:]], 1).view(T, -1)
+        if self.cfg.qk_norm:  # q and k heads normalised inside the packed tensor, v heads copied: one pass
+            qkv = ops.qk_norm(qkv, self.q_norm, self.k_norm, self.cfg.rms_norm_eps, self.hq, self.hkv, D)
         return qkv
 
     def forward(self, x, positions, rope, cu_seqlens, max_seqlen, tp_group, sp=None, seq_par=False):

@@ -22,7 +22,7 @@ from .logprob import (  # noqa: F401
     merge_shard_stats,
     vocab_shard_range,
 )
-from .norm_act import RotaryTable, apply_rope, rmsnorm, rope_inplace_, swiglu  # noqa: F401
+from .norm_act import RotaryTable, apply_rope, qk_norm, rmsnorm, rope_inplace_, swiglu  # noqa: F401
 from .optim import adam_prepare_, adamw_, scale_, sumsq_  # noqa: F401
 from .rl import gae_1d_packed, gae_2d, gae_padded, merge_intervals, set_intervals, slice_intervals  # noqa: F401
 from .sampling import TokenCounts, advance_step_, decode_advance_, decode_begin_, sample  # noqa: F401

@@ -101,6 +101,76 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, residual: 
     return _RMSNormFn.apply(x, residual, weight, eps, gemma)
 
 
+# ------------------------------------------------------------------- q / k norm inside a packed qkv
+def _qk_norm_ref(qkv3, qw, kw, eps, hq, hkv):
+    x = qkv3.float()
+    n = hq + hkv
+    rstd = torch.rsqrt(x[:, :n].pow(2).mean(-1, keepdim=True) + eps)
+    w = torch.cat([qw.float().expand(hq, -1), kw.float().expand(hkv, -1)], 0)
+    y = torch.cat([x[:, :n] * rstd * w, x[:, n:]], 1)
+    return y.to(qkv3.dtype), rstd.squeeze(-1)
+
+
+class _QKNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, qw, kw, eps, hq, hkv, D):
+        T = qkv.shape[0]
+        x = qkv.reshape(T, hq + 2 * hkv, D)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        hip = L.use_hip(x) and x.dtype == torch.bfloat16 and D in (64, 128, 256)
+        # the result is allocated in the caller's shape (RoPE rotates it in place afterwards: it must not be a view
+        # made inside this function)
+        out = torch.empty(qkv.shape, dtype=x.dtype, device=x.device)
+        if hip:
+            rstd = torch.empty(T, hq + hkv, dtype=torch.float32, device=x.device)
+            L.check(L.lib().areal_qk_norm_fwd(L.ptr(x), L.ptr(qw.contiguous()), L.ptr(kw.contiguous()), L.ptr(out),
+                                              L.ptr(rstd), L.c_int64(T), L.c_int(hq), L.c_int(hkv), L.c_int(D),
+                                              L.c_float(eps), L.stream_ptr()), "qk_norm_fwd")
+        else:
+            y, rstd = _qk_norm_ref(x, qw, kw, eps, hq, hkv)
+            out.view(T, hq + 2 * hkv, D).copy_(y)
+        ctx.save_for_backward(x, qw, kw, rstd)
+        ctx.dims, ctx.hip, ctx.shape = (hq, hkv, D), hip, qkv.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, qw, kw, rstd = ctx.saved_tensors
+        hq, hkv, D = ctx.dims
+        T = x.shape[0]
+        dy = dout.reshape(T, hq + 2 * hkv, D).contiguous()
+        if ctx.hip:
+            lib = L.lib()
+            dx = torch.empty_like(x)
+            dw = torch.empty(2, D, dtype=x.dtype, device=x.device)
+            G = int(lib.areal_qk_norm_bwd_nblocks(L.c_int64(T * (hq + 2 * hkv))))
+            ws = torch.empty(G * 2 * D, dtype=torch.float32, device=x.device)
+            L.check(lib.areal_qk_norm_bwd(L.ptr(dy), L.ptr(x), L.ptr(qw.contiguous()), L.ptr(kw.contiguous()),
+                                          L.ptr(rstd), L.ptr(dx), L.ptr(dw), L.ptr(ws), L.c_int64(T), L.c_int(hq),
+                                          L.c_int(hkv), L.c_int(D), L.stream_ptr()), "qk_norm_bwd")
+            dqw, dkw = dw[0].to(qw.dtype), dw[1].to(kw.dtype)
+        else:
+            n = hq + hkv
+            xf, g0 = x.float(), dy.float()
+            w = torch.cat([qw.float().expand(hq, -1), kw.float().expand(hkv, -1)], 0)
+            xh = xf[:, :n] * rstd.unsqueeze(-1)
+            g = g0[:, :n] * w
+            dxn = rstd.unsqueeze(-1) * (g - xh * (g * xh).mean(-1, keepdim=True))
+            dx = torch.cat([dxn, g0[:, n:]], 1).to(x.dtype).contiguous()
+            dwf = g0[:, :n] * xh
+            dqw, dkw = dwf[:, :hq].sum((0, 1)).to(qw.dtype), dwf[:, hq:].sum((0, 1)).to(kw.dtype)
+        return dx.reshape(ctx.shape), dqw, dkw, None, None, None, None
+
+
+def qk_norm(qkv: torch.Tensor, q_weight: torch.Tensor, k_weight: torch.Tensor, eps: float, hq: int, hkv: int,
+            D: int) -> torch.Tensor:
+    """Per-head RMSNorm of the q and k heads of a packed projection output ``qkv`` [T, (hq + 2 hkv) * D] (Qwen3's
+    q_norm / k_norm), the v heads copied: one pass forward and one backward (``csrc/hip/norm_act.hip``) instead of
+    slicing the heads out, normalising and concatenating. Same shape out."""
+    return _QKNormFn.apply(qkv, q_weight, k_weight, eps, hq, hkv, D)
+
+
 # -------------------------------------------------------------------------------- SwiGLU
 GLU_ACTS = {"silu": 0, "gelu_tanh": 1, "gelu_pytorch_tanh": 1}
 

@@ -390,3 +390,170 @@ extern "C" int areal_rope_inplace(void* x, const int* pos, const float* cos_t, c
                      n_heads_total, n_rot_heads, D, sign, max_pos);
   return (int)hipGetLastError();
 }
+
+// ----------------------------------------------------------------------------------
+// Per-head RMSNorm of the q and k heads inside a packed projection output qkv [T, Hq + 2 Hkv, D] (Qwen3): one pass
+// that normalises the q rows with one weight vector, the k rows with another and copies the v rows, instead of
+// slicing the heads out (two strided copies), normalising them and concatenating the result (a third pass), forward
+// and backward. A row is D = 64 / 128 / 256 values: D / 8 lanes hold it in 16-byte pieces, a wave takes 64 / (D / 8)
+// rows at a time. rstd [T, Hq + Hkv] is kept for the backward pass.
+//   y = x * rstd * w,  rstd = rsqrt(mean(x^2) + eps)
+//   dx = rstd * (g - xh * mean(g * xh)),  g = dy * w,  xh = x * rstd;   dw = sum over rows of dy * xh
+// ----------------------------------------------------------------------------------
+template <int LPR>  // lanes per row = D / 8
+DEVINL float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void qk_norm_fwd_kernel(const bf16_t* __restrict__ qkv,
+                                                          const bf16_t* __restrict__ qw,
+                                                          const bf16_t* __restrict__ kw, bf16_t* __restrict__ out,
+                                                          float* __restrict__ rstd, int64_t rows, int Hq, int Hkv,
+                                                          float eps) {
+  constexpr int D = LPR * 8, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const int Ht = Hq + 2 * Hkv, Hn = Hq + Hkv;
+  const int64_t r = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  if (r >= rows) return;
+  const int h = (int)(r % Ht);
+  const int64_t t = r / Ht;
+  const bf16x8 v = ld8(qkv + r * D + sub * 8);
+  if (h >= Hn) {  // v head: unchanged
+    st8(out + r * D + sub * 8, v);
+    return;
+  }
+  float x[8], ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    x[j] = bf2f(v[j]);
+    ss += x[j] * x[j];
+  }
+  // rows of one wave may be q, k or v rows: the shuffles stay inside the LPR lanes of a row, and the v rows' lanes
+  // above have left - reduce with the lanes that remain (xor partners inside a row are all of the same kind)
+  ss = row_sum<LPR>(ss);
+  const float rs = rsqrtf(ss / (float)D + eps);
+  const bf16x8 w = ld8((h < Hq ? qw : kw) + sub * 8);
+  bf16x8 y;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) y[j] = f2bf(x[j] * rs * bf2f(w[j]));
+  st8(out + r * D + sub * 8, y);
+  if (sub == 0) rstd[t * Hn + h] = rs;
+}
+
+// dw partial sums: part [gridDim.x][2][D] (q weight, k weight)
+template <int LPR>
+__global__ __launch_bounds__(256) void qk_norm_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                          const bf16_t* __restrict__ qkv,
+                                                          const bf16_t* __restrict__ qw,
+                                                          const bf16_t* __restrict__ kw,
+                                                          const float* __restrict__ rstd, bf16_t* __restrict__ dx,
+                                                          float* __restrict__ part, int64_t rows, int Hq, int Hkv) {
+  constexpr int D = LPR * 8, RPW = 64 / LPR;
+  __shared__ float red[4][2][D];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, sub = lane % LPR;
+  const int Ht = Hq + 2 * Hkv, Hn = Hq + Hkv;
+  float wq[8], wk[8], aq[8], ak[8];
+  {
+    const bf16x8 a = ld8(qw + sub * 8), b = ld8(kw + sub * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      wq[j] = bf2f(a[j]);
+      wk[j] = bf2f(b[j]);
+      aq[j] = ak[j] = 0.f;
+    }
+  }
+  const int64_t per_block = 4 * RPW;
+  for (int64_t r0 = (int64_t)blockIdx.x * per_block; r0 < rows; r0 += (int64_t)gridDim.x * per_block) {
+    const int64_t r = r0 + wid * RPW + lane / LPR;
+    const bool live = r < rows;
+    const int h = live ? (int)(r % Ht) : Ht;
+    const int64_t t = live ? r / Ht : 0;
+    bf16x8 g8, x8;
+    if (live) {
+      g8 = ld8(dy + r * D + sub * 8);
+      if (h < Hn) x8 = ld8(qkv + r * D + sub * 8);
+    }
+    if (live && h >= Hn) st8(dx + r * D + sub * 8, g8);  // v head: gradient passes through
+    const bool normed = live && h < Hn;
+    const float rs = normed ? rstd[t * Hn + h] : 0.f;
+    float g[8], xh[8], dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = normed ? bf2f(g8[j]) : 0.f;
+      xh[j] = normed ? bf2f(x8[j]) * rs : 0.f;
+      g[j] = d * (h < Hq ? wq[j] : wk[j]);
+      dot += g[j] * xh[j];
+      if (normed) {
+        if (h < Hq) aq[j] += d * xh[j]; else ak[j] += d * xh[j];
+      }
+    }
+    dot = row_sum<LPR>(dot) / (float)D;  // every lane of the wave takes part (zeros for rows that are not normed)
+    if (normed) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = f2bf(rs * (g[j] - xh[j] * dot));
+      st8(dx + r * D + sub * 8, o);
+    }
+  }
+  // lanes with the same `sub` hold the same columns: sum them inside the wave, then over the four waves
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      aq[j] += __shfl_xor(aq[j], o, 64);
+      ak[j] += __shfl_xor(ak[j], o, 64);
+    }
+  }
+  if (lane < LPR) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[wid][0][sub * 8 + j] = aq[j];
+      red[wid][1][sub * 8 + j] = ak[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * D; c += 256) {
+    const int which = c / D, col = c % D;
+    part[(size_t)blockIdx.x * 2 * D + c] = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+  }
+}
+
+extern "C" int areal_qk_norm_bwd_nblocks(int64_t rows) {
+  const int64_t g = (rows + 63) / 64;
+  return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
+
+extern "C" int areal_qk_norm_fwd(const void* qkv, const void* qw, const void* kw, void* out, float* rstd, int64_t T,
+                                 int Hq, int Hkv, int D, float eps, hipStream_t st) {
+  if (T == 0) return 0;
+  if (D != 64 && D != 128 && D != 256) return -1;
+  const int64_t rows = T * (Hq + 2 * Hkv);
+  const int rpw = 64 / (D / 8);
+  const dim3 grid((unsigned)((rows + 4 * rpw - 1) / (4 * rpw))), block(256);
+#define QKN(L_) hipLaunchKernelGGL(qk_norm_fwd_kernel<L_>, grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)qw, \
+                                   (const bf16_t*)kw, (bf16_t*)out, rstd, rows, Hq, Hkv, eps)
+  if (D == 64) QKN(8); else if (D == 128) QKN(16); else QKN(32);
+#undef QKN
+  return (int)hipGetLastError();
+}
+
+// workspace: areal_qk_norm_bwd_nblocks(rows) * 2 * D floats. dw_q / dw_k: bf16 [D] each (one buffer [2, D]).
+extern "C" int areal_qk_norm_bwd(const void* dy, const void* qkv, const void* qw, const void* kw, const float* rstd,
+                                 void* dx, void* dw_bf16, float* workspace, int64_t T, int Hq, int Hkv, int D,
+                                 hipStream_t st) {
+  if (T == 0) return 0;
+  if (D != 64 && D != 128 && D != 256) return -1;
+  const int64_t rows = T * (Hq + 2 * Hkv);
+  const int G = areal_qk_norm_bwd_nblocks(rows);
+  const dim3 grid(G), block(256);
+#define QKN(L_) hipLaunchKernelGGL(qk_norm_bwd_kernel<L_>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)qkv, \
+                                   (const bf16_t*)qw, (const bf16_t*)kw, rstd, (bf16_t*)dx, workspace, rows, Hq, Hkv)
+  if (D == 64) QKN(8); else if (D == 128) QKN(16); else QKN(32);
+#undef QKN
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((2 * D + 31) / 32), dim3(256), 0, st, workspace, (bf16_t*)dw_bf16,
+                     (float*)nullptr, G, 2 * D);
+  return (int)hipGetLastError();
+}

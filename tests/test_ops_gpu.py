@@ -729,6 +729,36 @@ def test_moe_routing_kernels_match_the_library_formulation(T, E, k):
     assert torch.equal(offsets[1:].long(), torch.cumsum(counts, 0)) and int(offsets[0]) == 0
 
 
+@pytest.mark.parametrize("T,hq,hkv,D", [(1000, 16, 8, 128), (37, 4, 2, 64), (513, 2, 1, 256), (4096, 32, 4, 128)])
+def test_qk_norm_in_packed_qkv_matches_fp32_reference(T, hq, hkv, D):
+    """Per-head RMSNorm of the q / k heads inside the packed projection output, v heads copied, forward and
+    backward, against the slice / normalise / concatenate formulation in fp32."""
+    torch.manual_seed(18)
+    Ht = hq + 2 * hkv
+    qkv = (torch.randn(T, Ht * D, device=DEV) * 1.5).bfloat16().requires_grad_(True)
+    qw = (1 + 0.2 * torch.randn(D, device=DEV)).bfloat16().requires_grad_(True)
+    kw = (1 + 0.2 * torch.randn(D, device=DEV)).bfloat16().requires_grad_(True)
+    eps = 1e-6
+    out = ops.qk_norm(qkv, qw, kw, eps, hq, hkv, D)
+    dout = torch.randn_like(out)
+    out.backward(dout)
+
+    x = qkv.detach().float().view(T, Ht, D).requires_grad_(True)
+    qf, kf = qw.detach().float().requires_grad_(True), kw.detach().float().requires_grad_(True)
+
+    def norm(v, w):
+        return v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + eps) * w
+
+    ref = torch.cat([norm(x[:, :hq], qf), norm(x[:, hq:hq + hkv], kf), x[:, hq + hkv:]], 1).view(T, -1)
+    ref.backward(dout.float())
+    assert (out.float() - ref).abs().max().item() < 0.04
+    assert torch.equal(out.view(T, Ht, D)[:, hq + hkv:], qkv.view(T, Ht, D)[:, hq + hkv:])
+    assert (qkv.grad.float() - x.grad.view(T, -1)).abs().max().item() < 0.06
+    scale = max(1.0, qf.grad.abs().max().item())
+    assert (qw.grad.float() - qf.grad).abs().max().item() < 0.02 * scale
+    assert (kw.grad.float() - kf.grad).abs().max().item() < 0.02 * max(1.0, kf.grad.abs().max().item())
+
+
 def test_decode_advance_and_begin_kernels_match_their_cpu_twins():
     """Device bookkeeping of a multi-step decode plan (early exit on stop ids / budget, kill mask of a
     continuation plan) against the PyTorch twins the CPU engine runs."""
