@@ -90,11 +90,13 @@ class ModelRunner:
         self.is_vl = cfg.vision is not None
         self.mm: Dict[int, Dict[str, Any]] = {}
         # Decode batches of FUSED_MIN_BATCH rows and more run the layer as seven launches (ops/decode_gemm.py);
-        # smaller ones, and model variants its epilogues do not cover, take the library GEMMs.
+        # model variants its epilogues do not cover (LayerNorm / ungated MLP families) take the library GEMMs.
+        # The gated-MLP epilogue has a SiLU and a tanh-GELU gate (SwiGLU: Llama / Qwen / Mistral; GeGLU: Gemma).
         # (tensor-parallel shards included: the row-parallel projections then hand their summed slabs to the group's
         # all-reduce ahead of the residual + norm kernel; mixture-of-experts layers run their attention half this
         # way and the routed experts through the grouped kernels)
-        fusable = (not self.plain_family and cfg.hidden_act == "silu" and cfg.hidden_size % 64 == 0
+        fusable = (not self.plain_family and cfg.hidden_act in ("silu", "gelu_tanh", "gelu_pytorch_tanh")
+                   and cfg.hidden_size % 64 == 0
                    and (cfg.n_experts > 0 or (cfg.intermediate_size // model.tp_size) % 64 == 0)
                    and cfg.head_dim % 16 == 0 and (self.hq * cfg.head_dim) % 64 == 0)
         if fused_decode is None:
@@ -444,11 +446,13 @@ class ModelRunner:
             return mode
         layers = self.model.layers
         x = torch.randn(Bp, self.cfg.hidden_size, device=self.device, dtype=self.dtype)
-        arms = {"tiled": lambda i: dg.dgemm(x, layers[i % len(layers)].mlp.gate_up, epilogue=dg.EPI_SWIGLU),
+        act = "silu" if self.cfg.hidden_act == "silu" else "gelu_tanh"
+        epi = dg.gated_epilogue(act)
+        arms = {"tiled": lambda i: dg.dgemm(x, layers[i % len(layers)].mlp.gate_up, epilogue=epi),
                 "library": lambda i: ops.swiglu(F.linear(x, layers[i % len(layers)].mlp.gate_up),
                                                 layers[i % len(layers)].mlp.act)}
         if has_plan:
-            arms["balanced"] = lambda i: dg.dgemm_swiglu_balanced(x, layers[i % len(layers)].mlp.gate_up)
+            arms["balanced"] = lambda i: dg.dgemm_swiglu_balanced(x, layers[i % len(layers)].mlp.gate_up, act=act)
         times = {}
         for name, fn in arms.items():
             for i in range(2):
@@ -487,6 +491,7 @@ class ModelRunner:
         eps, gemma = cfg.rms_norm_eps, cfg.gemma_norm
         layers = self.model.layers
         gate_up_mode = self._gate_up_mode(Bp)
+        gate_act = "silu" if cfg.hidden_act == "silu" else "gelu_tanh"  # SwiGLU, or GeGLU (Gemma)
         tp = self.tp_comm
 
         def finish(slab, residual, weight):
@@ -526,9 +531,9 @@ class ModelRunner:
                 x, residual = ops.rmsnorm(mixed, nw, eps, residual, gemma)
                 continue
             if gate_up_mode == "balanced":
-                act = dg.dgemm_swiglu_balanced(x, blk.mlp.gate_up)
+                act = dg.dgemm_swiglu_balanced(x, blk.mlp.gate_up, act=gate_act)
             elif gate_up_mode == "tiled":
-                act = dg.dgemm(x, blk.mlp.gate_up, epilogue=dg.EPI_SWIGLU)
+                act = dg.dgemm(x, blk.mlp.gate_up, epilogue=dg.gated_epilogue(gate_act))
             else:
                 act = ops.swiglu(F.linear(x, blk.mlp.gate_up), blk.mlp.act)
             slab = dg.dgemm(act, blk.mlp.down, epilogue=dg.EPI_SLAB)

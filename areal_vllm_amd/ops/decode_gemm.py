@@ -20,7 +20,17 @@ import torch.nn.functional as F
 
 from . import _lib as L
 
-EPI_BF16, EPI_SLAB, EPI_SWIGLU = 0, 1, 2
+EPI_BF16, EPI_SLAB, EPI_SWIGLU, EPI_GEGLU = 0, 1, 2, 3  # GEGLU: the SwiGLU epilogue with a tanh-GELU gate
+GATED = (EPI_SWIGLU, EPI_GEGLU)
+
+
+def gated_epilogue(act: str) -> int:
+    """Epilogue id of the gated-MLP projection for a model's `hidden_act`."""
+    return EPI_SWIGLU if act == "silu" else EPI_GEGLU
+
+
+def _gate(g: torch.Tensor, epilogue: int) -> torch.Tensor:
+    return F.silu(g) if epilogue == EPI_SWIGLU else F.gelu(g, approximate="tanh")
 
 # cfg id -> (rows per block, weight columns per block, threads); must match areal_dgemm_block_shape
 DG_CONFIGS = {0: (256, 64, 512), 1: (256, 128, 512), 2: (128, 128, 256), 3: (128, 64, 256), 4: (64, 128, 256),
@@ -77,8 +87,8 @@ def pick_config(M: int, N: int, K: int, epilogue: int) -> Tuple[int, int, int, i
     stages = max_stages(cfg)
     if wide and M > 256:
         stages = 2
-    cols = N // 2 if epilogue == EPI_SWIGLU else N
-    per_tile = bn // 2 if epilogue == EPI_SWIGLU else bn
+    cols = N // 2 if epilogue in GATED else N
+    per_tile = bn // 2 if epilogue in GATED else bn
     tiles = ((cols + per_tile - 1) // per_tile) * ((M + bm - 1) // bm)
     ksplit = 1
     if epilogue == EPI_SLAB:
@@ -118,7 +128,7 @@ def dgemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
         if epilogue == EPI_SLAB:
             out = torch.empty(ksplit, M, N, dtype=torch.float32, device=x.device)
         else:
-            out = torch.empty(M, N // 2 if epilogue == EPI_SWIGLU else N, dtype=x.dtype, device=x.device)
+            out = torch.empty(M, N // 2 if epilogue in GATED else N, dtype=x.dtype, device=x.device)
     if not L.use_hip(x):
         if epilogue == EPI_SLAB:
             steps = K // 64
@@ -128,9 +138,9 @@ def dgemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
                 out[s_, :M] = x[:, lo:hi].float() @ w[:, lo:hi].float().t()
             return out
         y = F.linear(x, w, bias)
-        if epilogue == EPI_SWIGLU:
+        if epilogue in GATED:
             f = N // 2
-            out.copy_((F.silu(y[:, :f].float()) * y[:, f:].float()).to(x.dtype))
+            out.copy_((_gate(y[:, :f].float(), epilogue) * y[:, f:].float()).to(x.dtype))
         else:
             out.copy_(y)
         return out
@@ -166,7 +176,7 @@ def swiglu_plan(M: int, F: int) -> Optional[Tuple[int, int]]:
 
 def dgemm_swiglu_balanced(x: torch.Tensor, w_gate_up: torch.Tensor, out: Optional[torch.Tensor] = None, *,
                           cols: Optional[int] = None, mblocks: Optional[int] = None, stages: int = 4,
-                          nt: bool = True) -> torch.Tensor:
+                          nt: bool = True, act: str = "silu") -> torch.Tensor:
     """``silu(x @ gate.T) * (x @ up.T)`` with ``w_gate_up = [gate; up]`` ``[2F, K]`` -> bf16 ``[M, F]``, one workgroup
     per CU: column ranges of ``cols`` columns each (``csrc/hip/decode_swiglu.hip``). Same rounding points as
     ``dgemm(..., epilogue=EPI_SWIGLU)``."""
@@ -178,7 +188,7 @@ def dgemm_swiglu_balanced(x: torch.Tensor, w_gate_up: torch.Tensor, out: Optiona
     if not L.use_hip(x):
         y = F.linear(x, w_gate_up)
         y = y.to(x.dtype)
-        out.copy_((F.silu(y[:, :Fc].float()) * y[:, Fc:].float()).to(x.dtype))
+        out.copy_((_gate(y[:, :Fc].float(), gated_epilogue(act)) * y[:, Fc:].float()).to(x.dtype))
         return out
     plan = swiglu_plan(M, Fc)
     if cols is None or mblocks is None:
@@ -189,7 +199,8 @@ def dgemm_swiglu_balanced(x: torch.Tensor, w_gate_up: torch.Tensor, out: Optiona
     assert w_gate_up.is_contiguous() and out.stride(1) == 1 and K % 64 == 0
     L.check(L.lib().areal_dswiglu(L.ptr(x), L.c_int64(x.stride(0)), L.ptr(w_gate_up), L.ptr(out),
                                   L.c_int64(out.stride(0)), L.c_int(M), L.c_int(Fc), L.c_int(K), L.c_int(int(cols)),
-                                  L.c_int(int(mblocks)), L.c_int(int(stages)), L.c_int(int(bool(nt))), L.stream_ptr()),
+                                  L.c_int(int(mblocks)), L.c_int(int(stages)), L.c_int(int(bool(nt))),
+                                  L.c_int(0 if act == "silu" else 1), L.stream_ptr()),
             "dswiglu")
     return out
 

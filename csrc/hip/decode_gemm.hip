@@ -41,6 +41,7 @@ struct DGArgs {
   long ys;
   int M, N, K, k_per_split;
   int nt;  // non-temporal weight loads (each weight byte is read once per launch)
+  int act;  // gate activation of the gated-MLP epilogue (gate_act_f)
   // DG_ROPE: W = the packed q|k|v projection, heads of D columns. Rotary tables [max_pos, D/2] fp32, position and
   // KV slot per row; q goes to q_out [M, Hq, D], k / v into the paged caches (K [P, Hkv, 32, D], V [P, Hkv, D, 32])
   const int* pos;
@@ -74,6 +75,13 @@ DEVINL void wait_tiles(int keep) {
 }
 
 DEVINL float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// gate activation of the gated-MLP epilogue: 0 = SiLU (SwiGLU), 1 = tanh-approximated GELU (GeGLU, Gemma)
+DEVINL float gate_act_f(float x, int act) {
+  if (act == 0) return silu_f(x);
+  const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float e = __expf(-2.f * fabsf(inner));
+  return 0.5f * x * (1.f + copysignf((1.f - e) / (1.f + e), inner));
+}
 
 // TM / TN: 32-row activation / weight tiles per wave; WM x WN MFMA waves per block. BK = 64.
 // LW = 0: every wave stages its share of each tile and computes. LW > 0: LW extra waves do nothing but issue the
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void dgemm_kernel(const DGArgs
             for (int j = 0; j < 4; ++j) {
               // gate / up rounded to bf16 first: the values an unfused bf16 GEMM output would carry
               const float gg = bf2f(f2bf(acc[tn][tm][4 * g + j])), uu = bf2f(f2bf(acc[tn + HT][tm][4 * g + j]));
-              o[j] = f2bf(silu_f(gg) * uu);
+              o[j] = f2bf(gate_act_f(gg, a.act) * uu);
             }
             *reinterpret_cast<bf16x4*>(yrow + n) = o;
           }
@@ -415,11 +423,17 @@ extern "C" int areal_dgemm_block_shape(int cfg, int* bm, int* bn, int* threads) 
 
 // X [M, K] bf16 (row stride xs), W [N, K] bf16 contiguous, K % 64 == 0, N % 32 == 0 (SwiGLU: N/2 % 32 == 0).
 // epilogue 0: Y bf16 [M, N] (+bias); 1: Y fp32 slab [ksplit, M, N] (ys = N; bias ignored);
-// 2: W = [gate; up], Y bf16 [M, N/2] = silu(X gate^T) * (X up^T). ksplit > 1 only with epilogue 1.
+// 2: W = [gate; up], Y bf16 [M, N/2] = silu(X gate^T) * (X up^T); 3: the same with the tanh-approximated GELU on the
+// gate (GeGLU). ksplit > 1 only with epilogue 1.
 extern "C" int areal_dgemm(const void* X, long xs, const void* W, const void* bias, void* Y, long ys, int M, int N,
                            int K, int cfg, int stages, int epilogue, int ksplit, int loader_waves, int nt,
                            hipStream_t st) {
   if (M <= 0) return 0;
+  int act = 0;
+  if (epilogue == 3) {
+    act = 1;
+    epilogue = DG_SWIGLU;
+  }
   if (K % 64 != 0 || xs % 8 != 0 || N % 32 != 0) return -1;
   if (epilogue == DG_SWIGLU && (N / 2) % 32 != 0) return -2;
   if (ksplit < 1) ksplit = 1;
@@ -429,7 +443,7 @@ extern "C" int areal_dgemm(const void* X, long xs, const void* W, const void* bi
   if (epilogue == DG_SLAB && ys != N) return -5;
   DGArgs a;
   a.X = (const bf16_t*)X; a.xs = xs; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.Y = Y; a.ys = ys;
-  a.M = M; a.N = N; a.K = K; a.k_per_split = kps; a.nt = nt;
+  a.M = M; a.N = N; a.K = K; a.k_per_split = kps; a.nt = nt; a.act = act;
   a.pos = nullptr; a.slots = nullptr; a.cos_t = a.sin_t = nullptr; a.q_out = a.kcache = a.vcache = nullptr;
   a.Hq = a.Hkv = 0; a.D = 2; a.max_pos = 0; a.do_rope = 0;
   switch (cfg) {
@@ -462,7 +476,7 @@ extern "C" int areal_dgemm_qkv_rope(const void* X, long xs, const void* W, const
   if (cfg == 4 && (D / 2) % 64 != 0) return -2;
   DGArgs a;
   a.X = (const bf16_t*)X; a.xs = xs; a.W = (const bf16_t*)W; a.bias = (const bf16_t*)bias; a.Y = nullptr; a.ys = 0;
-  a.M = M; a.N = N; a.K = K; a.k_per_split = K; a.nt = nt;
+  a.M = M; a.N = N; a.K = K; a.k_per_split = K; a.nt = nt; a.act = 0;
   a.pos = pos; a.slots = slots; a.cos_t = cos_t; a.sin_t = sin_t; a.q_out = (bf16_t*)q_out;
   a.kcache = (bf16_t*)kcache; a.vcache = (bf16_t*)vcache; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.max_pos = max_pos;
   a.do_rope = do_rope;

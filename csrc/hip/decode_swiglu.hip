@@ -40,6 +40,7 @@ struct SGArgs {
   int ntiles;   // ceil(F / w)
   int mblocks;  // row blocks (1 or 2)
   int nt;       // non-temporal weight loads
+  int act;      // gate activation: 0 SiLU (SwiGLU), 1 tanh-approximated GELU (GeGLU)
 };
 
 template <int N>
@@ -58,6 +59,12 @@ DEVINL void sg_wait_tiles(int keep) {
 }
 
 DEVINL float sg_silu(float x) { return x / (1.f + __expf(-x)); }
+DEVINL float sg_gate(float x, int act) {
+  if (act == 0) return sg_silu(x);
+  const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float e = __expf(-2.f * fabsf(inner));
+  return 0.5f * x * (1.f + copysignf((1.f - e) / (1.f + e), inner));
+}
 
 // RT: 16-row activation tiles per consumer wave (block rows BM = 64 RT); TW: 16-column tiles per half (gate / up).
 template <int RT, int TW, int STAGES>
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(512) void dswiglu_kernel(const SGArgs a) {
         for (int j = 0; j < 4; ++j) {
           // gate / up rounded to bf16 first: the values an unfused bf16 GEMM output would carry
           const float gg = bf2f(f2bf(acc[ct][rt][j])), uu = bf2f(f2bf(acc[ct + TW][rt][j]));
-          o[j] = f2bf(sg_silu(gg) * uu);
+          o[j] = f2bf(sg_gate(gg, a.act) * uu);
         }
         *reinterpret_cast<bf16x4*>(yrow + n) = o;
       }
@@ -225,14 +232,14 @@ int sg_stages(const SGArgs& a, int stages, hipStream_t st) {
 // K % 64 == 0, F % 4 == 0, w % 4 == 0, 4 <= w <= 80, M <= 256 mblocks, mblocks in {1, 2}. Returns -10 for a shape
 // no instantiation covers (the caller then takes another kernel).
 extern "C" int areal_dswiglu(const void* X, long xs, const void* W, void* Y, long ys, int M, int F, int K, int w,
-                             int mblocks, int stages, int nt, hipStream_t st) {
+                             int mblocks, int stages, int nt, int act, hipStream_t st) {
   if (M <= 0) return 0;
   if (K % 64 != 0 || xs % 8 != 0 || F % 4 != 0 || w % 4 != 0 || w < 4 || ys % 4 != 0) return -1;
   if (mblocks < 1 || mblocks > 2) return -2;
   if (((uintptr_t)X | (uintptr_t)W) % 16 != 0 || ((uintptr_t)Y) % 8 != 0) return -3;
   SGArgs a;
   a.X = (const bf16_t*)X; a.xs = xs; a.W = (const bf16_t*)W; a.Y = (bf16_t*)Y; a.ys = ys;
-  a.M = M; a.F = F; a.K = K; a.w = w; a.ntiles = (F + w - 1) / w; a.mblocks = mblocks; a.nt = nt;
+  a.M = M; a.F = F; a.K = K; a.w = w; a.ntiles = (F + w - 1) / w; a.mblocks = mblocks; a.nt = nt; a.act = act;
   const int rows = (M + mblocks - 1) / mblocks;  // rows per block
   const int rt = (rows + 63) / 64;
   const int tw = (w + 15) / 16;

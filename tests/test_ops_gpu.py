@@ -1058,6 +1058,25 @@ def test_balanced_swiglu_gemm_matches_fp32(M, Fc, K, cols, mblocks):
         _close(DG.dgemm_swiglu_balanced(x, w), want, 3e-2, 2e-2, "default plan")
 
 
+@pytest.mark.parametrize("M,Fc,K", [(8, 1024, 512), (256, 8960, 1536), (100, 2048, 256)])
+def test_gated_mlp_epilogues_with_gelu_gate(M, Fc, K):
+    """GeGLU (tanh-approximated GELU on the gate, Gemma) in the epilogue of the tiled and of the balanced decode
+    GEMM against fp32 with the rounding points of the unfused path."""
+    from areal_vllm_amd.ops import decode_gemm as DG
+
+    torch.manual_seed(M + Fc + 1)
+    dev = torch.device("cuda")
+    x = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(2 * Fc, K, device=dev) * (1.0 / K ** 0.5)).bfloat16()
+    y = (x.float() @ w.float().t()).bfloat16().float()
+    want = F.gelu(y[:, :Fc], approximate="tanh") * y[:, Fc:]
+    _close(DG.dgemm(x, w, epilogue=DG.EPI_GEGLU), want, 3e-2, 2e-2, "tiled")
+    if DG.swiglu_plan(M, Fc) is not None:
+        _close(DG.dgemm_swiglu_balanced(x, w, act="gelu_tanh"), want, 3e-2, 2e-2, "balanced")
+    # the SiLU gate is untouched by the flag
+    _close(DG.dgemm(x, w, epilogue=DG.EPI_SWIGLU), F.silu(y[:, :Fc]) * y[:, Fc:], 3e-2, 2e-2, "silu")
+
+
 def _ipc_allreduce_worker(rank, world, port, out_dir):
     import os
     import sys
