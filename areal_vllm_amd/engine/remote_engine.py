@@ -229,7 +229,8 @@ def _update_from_ipc(meta: WeightUpdateMeta, experiment_name, trial_name, model_
     name_resolve.wait(key, timeout=600)
     t0 = time.perf_counter()
     src = dict(meta.ipc_src or {})
-    plain = not src or (src.get("tp", 1) == 1 and src.get("pp", 1) == 1 and src.get("zero3", 1) == 1)
+    plain = not src or (src.get("tp", 1) == 1 and src.get("pp", 1) == 1 and src.get("zero3", 1) == 1
+                        and src.get("ep", 1) == 1)
     n = len(meta.ipc_buffers)
 
     async def go():

@@ -778,14 +778,16 @@ class NativeTrainEngine(TrainEngine):
             dist.barrier(group=self.grid.group("world"))
 
     def _load_sharded(self, meta: SaveLoadMeta):
-        """Load a sharded checkpoint. Written with the same (tp, pp) it is one file read per rank; written with
-        ANOTHER tensor / pipeline layout, every rank pulls the intervals of the source shards that make up its
-        own flat buffer (the plan of ``parallel/param_realloc.py``, applied to files instead of peers): the
+        """Load a sharded checkpoint. Written with the same layout it is one file read per rank (two with expert
+        parallelism); written with ANOTHER tensor / pipeline / expert-parallel layout, every rank pulls the intervals
+        of the source shard files that make up its own flat buffers (the piece algebra of
+        ``parallel/param_realloc.py``, applied to files instead of peers; dense and mixture-of-experts models): the
         resharding load of ``areal/experimental/utils/megatron_checkpointer.py`` /
         ``areal/experimental/model/hf_load.py``."""
         import glob
         import json
 
+        import numpy as np
         from safetensors.torch import load_file
 
         g = self.grid
@@ -805,7 +807,11 @@ class NativeTrainEngine(TrainEngine):
         with open(mans[0]) as f:
             lay = json.load(f)["layout"]
         flat = self.model.flat.flat
-        if (lay["tp"], lay["pp"], int(lay.get("vpp", 1))) == (g.tp, g.pp, g.vpp):
+        moe = self.model_config.n_experts > 0
+        same = (lay["tp"], lay["pp"], int(lay.get("vpp", 1))) == (g.tp, g.pp, g.vpp)
+        if moe:
+            same = same and (int(lay.get("ep", 1)), int(lay.get("etp", lay["tp"]))) == (g.ep, g.etp)
+        if same:
             tag = f"pp{g.coord.pp}-tp{g.coord.tp}"
             with open(os.path.join(meta.path, f"manifest-{tag}.json")) as f:
                 man = json.load(f)
@@ -813,39 +819,29 @@ class NativeTrainEngine(TrainEngine):
             assert man["offsets"] == mine, "parameter layout of the checkpoint differs from this model"
             t = load_file(os.path.join(meta.path, f"shard-{tag}.safetensors"))
             flat.copy_(t["flat"].to(flat.dtype))
-        else:
-            from ..parallel.param_realloc import Layout, derive_realloc_plan
-
             if self.model.flat_experts is not None:
-                raise NotImplementedError("resharding a mixture-of-experts checkpoint across tp / pp layouts: "
-                                          "convert through the hf format")
-            src = Layout(1, int(lay["tp"]), int(lay["pp"]), vpp=int(lay.get("vpp", 1)))
-            dst = Layout(1, g.tp, g.pp, vpp=g.vpp)
-            me = dst.index_of(g.coord.pp, 0, g.coord.tp)
-            host = torch.zeros(flat.numel(), dtype=flat.dtype)
-            filled = 0
-            for tr in derive_realloc_plan(self.model_config, src, dst, dtype=flat.dtype):
-                if tr.dst != me:
-                    continue
-                sp, st = divmod(tr.src, src.tp)
-                sflat = load_file(os.path.join(meta.path, f"shard-pp{sp}-tp{st}.safetensors"))["flat"].to(flat.dtype)
-                ops.set_intervals(ops.slice_intervals(sflat, tr.src_intervals), host, tr.dst_intervals)
-                filled += tr.numel
-            used = sum(k for _, k in self.model.flat.offsets.values())
-            assert filled == used, f"resharding load covered {filled} of {used} parameter elements"
-            flat.copy_(host)
-            logger.info(f"resharded checkpoint load: tp{src.tp} pp{src.pp} vpp{src.vpp} -> tp{dst.tp} pp{dst.pp} "
-                        f"vpp{dst.vpp}")
+                fe = self.model.flat_experts.flat
+                t = load_file(os.path.join(meta.path, self._expert_shard_file()))
+                fe.copy_(t["flat_experts"].to(fe.dtype))
+            return
+        from ..parallel.param_realloc import derive_file_load_plan
+
+        bufs = {"flat": self.model.flat}
         if self.model.flat_experts is not None:
-            if int(lay.get("ep", 1)) != g.ep:
-                raise ValueError(f"sharded checkpoint holds ep{lay.get('ep', 1)} expert shards, this engine is ep{g.ep}; "
-                                 "convert through the hf format")
-            if int(lay.get("etp", lay.get("tp", 1))) != g.etp:
-                raise ValueError(f"sharded checkpoint splits experts over {lay.get('etp', lay.get('tp', 1))} ranks, "
-                                 f"this engine over {g.etp}; convert through the hf format")
-            fe = self.model.flat_experts.flat
-            t = load_file(os.path.join(meta.path, self._expert_shard_file()))
-            fe.copy_(t["flat_experts"].to(fe.dtype))
+            bufs["flat_experts"] = self.model.flat_experts
+        host = {k: torch.zeros(fp.flat.numel(), dtype=fp.flat.dtype) for k, fp in bufs.items()}
+        filled = {k: 0 for k in bufs}
+        for fname, key, which, tri in derive_file_load_plan(self.model_config, lay, self.model):
+            sflat = load_file(os.path.join(meta.path, fname))[key].to(host[which].dtype)
+            ops.set_intervals(ops.slice_intervals(sflat, np.stack([tri[:, 0], tri[:, 0] + tri[:, 2]], 1)), host[which],
+                              np.stack([tri[:, 1], tri[:, 1] + tri[:, 2]], 1))
+            filled[which] += int(tri[:, 2].sum())
+        for k, fp in bufs.items():
+            used = sum(n for _, n in fp.offsets.values())
+            assert filled[k] == used, f"resharding load covered {filled[k]} of {used} elements of {k}"
+            fp.flat.copy_(host[k])
+        logger.info(f"resharded checkpoint load: tp{lay['tp']} pp{lay['pp']} vpp{lay.get('vpp', 1)} ep{lay.get('ep', 1)} "
+                    f"-> tp{g.tp} pp{g.pp} vpp{g.vpp} ep{g.ep}")
 
     def _expert_shard_file(self) -> str:
         g = self.grid
@@ -996,22 +992,28 @@ class NativeTrainEngine(TrainEngine):
         (replaces the funnel of ``areal/engine/fsdp_engine.py:399-433``)."""
         from ..ops import ipc
 
-        if self.model.flat_experts is not None:
-            raise NotImplementedError("peer-memory weight updates cover dense models; routed experts (their own flat "
-                                      "buffer, their own parallel groups) take the collective or disk transport")
         g = self.grid
         holds = self.zero3.param_shard if self.zero3 is not None else self.model.flat.flat
         if getattr(self, "_ipc_export", None) is None:
             self._ipc_export = ipc.export_buffer(holds)
-        descs = [self._ipc_export.desc]
+            # expert parallelism: the routed experts this rank holds live in a buffer of their own (they differ
+            # over the data-parallel ranks of a stage) and are exported next to the dense parameters
+            fe = self.model.flat_experts
+            self._ipc_export_experts = ipc.export_buffer(fe.flat) if fe is not None else None
+        ex = self._ipc_export_experts
+        mine = (self._ipc_export.desc, ex.desc if ex is not None else None)
+        pairs = [mine]
         if dist.is_initialized() and self.world_size > 1:
-            descs = [None] * self.world_size
-            dist.all_gather_object(descs, self._ipc_export.desc, group=g.group("world"))
+            pairs = [None] * self.world_size
+            dist.all_gather_object(pairs, mine, group=g.group("world"))
+        descs = [p[0] for p in pairs]
         name, off, shape = self.model.flat.specs[-1]
         used = (off + int(math.prod(shape))) * self.model.flat.flat.element_size()
         replicas = g.dp * g.cp  # ranks that hold the same (pp, tp) slice; ZeRO-3 cuts the slice over them instead
         src = dict(dp=replicas, tp=g.tp, pp=g.pp, vpp=g.vpp, vocab_parallel=bool(self.model.vocab_parallel),
                    zero3=replicas if self.zero3 is not None else 1)
+        if ex is not None:
+            src.update(ep=g.ep, etp=g.etp, cp=g.cp, expert_buffers=[p[1] for p in pairs])
         return dict(ipc_buffers=descs, ipc_layout=flat_layout_fingerprint(self.model), ipc_used_bytes=int(used),
                     ipc_src=src)
 
@@ -1020,6 +1022,8 @@ class NativeTrainEngine(TrainEngine):
         step's stream work; the trainer may then go on while the servers read) and says so: rank 0 posts the
         update key the client side waits for once every rank is ready."""
         self._ipc_export.refresh()
+        if self._ipc_export_experts is not None:
+            self._ipc_export_experts.refresh()
         if dist.is_initialized():
             dist.barrier(group=self.grid.group("world"))
         if self.rank == 0:

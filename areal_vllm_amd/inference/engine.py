@@ -647,7 +647,7 @@ class NativeInferenceEngine:
 
         flat = self.model.flat.flat
         sharded = bool(src) and (int(src.get("tp", 1)) > 1 or int(src.get("pp", 1)) > 1 or int(src.get("zero3", 1)) > 1
-                                 or self.tp_size > 1)
+                                 or int(src.get("ep", 1) or 1) > 1 or self.tp_size > 1)
         if not sharded:
             if buffer is None:
                 buffer = buffers[replica % len(buffers)]
@@ -719,22 +719,31 @@ class NativeInferenceEngine:
     def _pull_sharded(self, payload: Dict[str, Any], wait: bool):
         """This rank's ranges of the trainer ranks' exported buffers -> staging (current stream). The plan depends
         on the two layouts only: derived once, its device-side range lists kept for every later update."""
-        from ..parallel.param_realloc import Layout, derive_pull_plan
+        from ..parallel.param_realloc import Layout, derive_expert_parallel_pull_plan, derive_pull_plan
 
         src, buffers, replica = payload["src"], payload["buffers"], int(payload.get("replica", 0))
-        key = (repr(sorted(src.items())), replica, tuple(b["key"] for b in buffers))
+        experts = src.get("expert_buffers") or []
+        lay_items = sorted((k, v) for k, v in src.items() if k != "expert_buffers")
+        key = (repr(lay_items), replica, tuple(b["key"] for b in buffers), tuple(b["key"] for b in experts if b))
         cache = self.__dict__.setdefault("_ipc_plans", {})
         staging = self._staging()
         if key not in cache:
-            lay = Layout(dp=int(src.get("dp", 1)), tp=int(src.get("tp", 1)), pp=int(src.get("pp", 1)),
-                         vocab_parallel=bool(src.get("vocab_parallel", int(src.get("tp", 1)) > 1)),
-                         vpp=int(src.get("vpp", 1) or 1))
-            assert lay.world == len(buffers), f"trainer layout {lay} does not match {len(buffers)} exported buffers"
-            plan = derive_pull_plan(self.model_config, lay, self.tp_size, self.tp_rank, replica,
-                                    dtype=self.dtype, zero3=int(src.get("zero3", 1)))
             esz = staging.element_size()
-            cache[key] = [(self._peer(buffers[r]), self._peer(buffers[r]).prepare_moves(tri, esz, self.device))
-                          for r, tri in plan]
+            if int(src.get("ep", 1) or 1) > 1:  # expert-parallel trainer: two exported buffers per rank
+                assert len(experts) == len(buffers), "one expert buffer descriptor (or None) per trainer rank"
+                plan = derive_expert_parallel_pull_plan(self.model_config, dict(lay_items), self.tp_size, self.tp_rank,
+                                                        replica, dtype=self.dtype)
+                peers = [self._peer(buffers[r] if which == "flat" else experts[r]) for r, which, _ in plan]
+                cache[key] = [(pb, pb.prepare_moves(tri, esz, self.device)) for pb, (_, _, tri) in zip(peers, plan)]
+            else:
+                lay = Layout(dp=int(src.get("dp", 1)), tp=int(src.get("tp", 1)), pp=int(src.get("pp", 1)),
+                             vocab_parallel=bool(src.get("vocab_parallel", int(src.get("tp", 1)) > 1)),
+                             vpp=int(src.get("vpp", 1) or 1))
+                assert lay.world == len(buffers), f"trainer layout {lay} does not match {len(buffers)} exported buffers"
+                plan = derive_pull_plan(self.model_config, lay, self.tp_size, self.tp_rank, replica,
+                                        dtype=self.dtype, zero3=int(src.get("zero3", 1)))
+                cache[key] = [(self._peer(buffers[r]), self._peer(buffers[r]).prepare_moves(tri, esz, self.device))
+                              for r, tri in plan]
         for peer, prepared in cache[key]:
             peer.move_intervals(staging, prepared)
         if wait and self.device.type == "cuda":

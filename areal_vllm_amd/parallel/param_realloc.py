@@ -63,10 +63,14 @@ def _meta_shard(cfg: ModelConfig, lay: Layout, tp_rank: int, pp_rank: int, dtype
     return m
 
 
-def shard_pieces(model: Transformer) -> Dict[str, np.ndarray]:
-    """Global parameter name -> int64 array [n, 3] of (local_offset, full_offset, length) pieces."""
+def shard_pieces(model: Transformer, fp=None) -> Dict[str, np.ndarray]:
+    """Global parameter name -> int64 array [n, 3] of (local_offset, full_offset, length) pieces, for the
+    parameters of the flat buffer `fp` (the model's dense buffer by default; pass ``model.flat_experts`` for
+    the routed experts of an expert-parallel shard)."""
     cfg = model.cfg
+    fp = model.flat if fp is None else fp
     tp, tr = model.tp_size, model.tp_rank
+    etr = model.etp_rank  # routed experts are split over the expert tensor-parallel ranks (tp, or nobody)
     D, H = cfg.head_dim, cfg.hidden_size
     out: Dict[str, np.ndarray] = {}
 
@@ -77,7 +81,7 @@ def shard_pieces(model: Transformer) -> Dict[str, np.ndarray]:
         r = np.arange(n_rows, dtype=np.int64)
         return np.stack([off + r * local_w, r * full_w + col_lo, np.full(n_rows, local_w, dtype=np.int64)], 1)
 
-    for n, (off, numel) in model.flat.offsets.items():
+    for n, (off, numel) in fp.offsets.items():
         parts = n.split(".")
         leaf = parts[-1]
         if parts[0] == "layers":
@@ -105,20 +109,20 @@ def shard_pieces(model: Transformer) -> Dict[str, np.ndarray]:
         elif leaf == "down" and cfg.n_experts == 0:
             f = blk.mlp.down.shape[1]
             out[gname] = cols(off, H, f, cfg.intermediate_size, tr * f)
-        elif leaf == "gate_up":  # routed experts [E_local, 2f, H]; experts are not split over pipeline / tp here
+        elif leaf == "gate_up":  # routed experts [E_local, 2f, H]
             E, two_f, _ = blk.mlp.gate_up.shape
             f, F_ = two_f // 2, cfg.moe_intermediate_size
             e0 = blk.mlp.ep_rank * blk.mlp.n_local
             p = []
             for e in range(E):
                 base_l, base_f = off + e * two_f * H, (e0 + e) * 2 * F_ * H
-                p += [(base_l, base_f + tr * f * H, f * H), (base_l + f * H, base_f + (F_ + tr * f) * H, f * H)]
+                p += [(base_l, base_f + etr * f * H, f * H), (base_l + f * H, base_f + (F_ + etr * f) * H, f * H)]
             out[gname] = np.asarray(p, dtype=np.int64)
         elif leaf == "down":
             E, _, f = blk.mlp.down.shape
             F_ = cfg.moe_intermediate_size
             e0 = blk.mlp.ep_rank * blk.mlp.n_local
-            out[gname] = np.concatenate([cols(off + e * H * f, H, f, F_, tr * f) + np.array([0, (e0 + e) * H * F_, 0])
+            out[gname] = np.concatenate([cols(off + e * H * f, H, f, F_, etr * f) + np.array([0, (e0 + e) * H * F_, 0])
                                          for e in range(E)])
         elif model.vocab_parallel and (leaf == "embed" or (leaf == "head" and not cfg.is_critic)):
             v_lo, v_hi = model.vocab_range
@@ -162,10 +166,30 @@ def _intersect(src_pieces: np.ndarray, src_owner: np.ndarray, dst_pieces: np.nda
             ov_e - ov_s)
 
 
+def _match(dpieces: np.ndarray, cands: Sequence[np.ndarray]) -> Dict[int, np.ndarray]:
+    """Cover the destination pieces of one parameter from the pieces candidate source shards hold of it (in
+    order of preference: a range several candidates hold is taken from the first).
+    -> candidate index -> int64 [n, 3] of (source local offset, destination local offset, length)."""
+    seen, rows_, owner = set(), [], []
+    for ci, pieces in enumerate(cands):
+        for pc in pieces:
+            key = (int(pc[1]), int(pc[2]))
+            if key in seen:
+                continue
+            seen.add(key)
+            rows_.append(pc)
+            owner.append(ci)
+    sp = np.asarray(rows_, dtype=np.int64)
+    ow = np.asarray(owner, dtype=np.int64)
+    order = np.argsort(sp[:, 1], kind="stable")
+    sp, ow = sp[order], ow[order]
+    o, so, do, ln = _intersect(sp, ow, dpieces[np.argsort(dpieces[:, 1], kind="stable")])
+    return {int(ci): np.stack([so[o == ci], do[o == ci], ln[o == ci]], 1) for ci in np.unique(o)}
+
+
 def derive_realloc_plan(cfg: ModelConfig, src: Layout, dst: Layout, dtype=torch.bfloat16) -> List[Transfer]:
     """All transfers that turn the source layout's weights into the destination layout's, in a fixed order
     every process agrees on. Destination replica d pulls from source replica d % dp_src."""
-    assert cfg.n_experts == 0 or (src.pp == dst.pp == 1), "expert weights are re-allocated within one stage only"
     src_shards = {(p, t): shard_pieces(_meta_shard(cfg, src, t, p, dtype)) for p in range(src.pp) for t in range(src.tp)}
     tied = cfg.tie_word_embeddings and not cfg.is_critic
     plan: List[Transfer] = []
@@ -185,23 +209,8 @@ def derive_realloc_plan(cfg: ModelConfig, src: Layout, dst: Layout, dtype=torch.
                 # replicated pieces: prefer the source tp rank aligned with this destination rank
                 start = (dtp * src.tp) // dst.tp
                 cands.sort(key=lambda pt: (pt[0], (pt[1] - start) % src.tp))
-                seen, rows_, owner = set(), [], []
-                for ci, (p, t) in enumerate(cands):
-                    for pc in src_shards[(p, t)][lookup]:
-                        key = (int(pc[1]), int(pc[2]))
-                        if key in seen:
-                            continue
-                        seen.add(key)
-                        rows_.append(pc)
-                        owner.append(ci)
-                sp = np.asarray(rows_, dtype=np.int64)
-                ow = np.asarray(owner, dtype=np.int64)
-                order = np.argsort(sp[:, 1], kind="stable")
-                sp, ow = sp[order], ow[order]
-                o, so, do, ln = _intersect(sp, ow, dpieces[np.argsort(dpieces[:, 1], kind="stable")])
-                for ci in np.unique(o):
-                    m = o == ci
-                    seg.setdefault(cands[int(ci)], []).append(np.stack([so[m], do[m], ln[m]], 1))
+                for ci, a in _match(dpieces, [src_shards[pt][lookup] for pt in cands]).items():
+                    seg.setdefault(cands[ci], []).append(a)
             for (p, t), chunks in sorted(seg.items()):
                 a = np.concatenate(chunks)
                 a = a[np.argsort(a[:, 1], kind="stable")]
@@ -212,6 +221,127 @@ def derive_realloc_plan(cfg: ModelConfig, src: Layout, dst: Layout, dtype=torch.
                                          dst_intervals=np.stack([a[:, 1], a[:, 1] + a[:, 2]], 1)))
     plan.sort(key=lambda x: (x.dst, x.src))
     return plan
+
+
+def _layout_sources(cfg: ModelConfig, src: Dict[str, int], dtype) -> List[Tuple[int, int, Optional[int], Dict[str, np.ndarray]]]:
+    """Every distinct parameter buffer of a trainer laid out as `src` (tp, pp, vpp, ep, etp):
+    (pipeline stage, tp rank, expert-parallel rank or None for the dense buffer, pieces by parameter name).
+    Without expert parallelism the routed experts are part of the dense buffers; with it every (stage, expert
+    tensor-parallel rank, expert-parallel rank) has a buffer of its own."""
+    tp, pp, vpp = int(src["tp"]), int(src["pp"]), int(src.get("vpp", 1) or 1)
+    ep = int(src.get("ep", 1) or 1) if cfg.n_experts else 1
+    etp = int(src.get("etp", tp) or tp) if cfg.n_experts else tp
+    vocab_parallel = bool(src.get("vocab_parallel", tp > 1))
+
+    def twin(p, t, e):
+        lr, chunks = stage_layer_range(cfg.n_layers, pp, p), None
+        if vpp > 1:
+            lr, chunks = None, [stage_layer_range(cfg.n_layers, pp * vpp, c * pp + p) for c in range(vpp)]
+        m = Transformer(cfg, dtype=dtype, device="meta", tp_size=tp, tp_rank=t, layer_range=lr, layer_chunks=chunks,
+                        has_embed=p == 0, has_head=p == pp - 1, vocab_parallel=vocab_parallel, ep_size=ep, ep_rank=e,
+                        etp_size=etp)
+        m.flatten(expert_pad_to=1 if ep > 1 else None)
+        return m
+
+    out = []
+    for p in range(pp):
+        for t in range(tp):
+            m = twin(p, t, 0)
+            out.append((p, t, None, shard_pieces(m)))
+            if ep > 1 and (etp == tp or t == 0):
+                for e in range(ep):
+                    me = m if e == 0 else twin(p, t, e)
+                    out.append((p, t, e, shard_pieces(me, me.flat_experts)))
+    return out
+
+
+def _cover_from_sources(cfg: ModelConfig, sources, src_tp: int, model: Transformer) -> List[Tuple[int, str, np.ndarray]]:
+    """Cover the flat buffers of `model` from `sources` (``_layout_sources``).
+    -> [(index into sources, destination buffer "flat" | "flat_experts", int64 [n, 3] of (offset in the source
+    buffer, offset in the destination buffer, length))], sorted by source."""
+    tied = cfg.tie_word_embeddings and not cfg.is_critic
+    seg: Dict[Tuple[int, str], List[np.ndarray]] = {}
+    for which, fp in (("flat", model.flat), ("flat_experts", model.flat_experts)):
+        if fp is None:
+            continue
+        for gname, dpieces in shard_pieces(model, fp).items():
+            lookup = gname
+            cands = [i for i, sc in enumerate(sources) if lookup in sc[3]]
+            if not cands and gname == "head" and tied:  # tied LM head: the embedding is the source
+                lookup = "embed"
+                cands = [i for i, sc in enumerate(sources) if lookup in sc[3]]
+            if not cands:
+                raise RuntimeError(f"parameter {gname} does not exist in the source layout")
+            start = (model.tp_rank * src_tp) // model.tp_size  # replicated ranges: spread the reads over the sources
+            cands.sort(key=lambda i: (sources[i][0], (sources[i][1] - start) % src_tp, i))
+            for ci, a in _match(dpieces, [sources[i][3][lookup] for i in cands]).items():
+                seg.setdefault((cands[ci], which), []).append(a)
+    out = []
+    for (i, which), chunks in sorted(seg.items()):
+        a = np.concatenate(chunks)
+        out.append((i, which, a[np.argsort(a[:, 1], kind="stable")]))
+    return out
+
+
+def derive_file_load_plan(cfg: ModelConfig, src: Dict[str, int], model: Transformer
+                          ) -> List[Tuple[str, str, str, np.ndarray]]:
+    """What ONE rank reads from the files of a sharded checkpoint that was written under another layout.
+
+    `src`: the ``layout`` entry of the checkpoint's manifest (tp, pp, vpp, ep, etp); `model`: this rank's
+    (flattened) shard. -> [(file name, tensor key in that file, destination buffer ``"flat"`` |
+    ``"flat_experts"``, int64 [n, 3] of (offset in the file's tensor, offset in the destination buffer,
+    length), in elements)]. Routed experts are covered in every combination: a checkpoint written with expert
+    parallelism keeps them in their own files (one per pipeline stage, expert tensor-parallel rank and
+    expert-parallel rank), one written without keeps them inside the dense shards; the reader may hold them
+    either way (resharding load of ``areal/experimental/utils/megatron_checkpointer.py``)."""
+    sources = _layout_sources(cfg, dict(src, vocab_parallel=int(src["tp"]) > 1), model.dtype)
+    out = []
+    for i, which, tri in _cover_from_sources(cfg, sources, int(src["tp"]), model):
+        p, t, e, _ = sources[i]
+        if e is None:
+            out.append((f"shard-pp{p}-tp{t}.safetensors", "flat", which, tri))
+        else:
+            out.append((f"experts-pp{p}-tp{t}-ep{e}.safetensors", "flat_experts", which, tri))
+    return out
+
+
+def derive_expert_parallel_pull_plan(cfg: ModelConfig, src: Dict[str, int], dst_tp: int, dst_tp_rank: int,
+                                     replica: int = 0, dtype=torch.bfloat16) -> List[Tuple[int, str, np.ndarray]]:
+    """Pull plan of a rollout-server shard against a trainer WITH expert parallelism: its ranks export two buffers
+    each, the dense parameters (the same over the data-parallel ranks of a (pp, tp) slice) and the routed experts
+    they hold (which differ over the data-parallel ranks: expert-parallel rank = position in the expert grid of
+    the stage modulo ep). `src`: dp, cp, tp, pp, vpp, ep, etp, vocab_parallel of the trainer.
+    -> [(trainer rank in grid order, "flat" | "flat_experts" (which of that rank's buffers), int64 [n, 3] of
+    (offset in that buffer, offset in the server shard's flat buffer, length))]. Servers spread over the replicas
+    that hold the same shard by `replica`."""
+    tp, pp = int(src["tp"]), int(src["pp"])
+    cp = int(src.get("cp", 1) or 1)
+    dp = int(src["dp"]) // cp  # `dp` counts the ranks that hold the same dense slice: data x context parallel
+    ep, etp = int(src["ep"]), int(src.get("etp", tp) or tp)
+    key = ("ep", repr(cfg), repr(sorted(src.items())), dst_tp, dst_tp_rank, replica, str(dtype))
+    if key in _PULL_PLANS:
+        return _PULL_PLANS[key]
+    sources = _layout_sources(cfg, src, dtype)
+    dst = _meta_shard(cfg, Layout(dp=1, tp=dst_tp, pp=1, vocab_parallel=False), dst_tp_rank, 0, dtype)
+
+    def rank_of(p, d, t):
+        return ((p * dp + d) * cp) * tp + t
+
+    out = []
+    for i, _which, tri in _cover_from_sources(cfg, sources, tp, dst):
+        p, t, e, _ = sources[i]
+        if e is None:
+            r, buf = rank_of(p, replica % dp, t), "flat"
+        elif etp == tp:  # expert grid of a stage = its data-parallel ranks
+            r, buf = rank_of(p, e + ep * (replica % max(1, dp // ep)), t), "flat_experts"
+        else:  # whole experts: the grid runs over (dp x tp), tp fastest
+            slots = [s for s in range(dp * tp) if s % ep == e]
+            d, tt = divmod(slots[replica % len(slots)], tp)
+            r, buf = rank_of(p, d, tt), "flat_experts"
+        siv, div = _merged(np.stack([tri[:, 0], tri[:, 0] + tri[:, 2]], 1), np.stack([tri[:, 1], tri[:, 1] + tri[:, 2]], 1))
+        out.append((r, buf, np.stack([siv[:, 0], div[:, 0], siv[:, 1] - siv[:, 0]], 1).astype(np.int64)))
+    _PULL_PLANS[key] = out
+    return out
 
 
 def _merged(iv_src: np.ndarray, iv_dst: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:

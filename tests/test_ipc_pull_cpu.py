@@ -38,20 +38,29 @@ def _trainer_worker(rank, world, port, layout, out_dir):
     from areal_vllm_amd.models.transformer import Transformer
 
     layout = dict(layout)
-    cfg = TrainEngineConfig(experiment_name="t", trial_name="pull", path="tiny", init_from_scratch=True, dtype="float32",
+    preset_name = layout.pop("_preset", "tiny")
+    cfg = TrainEngineConfig(experiment_name="t", trial_name="pull", path=preset_name, init_from_scratch=True,
+                            dtype="float32",
                             optimizer=OptimizerConfig(lr=1e-2), mb_spec=MicroBatchSpec(max_tokens_per_mb=2048))
     cfg.native.zero_stage = layout.pop("_zero", 1)
     eng = NativeTrainEngine(cfg)
     eng.create_process_group(ParallelStrategy(**layout))
     eng.initialize(None, FinetuneSpec(1, 64, 8))
+    if eng.model.flat_experts is not None:
+        # equal seeds give the expert-parallel ranks equal expert values: make every rank's experts its own, so that
+        # a pull from the wrong rank shows (each expert shard has one holder in the layouts below)
+        eng.model.flat_experts.flat.add_(0.01 * (rank + 1))
     meta = eng.export_weight_buffers()
     assert len(meta["ipc_buffers"]) == world and meta["ipc_src"]["zero3"] == (world if cfg.native.zero_stage == 3 else 1)
     eng._ipc_export.refresh()
+    if eng._ipc_export_experts is not None:
+        assert meta["ipc_src"]["ep"] == eng.grid.ep and len(meta["ipc_src"]["expert_buffers"]) == world
+        eng._ipc_export_experts.refresh()
     ckpt = os.path.join(out_dir, "hf")
     eng.save(SaveLoadMeta(path=ckpt, weight_format="hf", with_optim=False))
     dist.barrier()
     if rank == 0:
-        srv = NativeInferenceEngine(InferenceServerConfig(model_path="tiny", dtype="float32", context_length=128,
+        srv = NativeInferenceEngine(InferenceServerConfig(model_path=preset_name, dtype="float32", context_length=128,
                                                           max_running_requests=4), device=torch.device("cpu"),
                                     num_pages=16).initialize(load_weights=False)
         info = srv.update_weights_from_ipc(None, "", 0, version=3, buffers=meta["ipc_buffers"], src=meta["ipc_src"])
@@ -72,6 +81,13 @@ def _trainer_worker(rank, world, port, layout, out_dir):
     ("zero3_dp2", 2, dict(data_parallel_size=2, _zero=3)),
     ("dp2", 2, dict(data_parallel_size=2)),
     ("tp2pp2", 4, dict(tensor_parallel_size=2, pipeline_parallel_size=2)),
+    # mixture-of-experts trainers: experts inside the dense buffers of two pipeline stages; expert-parallel ranks
+    # that export their experts as a second buffer (split over tp, and whole inside a tensor-parallel group)
+    ("moe_pp2", 2, dict(pipeline_parallel_size=2, _preset="tiny-moe")),
+    ("moe_dp2ep2", 2, dict(data_parallel_size=2, expert_parallel_size=2, _preset="tiny-moe")),
+    ("moe_dp2tp2ep2", 4, dict(data_parallel_size=2, tensor_parallel_size=2, expert_parallel_size=2, _preset="tiny-moe")),
+    ("moe_tp2ep2etp1", 2, dict(tensor_parallel_size=2, expert_parallel_size=2, expert_tensor_parallel_size=1,
+                               _preset="tiny-moe")),
 ])
 def test_unsharded_server_pulls_from_a_sharded_trainer(name, world, layout):
     out = tempfile.mkdtemp(prefix=f"areal_pull_{name}_")

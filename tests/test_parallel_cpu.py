@@ -89,6 +89,8 @@ def _worker(rank, world, port, strategy_kwargs, ckpt_in, ckpt_out, preset_name, 
     if reshard_from is not None:
         # load a sharded checkpoint written under ANOTHER (tp, pp) layout, write it back as HF
         eng.model.flat.flat.zero_()
+        if eng.model.flat_experts is not None:
+            eng.model.flat_experts.flat.zero_()
         eng.load(SaveLoadMeta(path=reshard_from, weight_format="dcp", with_optim=False))
         eng.save(SaveLoadMeta(path=ckpt_out, weight_format="hf", with_optim=False))
         eng.destroy()
@@ -268,6 +270,34 @@ def test_whole_experts_inside_a_tensor_parallel_group_match_single_process(name,
     _run(1, {}, init, ref, preset_name="tiny-moe")
     _run(world, kw, init, out, preset_name="tiny-moe")
     _compare(ref, out, atol=5e-5)
+
+
+def test_moe_sharded_checkpoint_loads_into_other_layouts():
+    """Sharded checkpoints of a mixture-of-experts model cross layouts in every direction: written with expert
+    parallelism (experts in their own files) and read without; written by pipeline stages and read by expert-parallel
+    ranks that split every expert over a tensor-parallel pair; written with whole experts inside a tensor-parallel
+    group and read by two pipeline stages. The hf export of the reader equals the hf export of the writer bit for bit."""
+    d = tempfile.mkdtemp(prefix="areal_moe_reshard_")
+    init = os.path.join(d, "init")
+    _run(1, {}, None, init, preset_name="tiny-moe")
+    writers = {"ep2": (2, dict(data_parallel_size=2, expert_parallel_size=2)),
+               "pp2": (2, dict(pipeline_parallel_size=2)),
+               "tp2ep2etp1": (2, dict(tensor_parallel_size=2, expert_parallel_size=2, expert_tensor_parallel_size=1))}
+    for name, (world, kw) in writers.items():
+        _run(world, kw, init, os.path.join(d, name), preset_name="tiny-moe")
+    readers = [("ep2", "to_single", 1, {}),
+               ("ep2", "to_tp2", 2, dict(tensor_parallel_size=2)),
+               ("pp2", "to_dp2tp2ep2", 4, dict(data_parallel_size=2, tensor_parallel_size=2, expert_parallel_size=2)),
+               ("tp2ep2etp1", "to_pp2", 2, dict(pipeline_parallel_size=2)),
+               ("pp2", "to_tp2ep2etp1", 2, dict(tensor_parallel_size=2, expert_parallel_size=2,
+                                                expert_tensor_parallel_size=1))]
+    for src, name, world, kw in readers:
+        out = os.path.join(d, f"{src}_{name}")
+        _run(world, dict(kw, _reshard_from=os.path.join(d, src, "sharded")), init, out, preset_name="tiny-moe")
+        a, b = _load_ckpt(os.path.join(d, src)), _load_ckpt(out)
+        assert set(a) == set(b), (src, name)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (src, name, k)
 
 
 def test_qk_norm_weights_under_tensor_parallel():
