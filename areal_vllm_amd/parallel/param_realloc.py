@@ -109,6 +109,12 @@ def shard_pieces(model: Transformer, fp=None) -> Dict[str, np.ndarray]:
         elif leaf == "down" and cfg.n_experts == 0:
             f = blk.mlp.down.shape[1]
             out[gname] = cols(off, H, f, cfg.intermediate_size, tr * f)
+        elif leaf in ("fc", "fc_bias"):  # ungated MLP (GPT-2): column-parallel rows, their bias with them
+            f, w = blk.mlp.fc.shape[0], (H if leaf == "fc" else 1)
+            out[gname] = np.asarray(rows(off, tr * f, f, w), dtype=np.int64)
+        elif leaf == "proj":  # its row-parallel output projection
+            f = blk.mlp.proj.shape[1]
+            out[gname] = cols(off, H, f, cfg.intermediate_size, tr * f)
         elif leaf == "gate_up":  # routed experts [E_local, 2f, H]
             E, two_f, _ = blk.mlp.gate_up.shape
             f, F_ = two_f // 2, cfg.moe_intermediate_size

@@ -1100,6 +1100,40 @@ def test_one_rank_rccl_group_runs_the_sharded_optimizers_collectives(tmp_path):
     assert z3["norms"] == pytest.approx(ref["norms"], rel=2e-2) and z3["ev"] == pytest.approx(ref["ev"], abs=2e-2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,world,layout", [
+    ("moe_dp2ep2", 2, dict(data_parallel_size=2, expert_parallel_size=2, _preset="tiny-moe")),
+    ("moe_tp2ep2etp1", 2, dict(tensor_parallel_size=2, expert_parallel_size=2, expert_tensor_parallel_size=1,
+                               _preset="tiny-moe")),
+    ("moe_pp2", 2, dict(pipeline_parallel_size=2, _preset="tiny-moe")),
+])
+def test_server_pulls_experts_from_expert_parallel_trainer_ranks_over_peer_memory(tmp_path, name, world, layout):
+    """Two trainer processes of a mixture-of-experts model on this GPU (expert-parallel: every rank exports its dense
+    parameters and ITS experts as two hipIpc buffers; pipeline stages: experts inside the stage buffers) and a rollout
+    engine that assembles its flat buffer from ranges of all of them with the interval kernel: bit-equal to the hf
+    checkpoint the trainer writes."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_ipc_pull_cpu import _trainer_worker
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, layout, str(tmp_path), True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(200)
+    alive = [p for p in procs if p.is_alive()]
+    for p in alive:
+        p.kill()
+    assert not alive and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
 def _rccl_graph_worker(port, force, out_path):
     os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0", AREAL_FORCE_COLLECTIVES="1" if force else "0")

@@ -22,9 +22,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _trainer_worker(rank, world, port, layout, out_dir):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo", AREAL_PLATFORM="cpu")
+def _trainer_worker(rank, world, port, layout, out_dir, gpu=False):
+    """`gpu`: all ranks (and the server) share device 0 - exported buffers are hipIpc handles, the server's interval
+    kernel reads the mapped peer memory; the trainer's collectives are staged through host memory (RCCL cannot put two
+    ranks on one device). Used by ``tests/test_engine_gpu.py``."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0" if gpu else str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    if gpu:
+        os.environ.update(AREAL_HOST_STAGED_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    else:
+        os.environ["AREAL_PLATFORM"] = "cpu"
     sys.path.insert(0, ROOT)
     torch.set_num_threads(1)
     import torch.distributed as dist
@@ -39,8 +46,9 @@ def _trainer_worker(rank, world, port, layout, out_dir):
 
     layout = dict(layout)
     preset_name = layout.pop("_preset", "tiny")
+    dtype = "bfloat16" if gpu else "float32"
     cfg = TrainEngineConfig(experiment_name="t", trial_name="pull", path=preset_name, init_from_scratch=True,
-                            dtype="float32",
+                            dtype=dtype,
                             optimizer=OptimizerConfig(lr=1e-2), mb_spec=MicroBatchSpec(max_tokens_per_mb=2048))
     cfg.native.zero_stage = layout.pop("_zero", 1)
     eng = NativeTrainEngine(cfg)
@@ -60,16 +68,18 @@ def _trainer_worker(rank, world, port, layout, out_dir):
     eng.save(SaveLoadMeta(path=ckpt, weight_format="hf", with_optim=False))
     dist.barrier()
     if rank == 0:
-        srv = NativeInferenceEngine(InferenceServerConfig(model_path=preset_name, dtype="float32", context_length=128,
-                                                          max_running_requests=4), device=torch.device("cpu"),
+        srv = NativeInferenceEngine(InferenceServerConfig(model_path=preset_name, dtype=dtype, context_length=128,
+                                                          max_running_requests=4),
+                                    device=torch.device("cuda:0" if gpu else "cpu"),
                                     num_pages=16).initialize(load_weights=False)
         info = srv.update_weights_from_ipc(None, "", 0, version=3, buffers=meta["ipc_buffers"], src=meta["ipc_src"])
         assert srv.get_version() == 3 and info["bytes"] > 0
-        ref = Transformer(eng.model_config, dtype=torch.float32, device="cpu")
+        ref = Transformer(eng.model_config, dtype=srv.model.flat.flat.dtype, device="cpu")
         ref.flatten()
         hf_io.load_hf_weights(ref, ckpt)
+        got = srv.model.flat.flat.cpu()
         for name, (o, numel) in ref.flat.offsets.items():
-            assert torch.equal(srv.model.flat.flat[o:o + numel], ref.flat.flat[o:o + numel]), name
+            assert torch.equal(got[o:o + numel], ref.flat.flat[o:o + numel]), name
         srv.destroy()
     dist.barrier()
     eng.destroy()

@@ -46,7 +46,7 @@ def _reference_shards(cfg, full, lay):
             assign_hf_named_tensors(m, tensors)
             if cfg.tie_word_embeddings and "head" in dict(m.named_parameters()):
                 v_lo, v_hi = m.vocab_range
-                m.head.data.copy_(tensors["model.embed_tokens.weight"][v_lo:v_hi])
+                m.head.data.copy_(full.embed.data[v_lo:v_hi])
             out[(pp, tp)] = m
     return out
 
@@ -82,6 +82,30 @@ def test_plan_matches_hf_sharding_and_round_trips(dst, tied):
     p2 = derive_realloc_plan(cfg, mid, one, dtype=torch.float32)
     back = {0: torch.full((full.flat.numel,), float("nan"))}
     _apply_locally(p2, mid_flats, back)
+    for n, (o, numel) in full.flat.offsets.items():
+        assert torch.equal(back[0][o:o + numel], full.flat.flat[o:o + numel]), n
+
+
+@pytest.mark.parametrize("name,dst", [("tiny-gpt2", Layout(1, 2, 1)), ("tiny-gpt2", Layout(1, 2, 2)),
+                                      ("tiny-moe", Layout(1, 2, 2)), ("tiny-moe", Layout(1, 1, 2))])
+def test_other_families_match_hf_sharding(name, dst):
+    """Ungated MLPs with biases (GPT-2) and routed experts (split over tp, spread over pipeline stages) against
+    the shards the HF-name based loader produces."""
+    cfg = preset(name)
+    full = _shard(cfg, Layout(), 0, 0)
+    full.init_weights(seed=4)
+    for n, p in full.named_parameters():
+        if n.endswith("bias"):
+            p.data.normal_(generator=torch.Generator().manual_seed(len(n)))
+    ref = _reference_shards(cfg, full, dst)
+    flats = {dst.index_of(pp, 0, tp): torch.full((ref[(pp, tp)].flat.numel,), float("nan"))
+             for pp in range(dst.pp) for tp in range(dst.tp)}
+    _apply_locally(derive_realloc_plan(cfg, Layout(), dst, dtype=torch.float32), {0: full.flat.flat}, flats)
+    for (pp, tp), want in ref.items():
+        for n, (o, numel) in want.flat.offsets.items():
+            assert torch.equal(flats[dst.index_of(pp, 0, tp)][o:o + numel], want.flat.flat[o:o + numel]), (pp, tp, n)
+    back = {0: torch.full((full.flat.numel,), float("nan"))}
+    _apply_locally(derive_realloc_plan(cfg, dst, Layout(), dtype=torch.float32), flats, back)
     for n, (o, numel) in full.flat.offsets.items():
         assert torch.equal(back[0][o:o + numel], full.flat.flat[o:o + numel]), n
 
