@@ -11,6 +11,7 @@ exporter owns a mirror segment and ``refresh()`` copies the tensor into it befor
 Role in the reference: the NCCL broadcast funnel of ``areal/engine/fsdp_engine.py:399-433``.
 """
 import ctypes
+import os
 from multiprocessing import shared_memory
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -21,6 +22,9 @@ from . import _lib as L
 
 
 CHUNK_BYTES = 1 << 30  # exported pieces stay well below 2 GiB: mapping a larger allocation hangs (see ipc.hip)
+
+
+_LOCAL_EXPORTS: Dict[str, "ExportedBuffer"] = {}  # device snapshots exported by this process, by descriptor key
 
 
 class ExportedBuffer:
@@ -51,8 +55,9 @@ class ExportedBuffer:
                 assert off.value == 0 and size.value < (1 << 31)
                 self._chunks.append((p.value, n))
                 pieces.append(dict(handle=bytes(handle).hex(), nbytes=n))
-            self.desc: Dict[str, Any] = dict(kind="hip", chunks=pieces, nbytes=self.nbytes,
+            self.desc: Dict[str, Any] = dict(kind="hip", chunks=pieces, nbytes=self.nbytes, pid=os.getpid(),
                                              device=int(t.device.index or 0), key=pieces[0]["handle"] if pieces else "")
+            _LOCAL_EXPORTS[self.desc["key"]] = self
         else:
             self._shm = shared_memory.SharedMemory(create=True, size=max(1, self.nbytes))
             self.desc = dict(kind="shm", name=self._shm.name, nbytes=self.nbytes, device=-1, key=self._shm.name)
@@ -73,6 +78,7 @@ class ExportedBuffer:
             torch.cuda.current_stream().synchronize()
 
     def close(self):
+        _LOCAL_EXPORTS.pop(self.desc.get("key"), None)
         for p, _ in self._chunks:
             L.lib().areal_ipc_free(ctypes.c_void_p(p))
         self._chunks = []
@@ -96,8 +102,15 @@ class PeerBuffer:
         self.desc = dict(desc)
         self.nbytes = int(desc["nbytes"])
         self._maps = []  # (mapped base pointer, nbytes)
+        self._own = False  # the pointers belong to an export of this process: nothing to unmap
         self._shm = None
-        if desc["kind"] == "hip":
+        local = _LOCAL_EXPORTS.get(desc.get("key")) if desc.get("pid") == os.getpid() else None
+        if desc["kind"] == "hip" and local is not None:
+            # exported by THIS process (a server that lives next to one of the trainer's ranks): the runtime refuses to
+            # open a handle in the process that made it, and there is nothing to map - use the snapshot's own pointers
+            self._maps = [(p, n) for p, n in local._chunks]
+            self._own = True
+        elif desc["kind"] == "hip":
             for piece in desc["chunks"]:
                 raw = bytes.fromhex(piece["handle"])
                 assert len(raw) == 64
@@ -167,7 +180,7 @@ class PeerBuffer:
                                                 L.stream_ptr()), "interval_move")
 
     def close(self):
-        for base, _ in self._maps:
+        for base, _ in ([] if self._own else self._maps):
             L.lib().areal_ipc_close(ctypes.c_void_p(base))
         self._maps = []
         if self._shm is not None:
