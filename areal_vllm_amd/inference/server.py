@@ -62,8 +62,8 @@ def parse_sampling_params(sp: Dict[str, Any], stop_to_ids=None) -> Dict[str, Any
     unknown = sorted(set(sp) - SAMPLING_KEYS)
     if unknown:
         raise BadRequest(f"unsupported sampling parameter(s) {unknown}; supported: {sorted(SAMPLING_KEYS)}")
-    if int(sp.get("n", 1)) != 1:
-        raise BadRequest("n > 1 is not supported: send one request per sample (they share the prompt's prefix cache)")
+    if not 1 <= int(1 if sp.get("n") is None else sp["n"]) <= 1024:
+        raise BadRequest("n: 1 .. 1024 samples per request")
     temp = float(sp.get("temperature", 1.0))
     top_k = int(sp.get("top_k", -1))
     seqs = [list(map(int, q)) for q in (sp.get("stop_sequences") or [])]
@@ -159,22 +159,34 @@ class InferenceServer:
                 multimodal = await self._offload(self._process_images, body["image_data"])
             except Exception as e:
                 return web.json_response({"error": f"cannot process image_data: {e!r}"}, status=400)
+        n = int((body.get("sampling_params") or {}).get("n", 1) or 1)
+        if n > 1 and body.get("stream"):
+            return web.json_response({"error": "streamed requests take n = 1"}, status=400)
         if body.get("stream"):
             return await self._generate_stream(req, rid, ids, multimodal, kw)
         stops = (body.get("sampling_params") or {}).get("stop") or []
         stops = [stops] if isinstance(stops, str) else [x for x in stops if x]
-        if stops and self._tokenizer:
-            res = await self._generate_until_text(f"{rid}-{uuid.uuid4().hex[:8]}", ids, multimodal, kw, stops)
-        else:
-            res = await self.engine.agenerate_once(f"{rid}-{uuid.uuid4().hex[:8]}", ids, multimodal=multimodal, **kw)
-        meta = {
-            "id": rid, "finish_reason": _finish(res.finish_reason), "prompt_tokens": res.prompt_len,
-            "completion_tokens": len(res.output_tokens),
-            "output_token_logprobs": [(lp, t, None) for lp, t in zip(res.output_logprobs, res.output_tokens)],
-            "output_versions": res.output_versions, "weight_version": self.engine.get_version(),
-            "e2e_latency": res.latency, "ttft": res.ttft,
-        }
-        return web.json_response({"text": "", "output_ids": res.output_tokens, "meta_info": meta})
+
+        async def one(i):
+            engine_rid = f"{rid}-{uuid.uuid4().hex[:8]}"
+            if stops and self._tokenizer:
+                res = await self._generate_until_text(engine_rid, ids, multimodal, kw, stops)
+            else:
+                res = await self.engine.agenerate_once(engine_rid, ids, multimodal=multimodal, **kw)
+            meta = {
+                "id": rid if n == 1 else f"{rid}-{i}", "finish_reason": _finish(res.finish_reason),
+                "prompt_tokens": res.prompt_len, "completion_tokens": len(res.output_tokens),
+                "output_token_logprobs": [(lp, t, None) for lp, t in zip(res.output_logprobs, res.output_tokens)],
+                "output_versions": res.output_versions, "weight_version": self.engine.get_version(),
+                "e2e_latency": res.latency, "ttft": res.ttft,
+            }
+            return {"text": "", "output_ids": res.output_tokens, "meta_info": meta}
+
+        if n == 1:
+            return web.json_response(await one(0))
+        # n samples of one prompt: n engine requests that share the prompt's pages through the prefix cache (the first
+        # one prefills, the others find the pages); the answer is a list, one entry per sample
+        return web.json_response(list(await asyncio.gather(*[one(i) for i in range(n)])))
 
     async def _generate_until_text(self, engine_rid, ids, multimodal, kw, stops: List[str]):
         """Generation that also ends where the DECODED output first contains one of the stop strings. The engine

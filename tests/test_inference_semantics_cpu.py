@@ -236,10 +236,24 @@ def _gen(url, sampling, **extra):
 def test_generate_rejects_what_it_cannot_honour(server):
     bad = _gen(server, {"max_new_tokens": 4, "repetition_penalty": 1.1, "beam_width": 4})
     assert bad.status_code == 400 and "repetition_penalty" in bad.json()["error"] and "beam_width" in bad.json()["error"]
-    assert _gen(server, {"max_new_tokens": 4, "n": 2}).status_code == 400
+    assert _gen(server, {"max_new_tokens": 4, "n": 2}, stream=True).status_code == 400
+    assert _gen(server, {"max_new_tokens": 4, "n": 0}).status_code == 400
     assert _gen(server, {"max_new_tokens": 4}, lora_path="x").status_code == 400
     no_tok = _gen(server, {"max_new_tokens": 4, "stop": ["</answer>"]})  # the preset has no tokenizer to map it with
     assert no_tok.status_code == 400 and "stop_sequences" in no_tok.json()["error"]
+
+
+def test_generate_returns_n_samples_of_one_prompt(server, eng):
+    """`n` samples per request (the list form of the reference servers' answer): sampled ones differ from each other,
+    greedy ones equal the single-sample answer, and the prompt is prefilled once (the others hit the prefix cache)."""
+    base = _gen(server, {"max_new_tokens": 12, "temperature": 0.0}).json()
+    out = _gen(server, {"max_new_tokens": 12, "temperature": 0.0, "n": 3}, rid="grp").json()
+    assert isinstance(out, list) and len(out) == 3
+    assert [o["meta_info"]["id"] for o in out] == ["grp-0", "grp-1", "grp-2"]
+    assert all(o["output_ids"] == base["output_ids"] for o in out)
+    hot = _gen(server, {"max_new_tokens": 12, "temperature": 1.5, "n": 4}).json()
+    assert len({tuple(o["output_ids"]) for o in hot}) > 1
+    assert all(len(o["meta_info"]["output_token_logprobs"]) == len(o["output_ids"]) for o in hot)
 
 
 def test_generate_honours_penalties_and_stop_sequences_over_http(server, eng):
