@@ -20,7 +20,7 @@ class ModelTrainEvalConfig:
     init_critic_from_actor: bool = False
     dtype: str = "bfloat16"
     gradient_checkpointing: bool = False
-    backend: str = "native_train"  # native_train | inference | mock_train | null
+    backend: str = "native_train"  # native_train | inference | native_generation (vllm, sglang) | mock_train | null
     optimizer: OptimizerConfig = dataclasses.field(default_factory=OptimizerConfig)
     tokenizer_path: Optional[str] = None
     # park the model's weights and optimizer state in pinned host memory whenever no function call runs on it

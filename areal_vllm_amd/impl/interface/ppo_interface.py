@@ -103,13 +103,15 @@ class PPOActorInterface(ModelInterface):
         """Synchronous PPO: answers come from a rollout engine living in this worker, fed with the
         trainer's current weights by one device copy of the flat parameter buffer; a tensor- / pipeline-parallel
         trainer generates through its own shards and stages instead."""
+        from ...impl.backend.native import GenerationEngineModule
         from ...inference.engine import NativeInferenceEngine
 
         eng = model.module
         eng.onload()
         g = self.gconfig
-        model_parallel = eng.grid.tp > 1 or eng.grid.pp > 1
-        if self._gen_engine is None and not model_parallel:
+        hosted = isinstance(eng, GenerationEngineModule)  # a generation-only model: its own engine, its own weights
+        model_parallel = not hosted and (eng.grid.tp > 1 or eng.grid.pp > 1)
+        if self._gen_engine is None and not model_parallel and not hosted:
             prompt_max = 2048
             srv = InferenceServerConfig(model_path="", dtype=eng.config.dtype, random_seed=1 + eng.grid.global_rank,
                                         context_length=prompt_max + g.max_new_tokens + 64, max_running_requests=256,
@@ -119,7 +121,7 @@ class PPOActorInterface(ModelInterface):
                 num_pages=None if eng.device.type == "cuda" else 1024,
                 kv_cache_gb=8.0 if eng.device.type == "cuda" else None)
             self._gen_engine.initialize(load_weights=False)
-        if not model_parallel:
+        if not model_parallel and not hosted:
             self._gen_engine.load_weights_from_trainer(eng.model, version=model.version.global_step)
         prompts = [p.data["packed_prompts"].tolist() for p in data.unpack()]
         best_of = self.generation_size is not None and self.generation_size > self.group_size
@@ -129,7 +131,9 @@ class PPOActorInterface(ModelInterface):
         for t in (mc.eos_token_id, mc.pad_token_id):
             if t is not None and t not in stops:
                 stops.append(int(t))
-        if model_parallel:
+        if hosted:
+            res = eng.generate_tokens(prompts, n, g, stops)
+        elif model_parallel:
             # a tensor- / pipeline-parallel trainer generates through its own stages and shards
             # (parallel/pipeline_generate.py; reference: realhf/impl/model/backend/pipe_runner.py:420-646)
             res = eng.generate([p for p in prompts for _ in range(n)], g, stop_token_ids=stops)

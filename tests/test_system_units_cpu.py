@@ -654,6 +654,60 @@ def test_best_of_k_keeps_the_highest_scored_longest_answers():
         PPOActorInterface(group_size=4, generation_size=2)
 
 
+def test_generation_only_model_under_the_reference_backend_names(tmp_path):
+    """A model worker's generation-only model (backend `vllm` / `sglang` in configurations written for the reference):
+    the PPO interface's generate call and the reference's ``module.generate`` convention both run on the hosted
+    rollout engine; weights arrive from a checkpoint directory."""
+    from types import SimpleNamespace
+
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters
+    from areal_vllm_amd.api.io_struct import FinetuneSpec
+    from areal_vllm_amd.impl.backend.native import GenerationEngineModule
+    from areal_vllm_amd.impl.interface.ppo_interface import PPOActorInterface
+    from areal_vllm_amd.models import hf_io
+    from areal_vllm_amd.models.config import preset
+    from areal_vllm_amd.models.transformer import Transformer
+    from areal_vllm_amd.system.data_api import SequenceSample
+    from areal_vllm_amd.system.model_api import (ALL_BACKEND_CLASSES, ModelAbstraction, ModelBackendAbstraction,
+                                                 make_backend, make_model)
+
+    model = make_model(ModelAbstraction("native", dict(path="tiny", init_from_scratch=True, dtype="float32")),
+                       "actor_gen", "cpu")
+    backend = make_backend(ModelBackendAbstraction("vllm", dict(max_num_seqs=8, max_model_len=256, hybrid_train=True)))
+    assert ALL_BACKEND_CLASSES["sglang"] is ALL_BACKEND_CLASSES["vllm"]
+    model = backend.initialize(model, FinetuneSpec(1, 8, 4))
+    try:
+        assert isinstance(model.module, GenerationEngineModule) and model.backend_name == "native_generation"
+        prompts = [[5, 9, 11, 200, 7], [3, 4, 5]]
+        data = SequenceSample.from_default(ids=["a", "b"], seqlens=[5, 3],
+                                           data=dict(packed_prompts=torch.tensor(sum(prompts, []))))
+        iface = PPOActorInterface(group_size=2, generation_config=dict(n_samples=2, max_new_tokens=6, greedy=True))
+        out = iface.generate(model, data, None)
+        lens = [x for g in out.seqlens["packed_input_ids"] for x in g]
+        assert len(lens) == 4 and all(6 <= n <= 11 for n in lens)
+        assert out.data["packed_logprobs"].numel() == sum(lens) - 4
+        first = out.data["packed_input_ids"][:lens[0]].tolist()
+        assert first[:5] == prompts[0]
+        # the reference's convention: padded ids and log-probs of the generated part only
+        tok = SimpleNamespace(eos_token_id=1, pad_token_id=0)
+        ids, lps, mask = model.module.generate(data, None, tok, GenerationHyperparameters(n_samples=1, max_new_tokens=6,
+                                                                                           greedy=True))
+        assert ids.shape == lps.shape and ids.shape[0] == 2 and mask is None
+        assert ids[0, :lens[0] - 5].tolist() == first[5:]
+        # new weights from a checkpoint directory change what is generated
+        other = Transformer(preset("tiny"), dtype=torch.float32, device="cpu")
+        other.flatten()
+        other.init_weights(seed=77)
+        wm = hf_io.save_hf_checkpoint(other, str(tmp_path / "ckpt"))
+        hf_io.finalize_hf_checkpoint(str(tmp_path / "ckpt"), other.cfg, [wm], None)
+        backend.load(model, str(tmp_path / "ckpt"))
+        ids2, _, _ = model.module.generate(data, None, tok, GenerationHyperparameters(n_samples=1, max_new_tokens=6,
+                                                                                      greedy=True))
+        assert ids2.tolist() != ids.tolist()
+    finally:
+        model.module.destroy()
+
+
 # ------------------------------------------------------------------------ slurm resource allocation
 SCONTROL = """NodeName=gpu01 Arch=x86_64 CoresPerSocket=64
    CPUAlloc=0 CPUTot=128 State=IDLE ThreadsPerCore=1
