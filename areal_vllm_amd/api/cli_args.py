@@ -271,9 +271,9 @@ class InferenceServerConfig:
         """Options that change what the server computes or where its memory lives, and that this engine
         does not implement, are errors - never silently ignored. (Options that only pick between
         third-party kernel back ends stay accepted: there is one HIP implementation.)"""
-        if str(self.kv_cache_dtype) not in ("auto", "bfloat16", "bf16"):
+        if str(self.kv_cache_dtype) not in ("auto", "bfloat16", "bf16", "fp8", "fp8_e4m3"):
             raise ValueError(f"kv_cache_dtype={self.kv_cache_dtype!r}: the paged KV cache is stored in the model "
-                             "dtype (bf16) only; use kv_cache_dtype=auto")
+                             "dtype (auto / bf16) or as e4m3 bytes with scale 1 (fp8 / fp8_e4m3)")
         if self.cpu_offload_gb and float(self.cpu_offload_gb) > 0:
             raise ValueError(f"cpu_offload_gb={self.cpu_offload_gb}: weights are resident in HBM (288 GB per GPU); "
                              "host offload of server weights is not implemented - use tensor parallelism instead")

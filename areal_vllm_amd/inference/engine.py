@@ -145,7 +145,8 @@ class NativeInferenceEngine:
             self.model.init_weights(seed=1)
         ctx = int(cfg.context_length or mc.max_position_embeddings)
         hkv = self.model.layers[0].attn.hkv
-        per_page = _kv_bytes_per_page(mc, len(self.model.layers), hkv, 2)
+        kv_fp8 = str(cfg.kv_cache_dtype) in ("fp8", "fp8_e4m3")
+        per_page = _kv_bytes_per_page(mc, len(self.model.layers), hkv, 1 if kv_fp8 else 2)
         if self._num_pages_arg is not None:
             num_pages = int(self._num_pages_arg)
         elif self._kv_cache_gb is not None:
@@ -161,7 +162,7 @@ class NativeInferenceEngine:
         self.decode_steps = max(1, int(cfg.num_continuous_decode_steps))
         self.runner = ModelRunner(self.model, num_pages, ctx, max_running, decode_steps=self.decode_steps,
                                   use_graph=not cfg.disable_cuda_graph, seed=int(cfg.random_seed),
-                                  buckets=cfg.cuda_graph_bs)
+                                  buckets=cfg.cuda_graph_bs, kv_dtype=torch.float8_e4m3fn if kv_fp8 else None)
         self.num_pages = num_pages
         self.runner.tune_decode_paths()
         if (self.tp_size > 1 and self.device.type == "cuda" and not cfg.disable_custom_all_reduce

@@ -39,7 +39,7 @@ DEFAULT_BUCKETS = [1, 2, 4, 8, 16, 24, 32, 48, 64, 96, 128, 160, 192, 256, 320, 
 class ModelRunner:
     def __init__(self, model: Transformer, num_pages: int, max_context: int, max_batch: int, decode_steps: int = 1,
                  use_graph: bool = True, seed: int = 1, buckets: Optional[List[int]] = None,
-                 fused_decode: Optional[bool] = None, n_stop_ids: int = 8):
+                 fused_decode: Optional[bool] = None, n_stop_ids: int = 8, kv_dtype: Optional[torch.dtype] = None):
         self.model = model
         self.cfg: ModelConfig = model.cfg
         self.device = next(model.parameters()).device
@@ -57,7 +57,8 @@ class ModelRunner:
         cfg = self.cfg
         self.hq = model.layers[0].attn.hq
         self.hkv = model.layers[0].attn.hkv
-        self.kv = [ops.alloc_kv_cache(num_pages, self.hkv, cfg.head_dim, self.dtype, self.device)
+        # kv_dtype: torch.float8_e4m3fn stores the cache as e4m3 bytes (None: the model's dtype)
+        self.kv = [ops.alloc_kv_cache(num_pages, self.hkv, cfg.head_dim, kv_dtype or self.dtype, self.device)
                    for _ in model.layers]
         if cfg.pos_embed == "rope":
             self.rope = model.rope(self.device)
@@ -368,7 +369,7 @@ class ModelRunner:
     def _alloc_static(self, Bp: int) -> Dict[str, torch.Tensor]:
         dev = self.device
         k = self.decode_steps
-        nsplit = ops.decode_num_splits(Bp, self.hkv, 4096)
+        nsplit = ops.decode_num_splits(Bp, self.hkv, 4096, fp8=ops.attention.is_fp8(self.kv[0][0]))
         st = dict(
             input_ids=torch.zeros(Bp, dtype=torch.int64, device=dev),
             positions=torch.zeros(Bp, dtype=torch.int32, device=dev),

@@ -270,8 +270,24 @@ def flash_attn_varlen(q, k, v, cu_q, cu_k, max_q, scale=None, causal=True):
 
 
 # ------------------------------------------------------------------------- paged KV cache ops
+FP8 = torch.float8_e4m3fn  # element type of an fp8 KV cache (``kv_cache_dtype=fp8_e4m3``)
+FP8_MAX = 448.0
+
+
+def is_fp8(cache: torch.Tensor) -> bool:
+    return cache.dtype == FP8
+
+
+def to_fp8(x: torch.Tensor) -> torch.Tensor:
+    """bf16 / fp32 -> e4m3 the way the kernels store it: round to nearest even, saturate at +-448."""
+    return x.float().clamp(-FP8_MAX, FP8_MAX).to(FP8)
+
+
 def alloc_kv_cache(num_pages: int, n_kv_heads: int, head_dim: int, dtype, device):
-    """K pages [P, Hkv, 32, D]; V pages [P, Hkv, D, 32] (transposed, see paged_attn.hip)."""
+    """K pages [P, Hkv, 32, D]; V pages [P, Hkv, D, 32] (transposed, see paged_attn.hip). `dtype`: the model's
+    compute dtype, or ``torch.float8_e4m3fn`` for a cache of e4m3 bytes (scale 1: post-rotary keys and values of
+    the supported families stay well inside +-448; half the bytes to stream per decoded token, twice the tokens
+    per GB; values are widened to bf16 inside the attention kernels, all arithmetic stays bf16 / fp32)."""
     k = torch.zeros(num_pages, n_kv_heads, PAGE_SIZE, head_dim, dtype=dtype, device=device)
     v = torch.zeros(num_pages, n_kv_heads, head_dim, PAGE_SIZE, dtype=dtype, device=device)
     return k, v
@@ -288,7 +304,7 @@ def rope_and_cache_write_(qkv, positions, slots, table, kcache, vcache, n_q_head
             L.lib().areal_rope_cache_write(
                 L.ptr(qkv), L.ptr(positions), L.ptr(slots), L.ptr(table.cos), L.ptr(table.sin), L.ptr(kcache),
                 L.ptr(vcache), L.c_int(T), L.c_int(n_q_heads), L.c_int(n_kv_heads), L.c_int(D),
-                L.c_int(table.max_pos), L.c_int(int(do_rope)), L.stream_ptr(),
+                L.c_int(table.max_pos), L.c_int(int(do_rope)), L.c_int(int(is_fp8(kcache))), L.stream_ptr(),
             ),
             "rope_cache_write",
         )
@@ -303,26 +319,35 @@ def rope_and_cache_write_(qkv, positions, slots, table, kcache, vcache, n_q_head
         off = (slots[ok] % PAGE_SIZE).long()
         kk = qkv[ok, n_q_heads:n_q_heads + n_kv_heads]  # [n, Hkv, D]
         vv = qkv[ok, n_q_heads + n_kv_heads:]
-        kcache[pg, :, off, :] = kk
-        vcache[pg, :, :, off] = vv
+        if is_fp8(kcache):  # index through the bytes: indexed assignment has no fp8 implementation
+            kcache.view(torch.uint8)[pg, :, off, :] = to_fp8(kk).view(torch.uint8)
+            vcache.view(torch.uint8)[pg, :, :, off] = to_fp8(vv).view(torch.uint8)
+        else:
+            kcache[pg, :, off, :] = kk
+            vcache[pg, :, :, off] = vv
     return qkv
 
 
 def cache_gather(kcache, vcache, slots):
-    """Read K, V of `slots` (int64 [N]) back as contiguous [N, Hkv, D] tensors."""
+    """Read K, V of `slots` (int64 [N]) back as contiguous [N, Hkv, D] tensors (bf16 from an fp8 cache)."""
     N = slots.numel()
     Hkv, D = kcache.shape[1], kcache.shape[3]
+    fp8 = is_fp8(kcache)
     if L.use_hip(kcache):
-        k = torch.empty(N, Hkv, D, dtype=kcache.dtype, device=kcache.device)
+        k = torch.empty(N, Hkv, D, dtype=torch.bfloat16 if fp8 else kcache.dtype, device=kcache.device)
         v = torch.empty_like(k)
         L.check(
             L.lib().areal_cache_gather(L.ptr(kcache), L.ptr(vcache), L.ptr(slots), L.ptr(k), L.ptr(v), L.c_int(N),
-                                       L.c_int(Hkv), L.c_int(D), L.c_int64(Hkv * D), L.stream_ptr()),
+                                       L.c_int(Hkv), L.c_int(D), L.c_int64(Hkv * D), L.c_int(int(fp8)),
+                                       L.stream_ptr()),
             "cache_gather",
         )
         return k, v
     pg = (slots // PAGE_SIZE).long()
     off = (slots % PAGE_SIZE).long()
+    if fp8:
+        return (kcache.view(torch.uint8)[pg, :, off, :].contiguous().view(FP8).to(torch.bfloat16),
+                vcache.view(torch.uint8)[pg, :, :, off].contiguous().view(FP8).to(torch.bfloat16))
     return kcache[pg, :, off, :].contiguous(), vcache[pg, :, :, off].contiguous()
 
 
@@ -346,7 +371,8 @@ def flash_attn_paged_prefill(q, kcache, vcache, block_tables, cu_q, cu_k, max_q:
     T, Hq, D = q.shape
     Hkv = kcache.shape[1]
     scale = float(scale) if scale is not None else 1.0 / math.sqrt(D)
-    if L.use_hip(q) and D == 128 and q.dtype == torch.bfloat16 and q.stride(2) == 1 and q.stride(1) == D:
+    if (L.use_hip(q) and D == 128 and q.dtype == torch.bfloat16 and q.stride(2) == 1 and q.stride(1) == D
+            and not is_fp8(kcache)):  # an fp8 cache is widened by the gather below
         assert block_tables.dtype == torch.int32 and block_tables.is_contiguous()
         assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
         out = torch.empty(T, Hq, D, dtype=q.dtype, device=q.device)
@@ -372,8 +398,12 @@ def paged_decode_ref(q, kcache, vcache, block_tables, context_lens, scale):
             continue
         npg = (n + PAGE_SIZE - 1) // PAGE_SIZE
         pages = block_tables[b, :npg].long()
-        kk = kcache[pages].permute(1, 0, 2, 3).reshape(Hkv, npg * PAGE_SIZE, D)[:, :n].float()
-        vv = vcache[pages].permute(1, 0, 3, 2).reshape(Hkv, npg * PAGE_SIZE, D)[:, :n].float()
+        if is_fp8(kcache):
+            kp, vp = kcache.view(torch.uint8)[pages].view(FP8), vcache.view(torch.uint8)[pages].view(FP8)
+        else:
+            kp, vp = kcache[pages], vcache[pages]
+        kk = kp.permute(1, 0, 2, 3).reshape(Hkv, npg * PAGE_SIZE, D)[:, :n].float()
+        vv = vp.permute(1, 0, 3, 2).reshape(Hkv, npg * PAGE_SIZE, D)[:, :n].float()
         kk = kk.repeat_interleave(G, 0)
         vv = vv.repeat_interleave(G, 0)
         s = torch.einsum("hd,hnd->hn", q[b].float(), kk) * scale
@@ -385,12 +415,17 @@ def paged_decode_ref(q, kcache, vcache, block_tables, context_lens, scale):
 # One workgroup per CU: measured on the decode graph (batch 32-384, context 640 and 1200) fewer, longer
 # KV ranges beat more splits - every split adds a partial result to write and the reduce kernel to run.
 DECODE_TARGET_WORKGROUPS = 256
+# An fp8 cache halves the bytes a wave has in flight per page: with one workgroup per CU the kernel is then bound by
+# load latency instead of bandwidth (128 rows x 8192 tokens: attention 3.6 ms at 256 workgroups, 2.8 at 512, 2.5 at
+# 1024 against 4.7 ms for the bf16 cache, which gains nothing from more workgroups).
+DECODE_TARGET_WORKGROUPS_FP8 = 1024
 
 
-def decode_num_splits(batch: int, n_kv_heads: int, max_context: int) -> int:
+def decode_num_splits(batch: int, n_kv_heads: int, max_context: int, fp8: bool = False) -> int:
     """Split the KV range so that roughly >= DECODE_TARGET_WORKGROUPS workgroups are in flight."""
     base = max(1, batch * n_kv_heads)
-    want = max(1, DECODE_TARGET_WORKGROUPS // base)
+    target = DECODE_TARGET_WORKGROUPS if DECODE_TARGET_WORKGROUPS != 256 or not fp8 else DECODE_TARGET_WORKGROUPS_FP8
+    want = max(1, target // base)
     max_useful = max(1, (max_context + 4 * PAGE_SIZE - 1) // (4 * PAGE_SIZE))
     return int(max(1, min(want, max_useful, 32)))
 
@@ -430,7 +465,7 @@ def paged_attention_decode(q, kcache, vcache, block_tables, context_lens, scale=
             L.ptr(q), L.ptr(kcache), L.ptr(vcache), L.ptr(block_tables), L.ptr(context_lens), L.ptr(out),
             L.ptr(part_o), L.ptr(part_ml), L.c_int(B), L.c_int(Hq), L.c_int(Hkv), L.c_int(D),
             L.c_int(block_tables.shape[1]), L.c_int(nsplit), L.c_float(scale), L.c_int(q_row_stride),
-            L.stream_ptr(),
+            L.c_int(int(is_fp8(kcache))), L.stream_ptr(),
         ),
         "paged_decode",
     )

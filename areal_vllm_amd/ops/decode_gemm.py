@@ -269,7 +269,8 @@ def splitk_rope_cache_write(slab: torch.Tensor, n_split: int, bias: Optional[tor
         L.ptr(slab), L.c_int(n_split), L.ptr(bias), L.ptr(positions), L.ptr(slots), L.ptr(table.cos), L.ptr(table.sin),
         L.ptr(q_out), L.ptr(kcache), L.ptr(vcache), L.c_int(T), L.c_int(n_q_heads), L.c_int(n_kv_heads),
         L.c_int(head_dim), L.c_int(table.max_pos), L.c_int(int(do_rope)), L.ptr(q_norm), L.ptr(k_norm),
-        L.c_float(float(norm_eps)), L.stream_ptr()), "splitk_rope_cache_write")
+        L.c_float(float(norm_eps)), L.c_int(int(kcache.dtype == torch.float8_e4m3fn)), L.stream_ptr()),
+        "splitk_rope_cache_write")
     return q_out
 
 
@@ -296,7 +297,8 @@ def dgemm_qkv_rope(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     assert w.shape == (Nq, K)
     if q_out is None:
         q_out = torch.empty(T, n_q_heads, head_dim, dtype=x.dtype, device=x.device)
-    if not L.use_hip(x) or head_dim % 64 != 0:
+    if not L.use_hip(x) or head_dim % 64 != 0 or kcache.dtype == torch.float8_e4m3fn:
+        # (the GEMM's epilogue writes bf16 caches only: an fp8 cache takes the library GEMM + the row kernel)
         from .attention import rope_and_cache_write_
 
         qkv = F.linear(x, w, bias).view(T, n_q_heads + 2 * n_kv_heads, head_dim).contiguous()

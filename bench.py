@@ -65,6 +65,9 @@ def parse_args():
     p.add_argument("--decode-steps", type=int, default=8)
     p.add_argument("--kv-cache-gb", type=float, default=24.0)
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e4m3"],
+                   help="element type of the rollout engine's KV cache. NOT the benchmark's recipe: fp8 is an opt-in "
+                        "serving option measured separately; such a run is labelled in `dtype` and `config`")
     p.add_argument("--gradient-checkpointing", action="store_true",
                    help="recompute block activations in the backward (long-context configurations)")
     p.add_argument("--eta", type=int, default=2, help="max_head_offpolicyness; 0 = synchronous RL")
@@ -139,7 +142,7 @@ def serve_rollouts(args, rank, local_rank, store):
                                 context_length=args.prompt_len_max + args.max_new_tokens + 64,
                                 max_running_requests=n_seqs * (args.eta + 1), max_prefill_tokens=32768,
                                 num_continuous_decode_steps=args.decode_steps, disable_cuda_graph=args.no_graph,
-                                schedule_policy="fcfs")
+                                schedule_policy="fcfs", kv_cache_dtype=args.kv_cache_dtype)
     mc = preset(args.model)
     engine = NativeInferenceEngine(srv, model_config=mc, device=dev, kv_cache_gb=args.kv_cache_gb if on_gpu else None,
                                    num_pages=None if on_gpu else 2048)
@@ -437,7 +440,7 @@ def run_rank(args):
                                 context_length=args.prompt_len_max + args.max_new_tokens + 64,
                                 max_running_requests=n_seqs_per_gpu * (args.eta + 1), max_prefill_tokens=32768,
                                 num_continuous_decode_steps=args.decode_steps, disable_cuda_graph=args.no_graph,
-                                schedule_policy="fcfs")
+                                schedule_policy="fcfs", kv_cache_dtype=args.kv_cache_dtype)
     if not decoupled:
         engine = NativeInferenceEngine(srv, model_config=actor.model_config, device=dev,
                                        kv_cache_gb=args.kv_cache_gb if on_gpu else None,
@@ -651,7 +654,8 @@ def run_rank(args):
             "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
             "higher_is_better": True, "scaling": "weak",
             # the reference publishes no samples/s figure for this configuration (nor any MI355X number)
-            "vs_baseline": None, "dtype": "bf16",
+            "vs_baseline": None,
+            "dtype": "bf16" if args.kv_cache_dtype == "auto" else f"bf16 compute, {args.kv_cache_dtype} KV cache",
             "data": "synthetic prompts, random-init weights",
             "gen_tokens_per_s": round(gen_tok / elapsed, 1), "e2e_tokens_per_s": round(tok_s, 1),
             "mean_seq_len": round(mean_len, 1), "mean_gen_len": round(gen_tok / max(1.0, samples), 1),
@@ -676,7 +680,8 @@ def run_rank(args):
                        "algo": "GRPO, decoupled PPO loss, recompute_logprob, ppo_n_minibatches=1"
                                + (", proximal log-probs fused into the training forward" if args.fuse_prox else ""),
                        "max_tokens_per_mb": args.max_tokens_per_mb, "decode_steps_per_plan": args.decode_steps,
-                       "gradient_checkpointing": bool(args.gradient_checkpointing)},
+                       "gradient_checkpointing": bool(args.gradient_checkpointing),
+                       "kv_cache_dtype": "bf16" if args.kv_cache_dtype == "auto" else args.kv_cache_dtype},
         }
         if args.profile_phases:
             print(json.dumps(phase), file=sys.stderr)

@@ -77,6 +77,42 @@ DEVINL float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 DEVINL bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 DEVINL void st8(bf16_t* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 
+// ---- fp8 (e4m3, the format of the gfx950 conversion instructions = torch.float8_e4m3fn) for the KV cache.
+// Values are clamped to the finite range (+-448) before the conversion; every fp8 value is exact in bf16.
+typedef unsigned char fp8_t;
+DEVINL float fp8_clamp(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+DEVINL unsigned pack_fp8x4(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(a), fp8_clamp(b), w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(c), fp8_clamp(d), w, true);
+  return (unsigned)w;
+}
+DEVINL fp8_t f2fp8(float x) { return (fp8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(x), 0.f, 0, false) & 0xff); }
+DEVINL u32x2 bf16x8_to_fp8(bf16x8 v) {
+  return (u32x2){pack_fp8x4(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])),
+                 pack_fp8x4(bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7]))};
+}
+DEVINL bf16x8 fp8x8_to_bf16(u32x2 w) {
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[0], false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[0], true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[1], false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)w[1], true);
+  return (bf16x8){f2bf(a[0]), f2bf(a[1]), f2bf(b[0]), f2bf(b[1]), f2bf(c[0]), f2bf(c[1]), f2bf(d[0]), f2bf(d[1])};
+}
+DEVINL float fp82f(fp8_t x) { return __builtin_amdgcn_cvt_pk_f32_fp8((int)x, false)[0]; }
+// 8 cache elements at element offset `i` of a cache of bf16 (FP8 = false) or fp8 (true) values, as bf16
+template <bool FP8>
+DEVINL bf16x8 ld8_cache(const void* base, size_t i) {
+  if (FP8) return fp8x8_to_bf16(*reinterpret_cast<const u32x2*>(reinterpret_cast<const fp8_t*>(base) + i));
+  return ld8(reinterpret_cast<const bf16_t*>(base) + i);
+}
+DEVINL void st8_cache(void* base, size_t i, bf16x8 v, int fp8) {
+  if (fp8) *reinterpret_cast<u32x2*>(reinterpret_cast<fp8_t*>(base) + i) = bf16x8_to_fp8(v);
+  else st8(reinterpret_cast<bf16_t*>(base) + i, v);
+}
+DEVINL void st1_cache(void* base, size_t i, float v, int fp8) {
+  if (fp8) reinterpret_cast<fp8_t*>(base)[i] = f2fp8(v);
+  else reinterpret_cast<bf16_t*>(base)[i] = f2bf(v);
+}
+
 // Block-wide sum for blocks of up to 1024 threads; `red` needs 16 floats of LDS.
 DEVINL float block_sum(float v, float* red) {
   v = wave_sum(v);

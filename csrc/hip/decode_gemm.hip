@@ -615,9 +615,9 @@ extern "C" int areal_splitk_residual_rmsnorm(const float* slab, int S, const voi
 __global__ __launch_bounds__(1024) void splitk_rope_cache_write_kernel(
     const float* __restrict__ slab, int S, const bf16_t* __restrict__ bias, const int* __restrict__ pos,
     const int64_t* __restrict__ slots, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-    bf16_t* __restrict__ q_out, bf16_t* __restrict__ kcache, bf16_t* __restrict__ vcache, int T, int Hq, int Hkv,
+    bf16_t* __restrict__ q_out, void* __restrict__ kcache, void* __restrict__ vcache, int T, int Hq, int Hkv,
     int D, int max_pos, int do_rope, const bf16_t* __restrict__ q_norm, const bf16_t* __restrict__ k_norm,
-    float norm_eps) {
+    float norm_eps, int fp8) {
   extern __shared__ __attribute__((aligned(16))) float rowbuf[];
   const int t = blockIdx.x;
   const int half = D >> 1;
@@ -713,16 +713,16 @@ __global__ __launch_bounds__(1024) void splitk_rope_cache_write_kernel(
       st8(qd + half, ohi);
     } else if (slot >= 0) {
       const int kh = head - Hq;
-      bf16_t* kd = kcache + (((size_t)page * Hkv + kh) * 32 + off) * D + sub * 8;
-      st8(kd, olo);
-      st8(kd + half, ohi);
+      const size_t kd = (((size_t)page * Hkv + kh) * 32 + off) * D + sub * 8;
+      st8_cache(kcache, kd, olo, fp8);
+      st8_cache(kcache, kd + half, ohi, fp8);
     }
   }
   if (slot >= 0) {
     const float* vrow = rowbuf + (Hq + Hkv) * D;
     for (int i = threadIdx.x; i < Hkv * D; i += blockDim.x) {
       const int vh = i / D, d = i % D;
-      vcache[(((size_t)page * Hkv + vh) * D + d) * 32 + off] = f2bf(vrow[i]);
+      st1_cache(vcache, (((size_t)page * Hkv + vh) * D + d) * 32 + off, vrow[i], fp8);
     }
   }
 }
@@ -731,7 +731,7 @@ extern "C" int areal_splitk_rope_cache_write(const float* slab, int S, const voi
                                              const int64_t* slots, const float* cos_t, const float* sin_t,
                                              void* q_out, void* kcache, void* vcache, int T, int Hq, int Hkv, int D,
                                              int max_pos, int do_rope, const void* q_norm, const void* k_norm,
-                                             float norm_eps, hipStream_t st) {
+                                             float norm_eps, int fp8, hipStream_t st) {
   if (T <= 0) return 0;
   const size_t lds = (size_t)(Hq + 2 * Hkv) * D * sizeof(float);
   if (D % 16 != 0 || S < 1 || lds > 64 * 1024) return -1;
@@ -741,7 +741,7 @@ extern "C" int areal_splitk_rope_cache_write(const float* slab, int S, const voi
   // flight at once (a second pass over the row would wait for the first one's loads)
   const int threads = std::min(1024, std::max(256, (((Hq + 2 * Hkv) * D / 4 + 63) / 64) * 64));
   hipLaunchKernelGGL(splitk_rope_cache_write_kernel, dim3(T), dim3(threads), lds, st, slab, S, (const bf16_t*)bias, pos,
-                     slots, cos_t, sin_t, (bf16_t*)q_out, (bf16_t*)kcache, (bf16_t*)vcache, T, Hq, Hkv, D, max_pos,
-                     do_rope, (const bf16_t*)q_norm, (const bf16_t*)k_norm, norm_eps);
+                     slots, cos_t, sin_t, (bf16_t*)q_out, kcache, vcache, T, Hq, Hkv, D, max_pos,
+                     do_rope, (const bf16_t*)q_norm, (const bf16_t*)k_norm, norm_eps, fp8);
   return (int)hipGetLastError();
 }

@@ -27,10 +27,12 @@ DEVINL f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 // K and V fragments in registers and runs one workgroup per SIMD set instead of two).
 // q: [B, Hq, D]; out: [B, Hq, D] when nsplit == 1 else partials.
 // part_o: [B, Hq, nsplit, D] fp32, part_ml: [B, Hq, nsplit, 2] (m in log2 units, l).
-template <int D>
+// FP8: the caches hold e4m3 bytes (same layouts); a lane fetches 8 bytes per fragment and widens them to bf16 in
+// registers - half the HBM traffic of the kernel, which is what bounds it at long contexts.
+template <int D, bool FP8>
 __global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void paged_decode_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kcache,
-    const bf16_t* __restrict__ vcache, const int* __restrict__ block_tables,
+    const bf16_t* __restrict__ q, const void* __restrict__ kcache,
+    const void* __restrict__ vcache, const int* __restrict__ block_tables,
     const int* __restrict__ context_lens, bf16_t* __restrict__ out, float* __restrict__ part_o,
     float* __restrict__ part_ml, int Hq, int Hkv, int max_pages, float scale_log2, int q_stride) {
   constexpr int KS = D / 32;  // k-steps of the QK product
@@ -63,19 +65,19 @@ __global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void paged_decode_kernel(
   const int* bt = block_tables + (size_t)b * max_pages;
   for (int p = p_beg + wid; p < p_end; p += 4) {
     const int page = bt[p];
-    const bf16_t* kp = kcache + ((size_t)page * Hkv + h) * PAGE * D;
-    const bf16_t* vp = vcache + ((size_t)page * Hkv + h) * D * PAGE;
+    const size_t kp = ((size_t)page * Hkv + h) * PAGE * D;  // element offsets of this page's K / V block
+    const size_t vp = ((size_t)page * Hkv + h) * D * PAGE;
     // issue all loads of the page up front (16 KiB per wave in flight)
     bf16x8 ka[KS], kb[KS], vt[DB];
     const int key_a = 8 * (col >> 2) + (col & 3);  // row `col` of tile a
     const int key_b = key_a + 4;                   // row `col` of tile b
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      ka[ks] = ld8(kp + key_a * D + ks * 32 + c * 8);
-      kb[ks] = ld8(kp + key_b * D + ks * 32 + c * 8);
+      ka[ks] = ld8_cache<FP8>(kcache, kp + key_a * D + ks * 32 + c * 8);
+      kb[ks] = ld8_cache<FP8>(kcache, kp + key_b * D + ks * 32 + c * 8);
     }
 #pragma unroll
-    for (int i = 0; i < DB; ++i) vt[i] = ld8(vp + (i * 16 + col) * PAGE + c * 8);
+    for (int i = 0; i < DB; ++i) vt[i] = ld8_cache<FP8>(vcache, vp + (i * 16 + col) * PAGE + c * 8);
 
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -207,36 +209,45 @@ __global__ void paged_decode_reduce_kernel(const float* __restrict__ part_o,
   out[(size_t)bh * D + d] = f2bf(ll > 0.f ? acc / ll : 0.f);
 }
 
+template <int D, bool FP8>
+static int launch_paged_decode(const void* q, const void* kcache, const void* vcache, const int* block_tables,
+                               const int* context_lens, void* out, float* part_o, float* part_ml, int B, int Hq, int Hkv,
+                               int max_pages, int nsplit, float scale_log2, int q_stride, hipStream_t st) {
+  const size_t lds = (size_t)(4 * 16 * (D + 4) + 2 * 4 * 16) * sizeof(float);
+  if (D == 256) {
+    static bool attr_set = false;  // 67 KiB of dynamic LDS: above the default limit
+    if (!attr_set) {
+      HIP_RET(hipFuncSetAttribute((const void*)paged_decode_kernel<D, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((paged_decode_kernel<D, FP8>), dim3(B, Hkv, nsplit), dim3(256), lds, st, (const bf16_t*)q, kcache,
+                     vcache, block_tables, context_lens, (bf16_t*)out, part_o, part_ml, Hq, Hkv, max_pages, scale_log2,
+                     q_stride);
+  return 0;
+}
+
+// fp8: the caches hold e4m3 bytes instead of bf16 values
 extern "C" int areal_paged_decode(const void* q, const void* kcache, const void* vcache,
                                   const int* block_tables, const int* context_lens, void* out,
                                   float* part_o, float* part_ml, int B, int Hq, int Hkv, int D,
-                                  int max_pages, int nsplit, float softmax_scale, int q_stride,
+                                  int max_pages, int nsplit, float softmax_scale, int q_stride, int fp8,
                                   hipStream_t st) {
   if (B == 0) return 0;
   if (Hq % Hkv != 0 || Hq / Hkv > 16) return -1;
   if (D != 128 && D != 64 && D != 256) return -2;
   if (nsplit < 1 || (nsplit > 1 && (!part_o || !part_ml))) return -3;
   const float scale_log2 = softmax_scale * 1.4426950408889634f;
-  const size_t lds = (size_t)(4 * 16 * (D + 4) + 2 * 4 * 16) * sizeof(float);
-  dim3 grid(B, Hkv, nsplit), block(256);
-  if (D == 256) {
-    static bool attr_set = false;  // 67 KiB of dynamic LDS: above the default limit
-    if (!attr_set) {
-      HIP_RET(hipFuncSetAttribute((const void*)paged_decode_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(paged_decode_kernel<256>, grid, block, lds, st, (const bf16_t*)q,
-                       (const bf16_t*)kcache, (const bf16_t*)vcache, block_tables, context_lens,
-                       (bf16_t*)out, part_o, part_ml, Hq, Hkv, max_pages, scale_log2, q_stride);
-  } else if (D == 128)
-    hipLaunchKernelGGL(paged_decode_kernel<128>, grid, block, lds, st, (const bf16_t*)q,
-                       (const bf16_t*)kcache, (const bf16_t*)vcache, block_tables, context_lens,
-                       (bf16_t*)out, part_o, part_ml, Hq, Hkv, max_pages, scale_log2, q_stride);
-  else
-    hipLaunchKernelGGL(paged_decode_kernel<64>, grid, block, lds, st, (const bf16_t*)q,
-                       (const bf16_t*)kcache, (const bf16_t*)vcache, block_tables, context_lens,
-                       (bf16_t*)out, part_o, part_ml, Hq, Hkv, max_pages, scale_log2, q_stride);
+  int rc = 0;
+#define PD(DD, F8)                                                                                                    \
+  rc = launch_paged_decode<DD, F8>(q, kcache, vcache, block_tables, context_lens, out, part_o, part_ml, B, Hq, Hkv,   \
+                                   max_pages, nsplit, scale_log2, q_stride, st)
+  if (D == 256) { if (fp8) PD(256, true); else PD(256, false); }
+  else if (D == 128) { if (fp8) PD(128, true); else PD(128, false); }
+  else { if (fp8) PD(64, true); else PD(64, false); }
+#undef PD
+  if (rc) return rc;
   if (nsplit > 1)
     hipLaunchKernelGGL(paged_decode_reduce_kernel, dim3(B * Hq), dim3(D), 0, st, part_o, part_ml,
                        (bf16_t*)out, nsplit, D);
@@ -251,8 +262,8 @@ extern "C" int areal_paged_decode(const void* q, const void* kcache, const void*
 // ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rope_cache_write_kernel(
     bf16_t* __restrict__ qkv, const int* __restrict__ pos, const int64_t* __restrict__ slots,
-    const float* __restrict__ cos_t, const float* __restrict__ sin_t, bf16_t* __restrict__ kcache,
-    bf16_t* __restrict__ vcache, int Hq, int Hkv, int D, int max_pos, int do_rope) {
+    const float* __restrict__ cos_t, const float* __restrict__ sin_t, void* __restrict__ kcache,
+    void* __restrict__ vcache, int Hq, int Hkv, int D, int max_pos, int do_rope, int fp8) {
   const int t = blockIdx.x;
   const int half = D >> 1;
   const int lph = half >> 3;  // lanes per head for the rotation
@@ -284,17 +295,17 @@ __global__ __launch_bounds__(256) void rope_cache_write_kernel(
     }
     if (head >= Hq && slot >= 0) {
       const int kh = head - Hq;
-      bf16_t* kd = kcache + (((size_t)page * Hkv + kh) * PAGE + off) * D + sub * 8;
-      st8(kd, lo);
-      st8(kd + half, hi);
+      const size_t kd = (((size_t)page * Hkv + kh) * PAGE + off) * D + sub * 8;
+      st8_cache(kcache, kd, lo, fp8);
+      st8_cache(kcache, kd + half, hi, fp8);
     }
   }
-  // phase 2: v heads -> transposed cache (2-byte scattered stores, stride 64 B)
+  // phase 2: v heads -> transposed cache (scattered element stores, one page row apart)
   if (slot >= 0) {
     const bf16_t* vrow = row + (size_t)(Hq + Hkv) * D;
     for (int i = threadIdx.x; i < Hkv * D; i += blockDim.x) {
       const int vh = i / D, d = i % D;
-      vcache[(((size_t)page * Hkv + vh) * D + d) * PAGE + off] = vrow[i];
+      st1_cache(vcache, (((size_t)page * Hkv + vh) * D + d) * PAGE + off, bf2f(vrow[i]), fp8);
     }
   }
 }
@@ -302,41 +313,47 @@ __global__ __launch_bounds__(256) void rope_cache_write_kernel(
 extern "C" int areal_rope_cache_write(void* qkv, const int* pos, const int64_t* slots,
                                       const float* cos_t, const float* sin_t, void* kcache,
                                       void* vcache, int T, int Hq, int Hkv, int D, int max_pos,
-                                      int do_rope, hipStream_t st) {
+                                      int do_rope, int fp8, hipStream_t st) {
   if (T == 0) return 0;
   if (D % 16 != 0) return -1;
   hipLaunchKernelGGL(rope_cache_write_kernel, dim3(T), dim3(256), 0, st, (bf16_t*)qkv, pos, slots,
-                     cos_t, sin_t, (bf16_t*)kcache, (bf16_t*)vcache, Hq, Hkv, D, max_pos, do_rope);
+                     cos_t, sin_t, kcache, vcache, Hq, Hkv, D, max_pos, do_rope, fp8);
   return (int)hipGetLastError();
 }
 
 // Gather cached K/V of token slots back into contiguous [N, Hkv, D] tensors (used when a
 // request extends a cached prefix: the prefix K/V are read from pages, the new tokens are
 // appended, and the varlen flash kernel runs over the concatenation).
-__global__ __launch_bounds__(256) void cache_gather_kernel(const bf16_t* __restrict__ kcache,
-                                                           const bf16_t* __restrict__ vcache,
+__global__ __launch_bounds__(256) void cache_gather_kernel(const void* __restrict__ kcache,
+                                                           const void* __restrict__ vcache,
                                                            const int64_t* __restrict__ slots,
                                                            bf16_t* __restrict__ k_out,
                                                            bf16_t* __restrict__ v_out, int Hkv, int D,
-                                                           int64_t out_stride) {
+                                                           int64_t out_stride, int fp8) {
   const int t = blockIdx.x;
   const int64_t slot = slots[t];
   const int64_t page = slot / PAGE;
   const int off = (int)(slot % PAGE);
   for (int i = threadIdx.x; i < Hkv * D; i += blockDim.x) {
     const int hh = i / D, d = i % D;
-    k_out[(size_t)t * out_stride + i] = kcache[(((size_t)page * Hkv + hh) * PAGE + off) * D + d];
-    v_out[(size_t)t * out_stride + i] = vcache[(((size_t)page * Hkv + hh) * D + d) * PAGE + off];
+    const size_t ki = (((size_t)page * Hkv + hh) * PAGE + off) * D + d;
+    const size_t vi = (((size_t)page * Hkv + hh) * D + d) * PAGE + off;
+    if (fp8) {
+      k_out[(size_t)t * out_stride + i] = f2bf(fp82f(reinterpret_cast<const fp8_t*>(kcache)[ki]));
+      v_out[(size_t)t * out_stride + i] = f2bf(fp82f(reinterpret_cast<const fp8_t*>(vcache)[vi]));
+    } else {
+      k_out[(size_t)t * out_stride + i] = reinterpret_cast<const bf16_t*>(kcache)[ki];
+      v_out[(size_t)t * out_stride + i] = reinterpret_cast<const bf16_t*>(vcache)[vi];
+    }
   }
 }
 
 extern "C" int areal_cache_gather(const void* kcache, const void* vcache, const int64_t* slots,
                                   void* k_out, void* v_out, int N, int Hkv, int D, int64_t out_stride,
-                                  hipStream_t st) {
+                                  int fp8, hipStream_t st) {
   if (N == 0) return 0;
-  hipLaunchKernelGGL(cache_gather_kernel, dim3(N), dim3(256), 0, st, (const bf16_t*)kcache,
-                     (const bf16_t*)vcache, slots, (bf16_t*)k_out, (bf16_t*)v_out, Hkv, D,
-                     out_stride);
+  hipLaunchKernelGGL(cache_gather_kernel, dim3(N), dim3(256), 0, st, kcache, vcache, slots, (bf16_t*)k_out,
+                     (bf16_t*)v_out, Hkv, D, out_stride, fp8);
   return (int)hipGetLastError();
 }
 

@@ -226,7 +226,7 @@ def test_gpt2_family_trains_on_gpu():
         eng.destroy()
 
 
-def _rollout_pair(model="small", decode_steps=4, pages=512):
+def _rollout_pair(model="small", decode_steps=4, pages=512, kv_cache_dtype="auto"):
     _env()
     from areal_vllm_amd.api.cli_args import (AdvNormConfig, InferenceEngineConfig, InferenceServerConfig,
                                              MicroBatchSpec, OptimizerConfig, PPOActorConfig)
@@ -245,7 +245,7 @@ def _rollout_pair(model="small", decode_steps=4, pages=512):
     actor.initialize(None, FinetuneSpec(1, 100, 4))
     dev = torch.device("cuda", 0)
     srv = InferenceServerConfig(model_path=model, dtype="bfloat16", context_length=1024, max_running_requests=32,
-                                num_continuous_decode_steps=decode_steps, random_seed=3)
+                                num_continuous_decode_steps=decode_steps, random_seed=3, kv_cache_dtype=kv_cache_dtype)
     eng = NativeInferenceEngine(srv, model_config=actor.model_config, device=dev, num_pages=pages)
     eng.initialize(load_weights=False)
     actor.connect_local_engine(eng)
@@ -294,6 +294,39 @@ def test_rollout_logprobs_match_trainer_recompute():
         assert torch.equal(eng.model.flat.flat, actor.model.flat.flat)
         b2 = ro.rollout_batch(prompts[:2], workflow=wf)
         assert torch.all(b2["versions"][b2["loss_mask"].bool()] == 1)
+    finally:
+        ro.destroy()
+        eng.destroy()
+        actor.destroy()
+
+
+def test_rollout_over_an_fp8_kv_cache_stays_close_to_the_trainer():
+    """`kv_cache_dtype=fp8_e4m3`: the captured decode graphs (row kernel and library-GEMM writer paths, split-KV
+    attention) and prefix-hit prefills run over a cache of e4m3 bytes. The behaviour log-probs of the samples stay
+    within the quantisation noise of the trainer's recomputation: a looser bound than the bf16 cache's, far from what
+    a broken cache layout would give (several nats)."""
+    from areal_vllm_amd.api.cli_args import GenerationHyperparameters
+    from areal_vllm_amd.workflow.rlvr import RLVRWorkflow
+
+    actor, eng, ro, meta, dev = _rollout_pair(kv_cache_dtype="fp8_e4m3")
+    try:
+        assert eng.runner.kv[0][0].dtype == torch.float8_e4m3fn
+        g = GenerationHyperparameters(n_samples=2, max_new_tokens=96, temperature=1.0, stop_token_ids=[1])
+        wf = RLVRWorkflow(lambda p, c, pi, ci, **kw: float(sum(ci) % 2), g, reward_in_process=True)
+        gen = torch.Generator().manual_seed(5)
+        prompts = [dict(input_ids=torch.randint(2, 4000, (n,), generator=gen).tolist())
+                   for n in (7, 40, 33, 90, 130, 17, 64, 255)]
+        batch = ro.rollout_batch(prompts, workflow=wf)
+        batch = {k: v.to(dev) if torch.is_tensor(v) else v for k, v in batch.items()}
+        lm = batch["loss_mask"].bool()
+        assert int(lm.sum()) > 16 * 40
+        prox = actor.compute_logp(batch)
+        behav = torch.roll(batch["logprobs"], -1, 1)
+        m = torch.roll(lm, -1, 1)
+        m[:, -1] = False
+        diff = (prox.float() - behav.float()).abs()[m]
+        assert float(diff.mean()) < 0.06, float(diff.mean())
+        assert float(diff.max()) < 1.0, float(diff.max())
     finally:
         ro.destroy()
         eng.destroy()

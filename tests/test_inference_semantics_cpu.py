@@ -18,6 +18,7 @@ from areal_vllm_amd.inference.engine import NativeInferenceEngine
 
 def _engine(**kw):
     cfg = InferenceServerConfig(model_path="tiny", dtype="float32", context_length=256,
+                                kv_cache_dtype=kw.pop("kv_cache_dtype", "auto"),
                                 max_running_requests=kw.pop("max_running", 8),
                                 num_continuous_decode_steps=kw.pop("decode_steps", 4),
                                 max_prefill_tokens=kw.pop("max_prefill_tokens", 4096))
@@ -199,6 +200,33 @@ def test_chunked_prefill_matches_whole_prompt_prefill():
     finally:
         whole.destroy()
         chunked.destroy()
+
+
+def test_fp8_kv_cache_serves_the_same_requests(eng):
+    """`kv_cache_dtype=fp8_e4m3`: keys and values rest as e4m3 bytes (half the cache bytes per token), prefill over
+    a cached prefix and decode read them widened. The behaviour log-probs stay close to the full-precision cache's,
+    a prefix hit reproduces the miss exactly, and both engines hold the same number of pages in half the memory."""
+    e8 = _engine(kv_cache_dtype="fp8_e4m3")
+    try:
+        k8, kf = e8.runner.kv[0][0], eng.runner.kv[0][0]
+        assert k8.dtype == torch.float8_e4m3fn and k8.shape == kf.shape
+        assert e8.runner.kv_cache_bytes() * kf.element_size() == eng.runner.kv_cache_bytes()
+        a = _greedy(e8, n=24)
+        b = _greedy(eng, n=24)
+        same = next((i for i, (x, y) in enumerate(zip(a.output_tokens, b.output_tokens)) if x != y), 24)
+        assert same >= 4  # the arg-max of a random tiny model may flip on a near tie later on
+        assert a.output_logprobs[:same] == pytest.approx(b.output_logprobs[:same], abs=0.05)
+        again = _greedy(e8, n=24)  # the prompt's pages are found in the prefix cache this time
+        assert again.output_tokens == a.output_tokens
+        assert again.output_logprobs == pytest.approx(a.output_logprobs, abs=1e-4)
+        long = list(range(3, 3 + 70))  # several pages, extended by a second request that shares them
+        first = e8.generate_blocking([long], max_new_tokens=4, greedy=True)[0]
+        ext = e8.generate_blocking([long + first.output_tokens[:2]], max_new_tokens=2, greedy=True)[0]
+        assert ext.output_tokens == first.output_tokens[2:4]
+    finally:
+        e8.destroy()
+    with pytest.raises(ValueError):
+        InferenceServerConfig(model_path="tiny", kv_cache_dtype="fp8_e5m2").reject_unsupported()
 
 
 # ------------------------------------------------------------------------------------ HTTP front end

@@ -349,6 +349,78 @@ def test_paged_decode_and_cache_write(Hq, Hkv, D, nsplit):
     _close(out.cpu(), ref, 2e-2, 2e-2, "paged decode")
 
 
+@pytest.mark.parametrize("Hq,Hkv,D", [(12, 2, 128), (28, 4, 128), (16, 2, 64), (8, 1, 256)])
+@pytest.mark.parametrize("nsplit", [1, 4])
+def test_fp8_kv_cache_writes_round_like_torch_and_decode_reads_them(Hq, Hkv, D, nsplit):
+    """KV cache of e4m3 bytes: both cache writers (the stand-alone rotate-and-write kernel, the split-K row kernel)
+    store exactly ``clamp(x, +-448).to(float8_e4m3fn)`` of the bf16 keys / values, the gather widens them back
+    exactly, and decode attention equals an fp32 reference over the widened cache (values beyond +-448 saturate)."""
+    torch.manual_seed(5)
+    B = 7
+    ctx = [1, 32, 33, 100, 257, 500, 77]
+    max_pages = (max(ctx) + 31) // 32
+    num_pages = 1 + sum((c + 31) // 32 for c in ctx)
+    kc, vc = ops.alloc_kv_cache(num_pages, Hkv, D, A.FP8, DEV)
+    kb, vb = ops.alloc_kv_cache(num_pages, Hkv, D, torch.bfloat16, DEV)
+    assert kc.element_size() == 1 and kc.shape == kb.shape
+    tab = ops.RotaryTable(D, 2048, 1e4, DEV)
+    bt = torch.zeros(B, max_pages, dtype=torch.int32, device=DEV)
+    nxt = 1
+    for b, c in enumerate(ctx):
+        n = (c + 31) // 32
+        pages = torch.arange(nxt, nxt + n, dtype=torch.int32)
+        nxt += n
+        bt[b, :n] = pages.to(DEV)
+        qkv = (3 * torch.randn(c, Hq + 2 * Hkv, D, device=DEV)).bfloat16()
+        qkv[0, Hq, :4] = torch.tensor([1000.0, -1000.0, 448.0, 1e-3], device=DEV).bfloat16()  # saturation, tiny values
+        pos = torch.arange(c, dtype=torch.int32, device=DEV)
+        slots = (pages.long()[pos.cpu().long() // 32] * 32 + pos.cpu().long() % 32).to(DEV)
+        q2 = qkv.clone()
+        ops.rope_and_cache_write_(qkv, pos, slots, tab, kc, vc, Hq, Hkv, do_rope=b % 2 == 0)
+        ops.rope_and_cache_write_(q2, pos, slots, tab, kb, vb, Hq, Hkv, do_rope=b % 2 == 0)
+        assert torch.equal(qkv, q2)  # the rotated q / k rows themselves stay bf16
+        kg, vg = ops.cache_gather(kc, vc, slots)
+        assert kg.dtype == torch.bfloat16
+        assert torch.equal(kg, A.to_fp8(qkv[:, Hq:Hq + Hkv]).to(torch.bfloat16))
+        assert torch.equal(vg, A.to_fp8(qkv[:, Hq + Hkv:]).to(torch.bfloat16))
+    # the whole cache is what torch's conversion makes of the bf16 cache
+    assert torch.equal(kc.view(torch.uint8), A.to_fp8(kb).view(torch.uint8))
+    assert torch.equal(vc.view(torch.uint8), A.to_fp8(vb).view(torch.uint8))
+    q = torch.randn(B, Hq, D, device=DEV).bfloat16()
+    cl = torch.tensor(ctx, dtype=torch.int32, device=DEV)
+    out = ops.paged_attention_decode(q, kc, vc, bt, cl, nsplit=nsplit)
+    ref = A.paged_decode_ref(q.cpu(), kc.cpu(), vc.cpu(), bt.cpu(), cl.cpu(), 1 / math.sqrt(D))
+    _close(out.cpu(), ref, 2e-2, 2e-2, "paged decode over an fp8 cache")
+    # prefill over a cached prefix widens the pages through the gather
+    cu = torch.tensor([0, 5], dtype=torch.int32, device=DEV)
+    cuk = torch.tensor([0, ctx[5]], dtype=torch.int32, device=DEV)
+    qp = torch.randn(5, Hq, D, device=DEV).bfloat16()
+    o8 = ops.flash_attn_paged_prefill(qp, kc, vc, bt[5:6].contiguous(), cu, cuk, 5)
+    kg, vg = ops.cache_gather(kc, vc, A.context_slots(bt[5:6], cuk))
+    ow, _ = ops.flash_attn_varlen(qp, kg, vg, cu, cuk, 5, causal=True)
+    assert torch.equal(o8, ow)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D", [(12, 2, 128), (16, 2, 64)])
+def test_splitk_row_kernel_writes_an_fp8_cache(Hq, Hkv, D):
+    torch.manual_seed(2)
+    T, S, P = 75, 4, 40
+    Nq = (Hq + 2 * Hkv) * D
+    slab = torch.randn(S, T, Nq, device=DEV)
+    bias = torch.randn(Nq, device=DEV).bfloat16()
+    pos = torch.randint(0, 900, (T,), device=DEV, dtype=torch.int32)
+    slots = torch.randperm(P * 32, device=DEV)[:T].long()
+    slots[3] = -1
+    table = NA.RotaryTable(D, 1024, 1e4, DEV)
+    kc, vc = A.alloc_kv_cache(P, Hkv, D, A.FP8, DEV)
+    kb, vb = A.alloc_kv_cache(P, Hkv, D, torch.bfloat16, DEV)
+    q = DG.splitk_rope_cache_write(slab, S, bias, pos, slots, table, kc, vc, Hq, Hkv, D)
+    qb = DG.splitk_rope_cache_write(slab, S, bias, pos, slots, table, kb, vb, Hq, Hkv, D)
+    assert torch.equal(q, qb)
+    assert torch.equal(kc.view(torch.uint8), A.to_fp8(kb).view(torch.uint8))
+    assert torch.equal(vc.view(torch.uint8), A.to_fp8(vb).view(torch.uint8))
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("V", [151936, 1000, 517])
 def test_logprob_entropy_fwd_bwd(dtype, V):

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kv-dtype", default="auto", choices=["auto", "fp8_e4m3"], help="element type of the KV cache")
     ap.add_argument("--target-wgs", type=int, default=0, help="override the split-KV workgroup target (experiment)")
     ap.add_argument("--lanes", type=int, default=1,
                     help="also time every batch split over this many runners (own KV cache, graphs and stream each, "
@@ -71,10 +72,15 @@ def main():
     grow = args.steps * (args.iters + 2)  # every plan appends `steps` tokens to every sequence
     pages_per_seq = (args.ctx + grow + PAGE_SIZE - 1) // PAGE_SIZE + 1
     runner = ModelRunner(model, maxb * pages_per_seq + 8, args.ctx + grow + 64, maxb, decode_steps=args.steps,
-                         use_graph=not args.no_graph, buckets=batches)
+                         use_graph=not args.no_graph, buckets=batches,
+                         kv_dtype=torch.float8_e4m3fn if args.kv_dtype == "fp8_e4m3" else None)
     for kc, vc in runner.kv:  # non-trivial cache contents (softmax over zeros is cheaper than real data)
-        kc.normal_(0, 0.5)
-        vc.normal_(0, 0.5)
+        if kc.dtype == torch.float8_e4m3fn:
+            kc.view(torch.uint8).random_(0, 0x78)  # finite positive e4m3 codes
+            vc.view(torch.uint8).random_(0, 0x40)
+        else:
+            kc.normal_(0, 0.5)
+            vc.normal_(0, 0.5)
     for B in batches:
         plans = [make_plan(B, args.ctx + i * args.steps, args.steps, runner.max_pages, cfg.vocab_size,
                            pages_per_seq=pages_per_seq) for i in range(args.iters + 1)]
