@@ -371,8 +371,7 @@ def flash_attn_paged_prefill(q, kcache, vcache, block_tables, cu_q, cu_k, max_q:
     T, Hq, D = q.shape
     Hkv = kcache.shape[1]
     scale = float(scale) if scale is not None else 1.0 / math.sqrt(D)
-    if (L.use_hip(q) and D == 128 and q.dtype == torch.bfloat16 and q.stride(2) == 1 and q.stride(1) == D
-            and not is_fp8(kcache)):  # an fp8 cache is widened by the gather below
+    if L.use_hip(q) and D == 128 and q.dtype == torch.bfloat16 and q.stride(2) == 1 and q.stride(1) == D:
         assert block_tables.dtype == torch.int32 and block_tables.is_contiguous()
         assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
         out = torch.empty(T, Hq, D, dtype=q.dtype, device=q.device)
@@ -380,7 +379,7 @@ def flash_attn_paged_prefill(q, kcache, vcache, block_tables, cu_q, cu_k, max_q:
             L.ptr(q), L.ptr(kcache), L.ptr(vcache), L.ptr(block_tables), L.c_int(block_tables.shape[1]), L.ptr(out),
             None, L.ptr(cu_q), L.ptr(cu_k), L.c_int(cu_q.numel() - 1), L.c_int(int(max_q)), L.c_int(T), L.c_int(Hq),
             L.c_int(Hkv), L.c_int(D), L.c_int64(q.stride(0)), L.c_int64(out.stride(0)), L.c_float(scale),
-            L.c_int(int(causal)), L.stream_ptr()), "flash_fwd_paged")
+            L.c_int(int(causal)), L.c_int(int(is_fp8(kcache))), L.stream_ptr()), "flash_fwd_paged")
         return out
     k, v = cache_gather(kcache, vcache, context_slots(block_tables, cu_k))
     out, _ = flash_attn_varlen(q, k, v, cu_q, cu_k, max_q, scale=scale, causal=causal)

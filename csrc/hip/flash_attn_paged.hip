@@ -19,8 +19,11 @@
 // flash_attn_with_kvcache at realhf/impl/model/modules/attn.py:272.
 #include "flash_tiles.hpp"
 
+// FP8: the caches hold e4m3 bytes (same layouts): a thread fetches 8 bytes per fragment and widens them to bf16 on the
+// way into LDS; everything behind the staging is the bf16 kernel.
+template <bool FP8>
 __global__ __launch_bounds__(256, 2) void flash_fwd_paged_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kcache, const bf16_t* __restrict__ vcache,
+    const bf16_t* __restrict__ q, const void* __restrict__ kcache, const void* __restrict__ vcache,
     const int* __restrict__ block_tables, int max_pages, bf16_t* __restrict__ o, float* __restrict__ lse,
     const int* __restrict__ cu_q, const int* __restrict__ cu_k, int64_t q_stride, int64_t o_stride, int Hq, int Hkv,
     int nbatch, int total_q, float scale_log2, int causal) {
@@ -83,12 +86,12 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_paged_kernel(
       int key = t * 64 + lrow + 16 * i;
       key = key < k_len ? key : k_len - 1;
       const int page = bt[key >> 5];
-      kreg[i] = ld8(kcache + (((size_t)page * Hkv + kvh) * 32 + (key & 31)) * D + lch * 8);
+      kreg[i] = ld8_cache<FP8>(kcache, (((size_t)page * Hkv + kvh) * 32 + (key & 31)) * D + lch * 8);
       const int id = tid + 256 * i;
       const int half = id >> 9, ch = (id >> 2) & 127, c16 = id & 3;
       int pg = t * 2 + half;
       pg = pg < last_page ? pg : last_page;
-      vreg[i] = ld8(vcache + (((size_t)bt[pg] * Hkv + kvh) * D + ch) * 32 + c16 * 8);
+      vreg[i] = ld8_cache<FP8>(vcache, (((size_t)bt[pg] * Hkv + kvh) * D + ch) * 32 + c16 * 8);
     }
   };
   auto store_tile = [&](int t) {
@@ -216,16 +219,20 @@ __global__ __launch_bounds__(256, 2) void flash_fwd_paged_kernel(
 extern "C" int areal_flash_fwd_paged(const void* q, const void* kcache, const void* vcache, const int* block_tables,
                                      int max_pages, void* o, float* lse, const int* cu_q, const int* cu_k, int B,
                                      int max_q, int total_q, int Hq, int Hkv, int D, int64_t q_stride,
-                                     int64_t o_stride, float softmax_scale, int causal, hipStream_t st) {
+                                     int64_t o_stride, float softmax_scale, int causal, int fp8, hipStream_t st) {
   if (B == 0 || max_q == 0) return 0;
   if (D != 128) return -1;
   if (Hq % Hkv != 0) return -2;
   if ((q_stride | o_stride) % 8 != 0) return -3;
   if (((uintptr_t)q | (uintptr_t)kcache | (uintptr_t)vcache | (uintptr_t)o) % 16 != 0) return -4;
+  const float scale_log2 = softmax_scale * 1.4426950408889634f;
   const int n_g_pad = (Hkv * B + 7) & ~7;
   dim3 grid((unsigned)(((max_q + 127) / 128) * (Hq / Hkv) * n_g_pad)), block(256);
-  hipLaunchKernelGGL(flash_fwd_paged_kernel, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)kcache,
-                     (const bf16_t*)vcache, block_tables, max_pages, (bf16_t*)o, lse, cu_q, cu_k, q_stride, o_stride, Hq,
-                     Hkv, B, total_q, softmax_scale * 1.4426950408889634f, causal);
+  if (fp8)
+    hipLaunchKernelGGL(flash_fwd_paged_kernel<true>, grid, block, 0, st, (const bf16_t*)q, kcache, vcache, block_tables,
+                       max_pages, (bf16_t*)o, lse, cu_q, cu_k, q_stride, o_stride, Hq, Hkv, B, total_q, scale_log2, causal);
+  else
+    hipLaunchKernelGGL(flash_fwd_paged_kernel<false>, grid, block, 0, st, (const bf16_t*)q, kcache, vcache, block_tables,
+                       max_pages, (bf16_t*)o, lse, cu_q, cu_k, q_stride, o_stride, Hq, Hkv, B, total_q, scale_log2, causal);
   return (int)hipGetLastError();
 }

@@ -391,14 +391,17 @@ def test_fp8_kv_cache_writes_round_like_torch_and_decode_reads_them(Hq, Hkv, D, 
     out = ops.paged_attention_decode(q, kc, vc, bt, cl, nsplit=nsplit)
     ref = A.paged_decode_ref(q.cpu(), kc.cpu(), vc.cpu(), bt.cpu(), cl.cpu(), 1 / math.sqrt(D))
     _close(out.cpu(), ref, 2e-2, 2e-2, "paged decode over an fp8 cache")
-    # prefill over a cached prefix widens the pages through the gather
-    cu = torch.tensor([0, 5], dtype=torch.int32, device=DEV)
-    cuk = torch.tensor([0, ctx[5]], dtype=torch.int32, device=DEV)
-    qp = torch.randn(5, Hq, D, device=DEV).bfloat16()
-    o8 = ops.flash_attn_paged_prefill(qp, kc, vc, bt[5:6].contiguous(), cu, cuk, 5)
-    kg, vg = ops.cache_gather(kc, vc, A.context_slots(bt[5:6], cuk))
-    ow, _ = ops.flash_attn_varlen(qp, kg, vg, cu, cuk, 5, causal=True)
-    assert torch.equal(o8, ow)
+    # prefill over cached prefixes: the paged kernel widens the pages itself (head size 128; others gather first)
+    rows = [5, 3, 4]  # requests 5, 3, 4 of the batch above with 5 / 40 / 130 query rows at the end of their contexts
+    nq = [5, 40, 130]
+    cu = torch.tensor([0, 5, 45, 175], dtype=torch.int32, device=DEV)
+    cuk = torch.tensor([0] + list(np.cumsum([ctx[r] for r in rows])), dtype=torch.int32, device=DEV)
+    qp = torch.randn(175, Hq, D, device=DEV).bfloat16()
+    btp = bt[rows].contiguous()
+    o8 = ops.flash_attn_paged_prefill(qp, kc, vc, btp, cu, cuk, max(nq))
+    kg, vg = ops.cache_gather(kc, vc, A.context_slots(btp, cuk))
+    ow, _ = A.attention_varlen_ref(qp.float(), kg.float(), vg.float(), cu, cuk, 1 / math.sqrt(D), True)
+    _close(o8, ow, 2e-2, 2e-2, "paged prefill over an fp8 cache")
 
 
 @pytest.mark.parametrize("Hq,Hkv,D", [(12, 2, 128), (16, 2, 64)])
