@@ -423,7 +423,7 @@ DECODE_TARGET_WORKGROUPS_FP8 = 1024
 def decode_num_splits(batch: int, n_kv_heads: int, max_context: int, fp8: bool = False) -> int:
     """Split the KV range so that roughly >= DECODE_TARGET_WORKGROUPS workgroups are in flight."""
     base = max(1, batch * n_kv_heads)
-    target = DECODE_TARGET_WORKGROUPS if DECODE_TARGET_WORKGROUPS != 256 or not fp8 else DECODE_TARGET_WORKGROUPS_FP8
+    target = DECODE_TARGET_WORKGROUPS_FP8 if fp8 else DECODE_TARGET_WORKGROUPS
     want = max(1, target // base)
     max_useful = max(1, (max_context + 4 * PAGE_SIZE - 1) // (4 * PAGE_SIZE))
     return int(max(1, min(want, max_useful, 32)))

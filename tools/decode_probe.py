@@ -58,7 +58,7 @@ def main():
     if args.target_wgs:
         from areal_vllm_amd.ops import attention as _att
 
-        _att.DECODE_TARGET_WORKGROUPS = args.target_wgs
+        _att.DECODE_TARGET_WORKGROUPS = _att.DECODE_TARGET_WORKGROUPS_FP8 = args.target_wgs
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     cfg = preset(args.model)
